@@ -1,0 +1,196 @@
+// Internal declarations shared by the HIP translation units of libdmpfold_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/dmpfold_hip.h"
+
+namespace dmp {
+
+constexpr int WIDTH = 512;     // GRU width
+constexpr int HID2 = 256;      // bidirectional GRU hidden per direction
+constexpr int CW = 128;        // pair trunk width
+constexpr int NBLOCK = 16;
+constexpr int STEM_OUT = 384;  // 128 * pool 3
+constexpr int STEM_IN = 955;
+constexpr int NS = 21;         // one-hot classes of the DCA features
+constexpr int GJ_NB = 128;     // Gauss-Jordan block size
+constexpr int CONV_TILE = 16;  // conv output tile edge
+constexpr int CONV_CC = 2;     // input channels per K stage
+constexpr int CONV_SPLIT = 4;  // 512 conv channels / 128 per workgroup
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define DMP_HIP(expr)                                                         \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) return ::dmp::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+#define DMP_LAUNCH_CHECK() DMP_HIP(hipGetLastError())
+#define DMP_ARG(cond, ...)                 \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::dmp::set_error(__VA_ARGS__);       \
+      return DMP_ERR_ARG;                  \
+    }                                      \
+  } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// padded activation geometry: interior [2, 2+L) in both axes, zero elsewhere
+inline int act_tiles(int L) { return cdiv(L, CONV_TILE); }
+inline int act_pitch(int L) { return act_tiles(L) * CONV_TILE + 4; }
+
+struct GruDirW {          // one direction of one layer of a sequence GRU
+  float* wihT = nullptr;  // [nin][3H]  (transposed, gate-major columns r|z|n)
+  float* whh = nullptr;   // [3H][H]    row-major as in the state_dict
+  float* bih = nullptr;   // [3H]
+  float* bhh = nullptr;   // [3H]
+  int nin = 0;
+};
+
+struct BlockW {
+  float* wpack = nullptr;  // [split 4][chunk 64][tap 25][cc 2][m 128]
+  float* bias = nullptr;   // [512]
+  float* gamma = nullptr;  // [128]
+  float* beta = nullptr;   // [128]
+  float* cse = nullptr;    // [128] channel gate sigma(W2 relu(W1 beta))
+  float* sse_w = nullptr;  // [128]
+  float sse_b = 0.f;
+};
+
+struct Weights {
+  bool ready = false;
+  std::map<std::string, std::vector<float>> host;          // raw tensors by key
+  std::map<std::string, std::vector<int64_t>> shapes;
+  // vertical GRU (transposed: [k][3*512])
+  float *v_wih0T = nullptr, *v_whh0T = nullptr, *v_wih1T = nullptr, *v_whh1T = nullptr;
+  float *v_b0 = nullptr, *v_b1 = nullptr;  // [4][512]: r(bi+bh), z(bi+bh), in(bi), hn(bh)
+  GruDirW hgru[2][2];                      // [layer][dir]
+  GruDirW cgru[3][2];
+  float* fc = nullptr;                     // [3][512]
+  float* stemT = nullptr;                  // [955][384]
+  float* stem_b = nullptr;                 // [384]
+  float* stem_wd = nullptr;                // [384] weights of channel 954
+  float *stem_gamma = nullptr, *stem_beta = nullptr;
+  BlockW blk[NBLOCK];
+  float* head_w = nullptr;                 // [2][128]
+  float head_b[2] = {0.f, 0.f};
+  std::vector<void*> allocs;
+};
+
+}  // namespace dmp
+
+struct dmp_ctx {
+  int device = 0;
+  int max_L = 0, max_N = 0;
+  int64_t bytes = 0;
+  dmp::Weights W;
+  std::vector<void*> allocs;
+
+  // feature builder
+  uint8_t* msa = nullptr;  // private copy is not needed; kept for packed words
+  uint32_t* msa_words = nullptr;
+  int* nbr_count = nullptr;
+  float* w = nullptr;
+  double* wsum = nullptr;   // [2]: sum w, (unused)
+  float* colmean = nullptr; // [21L]
+  float* xc = nullptr;      // [N][21L]
+  float* cov = nullptr;     // [D][D]
+  float *gj_p = nullptr, *gj_r = nullptr, *gj_c = nullptr;
+  float* contacts = nullptr;  // [L][L]
+  float* x3 = nullptr;
+  double* apc_sums = nullptr;  // [2L+1]
+  // sequence trunk
+  float* hT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [layer][parity][512][Lb]
+  float* vout = nullptr;    // [L][512]
+  float* seq_g = nullptr;   // [L][1536] input projections, both directions
+  float* seq_a = nullptr;   // [L][512]
+  float* seq_b = nullptr;   // [L][512]
+  float* emb = nullptr;     // [L][520]
+  float* mat1d = nullptr;   // [512][L]
+  // pair trunk
+  float* z0 = nullptr;      // [384][L][L]
+  float* dmap = nullptr;    // [L][L]
+  float* u = nullptr;       // [128][L][L]
+  float* xa = nullptr;      // padded activations
+  float* xb = nullptr;
+  float* xdense = nullptr;  // [128][L][L] scratch for the stage-level API
+  double* part = nullptr;   // [tiles][128][2]
+  double* stats = nullptr;  // [128][2]
+  float* ab = nullptr;      // [128][2] alpha, beta of the norm
+  float* head0 = nullptr;   // [L][L]
+  float* conf = nullptr;    // [L]
+  float* gram = nullptr;    // [L][L]
+  // coordinates
+  double* eig_a = nullptr;  // [L][L]
+  double* eig_ws = nullptr; // d, e, tau, lambda, z ...
+  float* mds = nullptr;     // [L][8]
+  float* ca = nullptr;      // [L][3]
+  float* best_ca = nullptr;
+  float* best_conf = nullptr;
+  float* best_mean = nullptr;  // [1]
+  float* conf_means = nullptr; // [P]
+  float* ca_pass = nullptr;    // [P][L][3]
+  float* best_ca_snapshot = nullptr;
+  int passes_done = 0;
+  int last_L = 0, last_N = 0;
+  int max_passes = 0;
+};
+
+namespace dmp {
+// ---- launchers implemented in the .hip files (all enqueue on `s`) -------------------------
+// gemm.hip : C[M x N] = alpha * op(A) * op(B) + beta * C, element strides given explicitly
+struct GemmArgs {
+  const float* A; int64_t sam, sak;   // A(m,k) = A[m*sam + k*sak]
+  const float* B; int64_t sbk, sbn;   // B(k,n) = B[k*sbk + n*sbn]
+  float* C; int64_t ldc;              // C(m,n) = C[m*ldc + n]
+  int M, N, K;
+  float alpha, beta;
+  const float* bias_n;                // optional, added per column n
+};
+int gemm_f32(const GemmArgs& g, hipStream_t s);
+
+// msa.hip
+int msa_weights(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_w, hipStream_t s);
+// dca.hip
+int cov_build(dmp_ctx* c, const uint8_t* d_msa, const float* d_w, int N, int L, float* d_cov,
+              hipStream_t s);
+int spd_inverse(dmp_ctx* c, float* d_A, int D, hipStream_t s);
+int dca_contacts(dmp_ctx* c, const float* d_inv, int L, float* d_contacts, hipStream_t s);
+// gru.hip
+int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s);
+int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hipStream_t s);
+// trunk.hip
+int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const float* d_contacts,
+                int L, float* d_z0, hipStream_t s);
+int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L, float* d_xpad,
+                       hipStream_t s);
+int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
+                          double* d_stats, hipStream_t s);
+int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
+                              const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s);
+int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
+                     hipStream_t s);
+int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);
+int act_unpad(const float* d_xpad, int L, float* d_dense, hipStream_t s);
+int act_clear(float* d_xpad, int L, hipStream_t s);
+// mds.hip
+int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s);
+// coords.hip
+int coord_fc(dmp_ctx* c, const float* d_g, int L, float* d_ca, hipStream_t s);
+int build_embed(const float* d_mat1d, const float* d_mds, int L, float* d_emb, hipStream_t s);
+int transpose_f32(const float* d_in, int R, int C, float* d_out, hipStream_t s);
+int pair_distances(const float* d_ca, int L, int clamp, float* d_dmap, hipStream_t s);
+int fill_f32(float* d, int64_t n, float v, hipStream_t s);
+int select_best(dmp_ctx* c, const float* d_conf, const float* d_ca, int L, int pass,
+                hipStream_t s);
+int refine_coords(float* d_ca, int L, int steps, hipStream_t s);
+int ca_to_backbone(const float* d_ca, const float* d_logit, int L, float* d_coords,
+                   float* d_conf_out, hipStream_t s);
+}  // namespace dmp

@@ -1,0 +1,114 @@
+// Generic float32 GEMM on the gfx950 f32 matrix cores (v_mfma_f32_32x32x2_f32).
+// Used for the covariance outer product, the Gauss-Jordan panel/trailing updates and the
+// GRU input projections.  Exact f32: an MFMA chain is bitwise an fmaf chain in k order.
+#include "common.h"
+
+namespace dmp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDS_PITCH = 132;
+
+template <bool A_MCONTIG, bool B_NCONTIG>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ float As[2][BK][LDS_PITCH];
+  __shared__ float Bs[2][BK][LDS_PITCH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  float ra[8], rb[8];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m, k;
+      if (A_MCONTIG) { m = tid & 127; k = (tid >> 7) + 2 * i; }
+      else           { k = tid & 15;  m = (tid >> 4) + 16 * i; }
+      const int gm = m0 + m, gk = k0 + k;
+      ra[i] = (gm < g.M && gk < g.K) ? g.A[(int64_t)gm * g.sam + (int64_t)gk * g.sak] : 0.f;
+      int n, kb;
+      if (B_NCONTIG) { n = tid & 127; kb = (tid >> 7) + 2 * i; }
+      else           { kb = tid & 15; n = (tid >> 4) + 16 * i; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      rb[i] = (gn < g.N && gkb < g.K) ? g.B[(int64_t)gkb * g.sbk + (int64_t)gn * g.sbn] : 0.f;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m, k;
+      if (A_MCONTIG) { m = tid & 127; k = (tid >> 7) + 2 * i; }
+      else           { k = tid & 15;  m = (tid >> 4) + 16 * i; }
+      As[buf][k][m] = ra[i];
+      int n, kb;
+      if (B_NCONTIG) { n = tid & 127; kb = (tid >> 7) + 2 * i; }
+      else           { kb = tid & 15; n = (tid >> 4) + 16 * i; }
+      Bs[buf][kb][n] = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (g.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    const int kk = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int k = 0; k < BK; k += 2) {
+      float a0 = As[buf][k + kk][wm * 64 + li];
+      float a1 = As[buf][k + kk][wm * 64 + 32 + li];
+      float b0 = Bs[buf][k + kk][wn * 64 + li];
+      float b1 = Bs[buf][k + kk][wn * 64 + 32 + li];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int hi = lane >> 5, col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = n0 + wn * 64 + j * 32 + col;
+      if (gn >= g.N) continue;
+      const float bn = g.bias_n ? g.bias_n[gn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (gm >= g.M) continue;
+        float* p = g.C + (int64_t)gm * g.ldc + gn;
+        float v = g.alpha * acc[i][j][r] + bn;
+        if (g.beta != 0.f) v += g.beta * *p;
+        *p = v;
+      }
+    }
+}
+
+int gemm_f32(const GemmArgs& g, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0) return DMP_OK;
+  dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
+  const bool am = (g.sam == 1), bn = (g.sbn == 1);
+  if (am && bn) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
+  else if (am && !bn) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
+  else if (!am && bn) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+}  // namespace dmp

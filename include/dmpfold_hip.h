@@ -1,0 +1,164 @@
+/*
+ * dmpfold_hip.h - C ABI of libdmpfold_hip.so: the DMPfold2 alignment -> coordinates
+ * hot path as hand-written HIP for MI355X (gfx950).
+ *
+ * The reference (psipred/DMPfold2) has no FFI / plugin interface: its boundary is the
+ * Python function dmpfold.aln_to_coords() (reference dmpfold/predict.py:74-158) whose
+ * arithmetic lives in PyTorch operator calls.  Every entry point below replaces the
+ * operator call sites named in its comment (file:line relative to the reference tree).
+ * The Python shim dmpfold2_amd/predict.py binds them with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `d_` = device pointer, `h_` = host pointer;
+ *   - every function returns 0 on success or a negative dmp_status; the message of the
+ *     last failure on the calling thread is dmp_last_error();
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only
+ *     enqueue work, they never synchronise unless stated;
+ *   - all floating point buffers are float32 row-major unless stated;
+ *   - one dmp_ctx per GPU and per host thread; contexts are independent.
+ */
+#ifndef DMPFOLD_HIP_H
+#define DMPFOLD_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMP_ABI_VERSION 1
+#define DMP_MAX_SEQS 3000 /* predict.py:130-132: deeper MSAs are truncated */
+
+typedef struct dmp_ctx dmp_ctx;
+
+typedef enum dmp_status {
+  DMP_OK = 0,
+  DMP_ERR_ARG = -1,     /* bad argument (sizes, NULL, L < 8 ...) */
+  DMP_ERR_HIP = -2,     /* a HIP runtime call failed */
+  DMP_ERR_WEIGHTS = -3, /* unknown key, wrong shape, or weights incomplete */
+  DMP_ERR_CAPACITY = -4 /* L or N exceeds what the context was created for */
+} dmp_status;
+
+int dmp_abi_version(void);
+const char* dmp_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------
+ * Allocates every device buffer the path needs for alignments up to max_N x max_L
+ * (max_N is clamped to DMP_MAX_SEQS).  No allocation happens after this call. */
+int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out);
+void dmp_ctx_destroy(dmp_ctx* ctx);
+/* bytes of device memory held by the context */
+int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
+
+/* ---- weights (the reference's state_dict ABI, network.py:182-215) ---------------------
+ * dmp_weights_set: hand over one tensor of GRUResNet(512,128).state_dict() by key, host
+ * float32, contiguous, with its shape (replaces load_state_dict, predict.py:98).
+ * dmp_weights_finalize: checks that all 184 tensors arrived and builds the packed device
+ * layouts the kernels read (transposed GRU matrices, K-major conv slabs, the cSE gate
+ * sigma(W2 relu(W1 beta)) of every block). */
+int dmp_weights_set(dmp_ctx* ctx, const char* key, const float* h_data, const int64_t* shape,
+                    int ndim);
+int dmp_weights_finalize(dmp_ctx* ctx);
+
+/* ---- host-side text -> residue codes (predict.py:124-128) -----------------------------
+ * Translates nbytes alignment characters to codes: ARNDCQEGHILKMFPSTWYV -> 0..19,
+ * BJOUXZ -> 20, '-' '.' -> 21, any other byte b -> (b - 65) mod 256.  Pure host code. */
+int dmp_msa_encode(const uint8_t* h_text, int64_t nbytes, uint8_t* h_codes);
+
+/* ---- feature builder ----------------------------------------------------------------- */
+/* reweight(), predict.py:32-37.  d_msa: N x L codes (uint8, 0..21). d_w: N floats.
+ * Integer exact: w[n] = 1 / #{m : #{l : min(a_nl,20)==min(a_ml,20)} > float32(L*0.8)}. */
+int dmp_msa_weights(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_w, void* stream);
+/* fast_dca() first half, predict.py:45-51: cov_reg (21L x 21L). */
+int dmp_cov_build(dmp_ctx* ctx, const uint8_t* d_msa, const float* d_w, int N, int L,
+                  float* d_cov, void* stream);
+/* torch.inverse, predict.py:53: in-place inverse of a symmetric positive definite D x D
+ * matrix (blocked Gauss-Jordan, fp32 MFMA trailing updates). */
+int dmp_spd_inverse(dmp_ctx* ctx, float* d_A, int D, void* stream);
+/* predict.py:58-60: APC-corrected contact channel (L x L) from the inverse covariance.
+ * The 441 coupling channels are never materialised: the stem reads d_inv in place. */
+int dmp_dca_contacts(dmp_ctx* ctx, const float* d_inv, int L, float* d_contacts, void* stream);
+
+/* ---- sequence trunk ------------------------------------------------------------------- */
+/* embed + vgru, network.py:223-224: 2-layer GRU down the alignment (time = N, batch = L);
+ * d_out: L x 512, top-layer state after the last row. */
+int dmp_gru_vertical(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_out,
+                     void* stream);
+/* hgru (which = 0; network.py:225, in T x 512) or coord_gru (which = 1; network.py:253,
+ * in T x 520): multi-layer bidirectional GRU along the sequence, batch 1.
+ * d_out: T x 512 (forward | reverse halves). */
+int dmp_gru_bidir(dmp_ctx* ctx, int which, const float* d_in, int T, float* d_out, void* stream);
+
+/* ---- pair trunk ------------------------------------------------------------------------ */
+/* network.py:227-229 + the input-independent part of the stem 1x1 convolution
+ * (network.py:25-27, 194): Z0[o,i,j] = b_o + sum_c W[o,c] m[c,i] m[c,j]
+ *   + sum_ab W[o,512+21a+b] inv[21i+a,21j+b] + W[o,953] contacts[i,j]   (o < 384).
+ * d_mat1d: 512 x L.  d_inv / d_contacts may both be NULL (single-sequence MSA: zero
+ * features, predict.py:139).  d_z0: 384 x L x L. */
+int dmp_stem_static(dmp_ctx* ctx, const float* d_mat1d, const float* d_inv,
+                    const float* d_contacts, int L, float* d_z0, void* stream);
+/* Rest of the stem for one trunk pass: + W[o,954]*dmap, max over channel triples,
+ * InstanceNorm (network.py:28-32).  d_dmap: L x L.  d_x: 128 x L x L. */
+int dmp_stem_update(dmp_ctx* ctx, const float* d_z0, const float* d_dmap, int L, float* d_x,
+                    void* stream);
+/* ResNet block `block` (1..16), network.py:94-103, as its two kernels:
+ * conv 5x5 (128->512) + bias + max over channel quadruples -> d_u (128 x L x L) and the
+ * per-channel sum / sum of squares (d_stats: 128 x 2 doubles) ... */
+int dmp_block_conv5x5_maxout(dmp_ctx* ctx, int block, const float* d_x, int L, float* d_u,
+                             double* d_stats, void* stream);
+/* ... then InstanceNorm, scSE gates and the residual add: d_out = d_x + y*(cSE + sSE). */
+int dmp_block_norm_scse_residual(dmp_ctx* ctx, int block, const float* d_u,
+                                 const double* d_stats, const float* d_x, int L, float* d_out,
+                                 void* stream);
+/* Head 1x1 conv (network.py:207) + network.py:237-246: d_conf (L) = row means of channel 1,
+ * d_M (L x L) = Gram matrix 0.5*(dm_0j^2 + dm_i0^2 - dm_ij^2) of dm = |sym(channel 0)|. */
+int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M,
+                  void* stream);
+/* One whole trunk pass on internal buffers: stem_update + 16 blocks + head_gram. */
+int dmp_trunk_pass(dmp_ctx* ctx, const float* d_z0, const float* d_dmap, int L, float* d_conf,
+                   float* d_M, void* stream);
+
+/* ---- coordinates ----------------------------------------------------------------------- */
+/* torch.symeig + scaling, network.py:247-250: the 8 algebraically largest eigenpairs of the
+ * symmetric d_M (upper triangle used), eigenvalues clamped to >= 1e-8, d_mds (L x 8) =
+ * V*sqrt(lambda) in ascending order.  Solved on the device in float64.  Sign rule: each
+ * eigenvector's largest-magnitude component is positive. */
+int dmp_eigh_top8(dmp_ctx* ctx, const float* d_M, int L, float* d_mds, void* stream);
+/* network.py:251-255: coord_gru on [mat1d^T | mds] then coord_fc -> d_ca (L x 3). */
+int dmp_coords_from_mds(dmp_ctx* ctx, const float* d_mat1d, const float* d_mds, int L,
+                        float* d_ca, void* stream);
+/* network.py:272: d_dmap[i,j] = sqrt(max(|ca_i - ca_j|^2, 1e-8)); clamp = 0 gives the
+ * template form of predict.py:143 (no clamp, zero diagonal). */
+int dmp_pair_distances(dmp_ctx* ctx, const float* d_ca, int L, int clamp, float* d_dmap,
+                       void* stream);
+/* refine_coords(), network.py:106-137, all steps in one launch; in place on d_ca (L x 3). */
+int dmp_refine_coords(dmp_ctx* ctx, float* d_ca, int L, int steps, void* stream);
+/* calpha_to_main_chain() + sigmoid, network.py:141-177, 311-312.
+ * d_coords: L x 5 x 3 (N, CA, C, O, CB); d_conf_out: L. */
+int dmp_ca_to_backbone(dmp_ctx* ctx, const float* d_ca, const float* d_conf_logit, int L,
+                       float* d_coords, float* d_conf_out, void* stream);
+
+/* ---- the whole path -------------------------------------------------------------------- */
+/* GRUResNet.forward + the feature glue of aln_to_coords (predict.py:134-153,
+ * network.py:218-314).  d_msa: N x L codes (N already capped).  d_template_ca: Lt x 3 or NULL
+ * (seed distance channel = -1).  nloops = recycling iterations, refine_steps = minimiser
+ * steps.  Outputs d_coords (L x 5 x 3) and d_conf (L).  No host synchronisation. */
+int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
+                int Lt, int nloops, int refine_steps, float* d_coords, float* d_conf,
+                void* stream);
+
+/* ---- introspection for tests and the benchmark ------------------------------------------- */
+/* After dmp_predict: copy an internal tensor to d_dst (device).  Names: "w", "contacts",
+ * "mat1d", "conf_means" (P floats), "ca_pass" (P x L x 3), "best_ca" (L x 3, before the final
+ * refinement).  Returns the number of floats written or a negative status. */
+int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t capacity,
+                        void* stream);
+/* Time the pair-trunk convolution kernel alone with HIP events on `stream`: runs `iters`
+ * launches of block `block` at length L on internal buffers, returns average ms per launch. */
+int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMPFOLD_HIP_H */
