@@ -1,0 +1,621 @@
+// extern "C" surface of libdmpfold_hip.so (see include/dmpfold_hip.h): context and weight
+// management, host-side residue encoding, stage-level entry points and the fused dmp_predict.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+
+namespace dmp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  return DMP_ERR_HIP;
+}
+
+template <typename T>
+static int dev_alloc(std::vector<void*>& pool, int64_t& bytes, T** out, int64_t count) {
+  void* p = nullptr;
+  const size_t sz = sizeof(T) * (size_t)(count > 0 ? count : 1);
+  hipError_t e = hipMalloc(&p, sz);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  pool.push_back(p);
+  bytes += (int64_t)sz;
+  *out = (T*)p;
+  return DMP_OK;
+}
+
+static int upload(std::vector<void*>& pool, int64_t& bytes, float** out, const std::vector<float>& h) {
+  int rc = dev_alloc(pool, bytes, out, (int64_t)h.size());
+  if (rc) return rc;
+  DMP_HIP(hipMemcpy(*out, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+  return DMP_OK;
+}
+
+struct KeySpec { std::string key; std::vector<int64_t> shape; };
+
+static std::vector<KeySpec> weight_spec() {
+  std::vector<KeySpec> s;
+  s.push_back({"embed.weight", {22, 22}});
+  auto gru = [&](const std::string& p, int nin, int hid, int layers, bool bidir) {
+    for (int l = 0; l < layers; ++l) {
+      const int lin = l == 0 ? nin : hid * (bidir ? 2 : 1);
+      for (int d = 0; d < (bidir ? 2 : 1); ++d) {
+        const std::string sfx = std::to_string(l) + (d ? "_reverse" : "");
+        s.push_back({p + ".weight_ih_l" + sfx, {3 * hid, lin}});
+        s.push_back({p + ".weight_hh_l" + sfx, {3 * hid, hid}});
+        s.push_back({p + ".bias_ih_l" + sfx, {3 * hid}});
+        s.push_back({p + ".bias_hh_l" + sfx, {3 * hid}});
+      }
+    }
+  };
+  gru("vgru", 22, 512, 2, false);
+  gru("hgru", 512, 256, 2, true);
+  s.push_back({"resnet.0.lin.weight", {STEM_OUT, STEM_IN, 1, 1}});
+  s.push_back({"resnet.0.lin.bias", {STEM_OUT}});
+  s.push_back({"resnet.0.norm.weight", {CW}});
+  s.push_back({"resnet.0.norm.bias", {CW}});
+  for (int k = 1; k <= NBLOCK; ++k) {
+    const std::string p = "resnet." + std::to_string(k);
+    s.push_back({p + ".layer1.lin.weight", {4 * CW, CW, 5, 5}});
+    s.push_back({p + ".layer1.lin.bias", {4 * CW}});
+    s.push_back({p + ".layer1.norm.weight", {CW}});
+    s.push_back({p + ".layer1.norm.bias", {CW}});
+    s.push_back({p + ".scSE.cSE.fc.0.weight", {CW / 16, CW}});
+    s.push_back({p + ".scSE.cSE.fc.2.weight", {CW, CW / 16}});
+    s.push_back({p + ".scSE.sSE.conv.weight", {1, CW, 1, 1}});
+    s.push_back({p + ".scSE.sSE.conv.bias", {1}});
+  }
+  s.push_back({"resnet.17.weight", {2, CW, 1, 1}});
+  s.push_back({"resnet.17.bias", {2}});
+  gru("coord_gru", 520, 256, 3, true);
+  s.push_back({"coord_fc.weight", {3, 512}});
+  return s;
+}
+
+static std::vector<float> transposed(const std::vector<float>& w, int rows, int cols, int pad_rows = 0) {
+  // w is [rows][cols]; returns [cols + pad_rows][rows]
+  std::vector<float> t((size_t)(cols + pad_rows) * rows, 0.f);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols + c];
+  return t;
+}
+
+static int pack_weights(dmp_ctx* c) {
+  Weights& W = c->W;
+  auto& H = W.host;
+  int64_t& bytes = c->bytes;
+  auto& pool = W.allocs;
+  int rc;
+  // vertical GRU
+  if ((rc = upload(pool, bytes, &W.v_wih0T, transposed(H["vgru.weight_ih_l0"], 1536, 22, 2)))) return rc;
+  if ((rc = upload(pool, bytes, &W.v_whh0T, transposed(H["vgru.weight_hh_l0"], 1536, 512)))) return rc;
+  if ((rc = upload(pool, bytes, &W.v_wih1T, transposed(H["vgru.weight_ih_l1"], 1536, 512)))) return rc;
+  if ((rc = upload(pool, bytes, &W.v_whh1T, transposed(H["vgru.weight_hh_l1"], 1536, 512)))) return rc;
+  for (int l = 0; l < 2; ++l) {
+    const auto& bi = H["vgru.bias_ih_l" + std::to_string(l)];
+    const auto& bh = H["vgru.bias_hh_l" + std::to_string(l)];
+    std::vector<float> b(4 * 512);
+    for (int j = 0; j < 512; ++j) {
+      b[j] = bi[j] + bh[j];
+      b[512 + j] = bi[512 + j] + bh[512 + j];
+      b[1024 + j] = bi[1024 + j];
+      b[1536 + j] = bh[1024 + j];
+    }
+    if ((rc = upload(pool, bytes, l == 0 ? &W.v_b0 : &W.v_b1, b))) return rc;
+  }
+  // sequence GRUs
+  auto seq = [&](const std::string& p, int layers, int nin0, GruDirW (*dst)[2]) -> int {
+    for (int l = 0; l < layers; ++l)
+      for (int d = 0; d < 2; ++d) {
+        const std::string sfx = std::to_string(l) + (d ? "_reverse" : "");
+        const int nin = l == 0 ? nin0 : 512;
+        GruDirW& g = dst[l][d];
+        g.nin = nin;
+        int r;
+        if ((r = upload(pool, bytes, &g.wihT, transposed(H[p + ".weight_ih_l" + sfx], 768, nin)))) return r;
+        if ((r = upload(pool, bytes, &g.whh, H[p + ".weight_hh_l" + sfx]))) return r;
+        if ((r = upload(pool, bytes, &g.bih, H[p + ".bias_ih_l" + sfx]))) return r;
+        if ((r = upload(pool, bytes, &g.bhh, H[p + ".bias_hh_l" + sfx]))) return r;
+      }
+    return DMP_OK;
+  };
+  if ((rc = seq("hgru", 2, 512, W.hgru))) return rc;
+  if ((rc = seq("coord_gru", 3, 520, W.cgru))) return rc;
+  if ((rc = upload(pool, bytes, &W.fc, H["coord_fc.weight"]))) return rc;
+  // stem
+  {
+    const auto& w = H["resnet.0.lin.weight"];   // [384][955]
+    if ((rc = upload(pool, bytes, &W.stemT, transposed(w, STEM_OUT, STEM_IN)))) return rc;
+    std::vector<float> wd(STEM_OUT);
+    for (int o = 0; o < STEM_OUT; ++o) wd[o] = w[(size_t)o * STEM_IN + (STEM_IN - 1)];
+    if ((rc = upload(pool, bytes, &W.stem_wd, wd))) return rc;
+    if ((rc = upload(pool, bytes, &W.stem_b, H["resnet.0.lin.bias"]))) return rc;
+    if ((rc = upload(pool, bytes, &W.stem_gamma, H["resnet.0.norm.weight"]))) return rc;
+    if ((rc = upload(pool, bytes, &W.stem_beta, H["resnet.0.norm.bias"]))) return rc;
+  }
+  // residual blocks
+  for (int k = 1; k <= NBLOCK; ++k) {
+    const std::string p = "resnet." + std::to_string(k);
+    BlockW& B = W.blk[k - 1];
+    const auto& w = H[p + ".layer1.lin.weight"];   // [512][128][5][5]
+    std::vector<float> pk((size_t)512 * 128 * 25);
+    for (int split = 0; split < CONV_SPLIT; ++split)
+      for (int chunk = 0; chunk < CW / CONV_CC; ++chunk)
+        for (int tap = 0; tap < 25; ++tap)
+          for (int cc = 0; cc < CONV_CC; ++cc)
+            for (int m = 0; m < 128; ++m) {
+              const int och = split * 128 + m, ich = chunk * CONV_CC + cc;
+              pk[((((size_t)split * (CW / CONV_CC) + chunk) * 25 + tap) * CONV_CC + cc) * 128 + m] =
+                  w[((size_t)och * 128 + ich) * 25 + tap];
+            }
+    if ((rc = upload(pool, bytes, &B.wpack, pk))) return rc;
+    if ((rc = upload(pool, bytes, &B.bias, H[p + ".layer1.lin.bias"]))) return rc;
+    if ((rc = upload(pool, bytes, &B.gamma, H[p + ".layer1.norm.weight"]))) return rc;
+    const auto& beta = H[p + ".layer1.norm.bias"];
+    if ((rc = upload(pool, bytes, &B.beta, beta))) return rc;
+    // cSE gate: avgpool(InstanceNorm(x)) == beta, so the gate is a constant of the weights
+    const auto& w1 = H[p + ".scSE.cSE.fc.0.weight"];   // [8][128]
+    const auto& w2 = H[p + ".scSE.cSE.fc.2.weight"];   // [128][8]
+    std::vector<float> hid(8), gate(128);
+    for (int r = 0; r < 8; ++r) {
+      float a = 0.f;
+      for (int q = 0; q < 128; ++q) a += w1[r * 128 + q] * beta[q];
+      hid[r] = a > 0.f ? a : 0.f;
+    }
+    for (int q = 0; q < 128; ++q) {
+      float a = 0.f;
+      for (int r = 0; r < 8; ++r) a += w2[q * 8 + r] * hid[r];
+      gate[q] = 1.0f / (1.0f + std::exp(-a));
+    }
+    if ((rc = upload(pool, bytes, &B.cse, gate))) return rc;
+    if ((rc = upload(pool, bytes, &B.sse_w, H[p + ".scSE.sSE.conv.weight"]))) return rc;
+    B.sse_b = H[p + ".scSE.sSE.conv.bias"][0];
+  }
+  if ((rc = upload(pool, bytes, &W.head_w, H["resnet.17.weight"]))) return rc;
+  W.head_b[0] = H["resnet.17.bias"][0];
+  W.head_b[1] = H["resnet.17.bias"][1];
+  return DMP_OK;
+}
+
+static int check_ready(dmp_ctx* c, int L, int N) {
+  if (!c) { set_error("null context"); return DMP_ERR_ARG; }
+  if (L > c->max_L || N > c->max_N) {
+    set_error("alignment %d x %d exceeds the context capacity %d x %d", N, L, c->max_N, c->max_L);
+    return DMP_ERR_CAPACITY;
+  }
+  return DMP_OK;
+}
+static int need_weights(dmp_ctx* c) {
+  if (!c->W.ready) { set_error("weights not finalized"); return DMP_ERR_WEIGHTS; }
+  return DMP_OK;
+}
+
+static int trunk_pass(dmp_ctx* c, const float* z0, const float* dmap, int L, float* d_conf,
+                      float* d_M, hipStream_t s) {
+  int rc;
+  float* cur = c->xa;
+  float* oth = c->xb;
+  if ((rc = stem_update_padded(c, z0, dmap, L, cur, s))) return rc;
+  for (int k = 1; k <= NBLOCK; ++k) {
+    if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
+      DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n], s));
+    }
+    if ((rc = conv5x5_maxout_padded(c, k, cur, L, c->u, c->stats, s, false))) return rc;
+    if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
+      DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n + 1], s));
+      c->prof_n += 2;
+    }
+    if ((rc = conv5x5_reduce_stats(c, L, c->stats, s))) return rc;
+    if ((rc = norm_scse_residual_padded(c, k, c->u, c->stats, cur, L, oth, s))) return rc;
+    std::swap(cur, oth);
+  }
+  return head_gram_padded(c, cur, L, d_conf, d_M, s);
+}
+
+static int coords_from_mds(dmp_ctx* c, const float* mat1d, const float* mds, int L, float* d_ca,
+                           hipStream_t s) {
+  int rc;
+  if ((rc = build_embed(mat1d, mds, L, c->emb, s))) return rc;
+  if ((rc = gru_bidir(c, 1, c->emb, L, c->seq_a, s))) return rc;
+  return coord_fc(c, c->seq_a, L, d_ca, s);
+}
+
+}  // namespace dmp
+
+using namespace dmp;
+
+extern "C" {
+
+int dmp_abi_version(void) { return DMP_ABI_VERSION; }
+const char* dmp_last_error(void) { return g_err; }
+
+int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
+  DMP_ARG(out != nullptr, "out is NULL");
+  DMP_ARG(max_L >= 8 && max_L <= 1280, "max_L must be in [8, 1280], got %d", max_L);
+  DMP_ARG(max_N >= 1, "max_N must be >= 1, got %d", max_N);
+  if (max_N > DMP_MAX_SEQS) max_N = DMP_MAX_SEQS;
+  DMP_HIP(hipSetDevice(device));
+  dmp_ctx* c = new dmp_ctx();
+  c->device = device;
+  c->max_L = max_L;
+  c->max_N = max_N;
+  c->max_passes = 128;
+  const int64_t L = max_L, N = max_N, D = NS * L, LL = L * L;
+  const int64_t Lb = round_up(max_L, 32), P = act_pitch(max_L), T = act_tiles(max_L);
+  int rc = 0;
+#define A_(field, count) if (!rc) rc = dev_alloc(c->allocs, c->bytes, &c->field, (count))
+  A_(msa_words, N * cdiv64(L, 4));
+  A_(nbr_count, N);
+  A_(w, N);
+  A_(wsum, 2);
+  A_(colmean, D);
+  A_(xc, N * D);
+  A_(cov, D * D);
+  A_(gj_p, GJ_NB * GJ_NB);
+  A_(gj_r, GJ_NB * D);
+  A_(gj_c, D * GJ_NB);
+  A_(contacts, LL);
+  A_(x3, LL);
+  A_(apc_sums, 2 * L + 1);
+  for (int l = 0; l < 2; ++l)
+    for (int p = 0; p < 2; ++p) A_(hT[l][p], (int64_t)WIDTH * Lb);
+  A_(vout, L * WIDTH);
+  A_(seq_g, L * 1536);
+  A_(seq_a, L * WIDTH);
+  A_(seq_b, L * WIDTH);
+  A_(emb, L * (WIDTH + 8));
+  A_(mat1d, L * WIDTH);
+  A_(z0, (int64_t)STEM_OUT * LL);
+  A_(dmap, LL);
+  A_(u, (int64_t)CW * LL);
+  A_(xa, (int64_t)CW * P * P);
+  A_(xb, (int64_t)CW * P * P);
+  A_(xdense, (int64_t)CW * LL);
+  A_(part, std::max<int64_t>(T * T, 8) * CW * 2);
+  A_(stats, CW * 2);
+  A_(ab, CW * 2);
+  A_(head0, LL);
+  A_(conf, L);
+  A_(gram, LL);
+  A_(eig_a, LL);
+  A_(eig_ws, 3 * L + 16 + 8 * L + 40 * L + LL);
+  A_(mds, L * 8);
+  A_(ca, L * 3);
+  A_(best_ca, L * 3);
+  A_(best_ca_snapshot, L * 3);
+  A_(best_conf, L);
+  A_(best_mean, 1);
+  A_(conf_means, c->max_passes);
+  A_(ca_pass, (int64_t)c->max_passes * L * 3);
+#undef A_
+  if (rc) { dmp_ctx_destroy(c); return rc; }
+  *out = c;
+  return DMP_OK;
+}
+
+void dmp_ctx_destroy(dmp_ctx* c) {
+  if (!c) return;
+  for (void* p : c->allocs) (void)hipFree(p);
+  for (void* p : c->W.allocs) (void)hipFree(p);
+  for (void* e : c->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
+  delete c;
+}
+
+int64_t dmp_ctx_device_bytes(const dmp_ctx* c) { return c ? c->bytes : 0; }
+
+int dmp_weights_set(dmp_ctx* c, const char* key, const float* h_data, const int64_t* shape, int ndim) {
+  DMP_ARG(c && key && h_data && shape, "null argument");
+  static const std::vector<KeySpec> spec = weight_spec();
+  for (const auto& k : spec) {
+    if (k.key != key) continue;
+    int64_t n = 1;
+    bool ok = (int)k.shape.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) { ok = (shape[i] == k.shape[i]); n *= shape[i]; }
+    if (!ok) { set_error("size mismatch for %s", key); return DMP_ERR_WEIGHTS; }
+    c->W.host[key].assign(h_data, h_data + n);
+    c->W.ready = false;
+    return DMP_OK;
+  }
+  set_error("unexpected key %s in state_dict", key);
+  return DMP_ERR_WEIGHTS;
+}
+
+int dmp_weights_finalize(dmp_ctx* c) {
+  DMP_ARG(c != nullptr, "null context");
+  static const std::vector<KeySpec> spec = weight_spec();
+  for (const auto& k : spec)
+    if (!c->W.host.count(k.key)) { set_error("missing key %s in state_dict", k.key.c_str()); return DMP_ERR_WEIGHTS; }
+  DMP_HIP(hipSetDevice(c->device));
+  for (void* p : c->W.allocs) { (void)hipFree(p); }
+  c->W.allocs.clear();
+  int rc = pack_weights(c);
+  if (rc) return rc;
+  c->W.host.clear();
+  c->W.ready = true;
+  return DMP_OK;
+}
+
+int dmp_msa_encode(const uint8_t* h_text, int64_t nbytes, uint8_t* h_codes) {
+  DMP_ARG(h_text && h_codes && nbytes >= 0, "bad argument");
+  uint8_t tab[256];
+  for (int b = 0; b < 256; ++b) tab[b] = (uint8_t)(b - 65);
+  const char* aa = "ARNDCQEGHILKMFPSTWYV";
+  for (int i = 0; i < 20; ++i) tab[(uint8_t)aa[i]] = (uint8_t)i;
+  for (const char* p = "BJOUXZ"; *p; ++p) tab[(uint8_t)*p] = 20;
+  tab[(uint8_t)'-'] = 21;
+  tab[(uint8_t)'.'] = 21;
+  for (int64_t i = 0; i < nbytes; ++i) h_codes[i] = tab[h_text[i]];
+  return DMP_OK;
+}
+
+#define STREAM ((hipStream_t)stream)
+#define CHECK_CAP(L, N) do { int _rc = check_ready(ctx, (L), (N)); if (_rc) return _rc; } while (0)
+#define CHECK_W() do { int _rc = need_weights(ctx); if (_rc) return _rc; } while (0)
+
+int dmp_msa_weights(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_w, void* stream) {
+  CHECK_CAP(L, N);
+  DMP_ARG(d_msa && d_w && N >= 1 && L >= 1, "bad argument");
+  return msa_weights(ctx, d_msa, N, L, d_w, STREAM);
+}
+
+int dmp_cov_build(dmp_ctx* ctx, const uint8_t* d_msa, const float* d_w, int N, int L, float* d_cov,
+                  void* stream) {
+  CHECK_CAP(L, N);
+  DMP_ARG(d_msa && d_w && d_cov && N >= 1 && L >= 1, "bad argument");
+  return cov_build(ctx, d_msa, d_w, N, L, d_cov, STREAM);
+}
+
+int dmp_spd_inverse(dmp_ctx* ctx, float* d_A, int D, void* stream) {
+  DMP_ARG(ctx && d_A && D >= 1, "bad argument");
+  if (D > NS * ctx->max_L) { set_error("D=%d exceeds capacity %d", D, NS * ctx->max_L); return DMP_ERR_CAPACITY; }
+  return spd_inverse(ctx, d_A, D, STREAM);
+}
+
+int dmp_dca_contacts(dmp_ctx* ctx, const float* d_inv, int L, float* d_contacts, void* stream) {
+  CHECK_CAP(L, 1);
+  DMP_ARG(d_inv && d_contacts, "null argument");
+  return dca_contacts(ctx, d_inv, L, d_contacts, STREAM);
+}
+
+int dmp_gru_vertical(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_out, void* stream) {
+  CHECK_CAP(L, N);
+  CHECK_W();
+  DMP_ARG(d_msa && d_out && N >= 1, "bad argument");
+  return gru_vertical(ctx, d_msa, N, L, d_out, STREAM);
+}
+
+int dmp_gru_bidir(dmp_ctx* ctx, int which, const float* d_in, int T, float* d_out, void* stream) {
+  CHECK_CAP(T, 1);
+  CHECK_W();
+  DMP_ARG((which == 0 || which == 1) && d_in && d_out && T >= 1, "bad argument");
+  return gru_bidir(ctx, which, d_in, T, d_out, STREAM);
+}
+
+int dmp_stem_static(dmp_ctx* ctx, const float* d_mat1d, const float* d_inv, const float* d_contacts,
+                    int L, float* d_z0, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_mat1d && d_z0, "null argument");
+  DMP_ARG((d_inv == nullptr) == (d_contacts == nullptr), "d_inv and d_contacts must both be given or both NULL");
+  return stem_static(ctx, d_mat1d, d_inv, d_contacts, L, d_z0, STREAM);
+}
+
+int dmp_stem_update(dmp_ctx* ctx, const float* d_z0, const float* d_dmap, int L, float* d_x,
+                    void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_z0 && d_dmap && d_x, "null argument");
+  int rc;
+  if ((rc = act_clear(ctx->xa, L, STREAM))) return rc;
+  if ((rc = stem_update_padded(ctx, d_z0, d_dmap, L, ctx->xa, STREAM))) return rc;
+  return act_unpad(ctx->xa, L, d_x, STREAM);
+}
+
+int dmp_block_conv5x5_maxout(dmp_ctx* ctx, int block, const float* d_x, int L, float* d_u,
+                             double* d_stats, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(block >= 1 && block <= NBLOCK && d_x && d_u && d_stats, "bad argument");
+  int rc;
+  if ((rc = act_pad(d_x, L, ctx->xa, STREAM))) return rc;
+  return conv5x5_maxout_padded(ctx, block, ctx->xa, L, d_u, d_stats, STREAM, true);
+}
+
+int dmp_block_norm_scse_residual(dmp_ctx* ctx, int block, const float* d_u, const double* d_stats,
+                                 const float* d_x, int L, float* d_out, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(block >= 1 && block <= NBLOCK && d_u && d_stats && d_x && d_out, "bad argument");
+  int rc;
+  if ((rc = act_pad(d_x, L, ctx->xa, STREAM))) return rc;
+  if ((rc = act_clear(ctx->xb, L, STREAM))) return rc;
+  if ((rc = norm_scse_residual_padded(ctx, block, d_u, d_stats, ctx->xa, L, ctx->xb, STREAM))) return rc;
+  return act_unpad(ctx->xb, L, d_out, STREAM);
+}
+
+int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_x && d_conf && d_M, "null argument");
+  int rc;
+  if ((rc = act_pad(d_x, L, ctx->xa, STREAM))) return rc;
+  return head_gram_padded(ctx, ctx->xa, L, d_conf, d_M, STREAM);
+}
+
+int dmp_trunk_pass(dmp_ctx* ctx, const float* d_z0, const float* d_dmap, int L, float* d_conf,
+                   float* d_M, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_z0 && d_dmap && d_conf && d_M, "null argument");
+  int rc;
+  if ((rc = act_clear(ctx->xa, L, STREAM))) return rc;
+  if ((rc = act_clear(ctx->xb, L, STREAM))) return rc;
+  return trunk_pass(ctx, d_z0, d_dmap, L, d_conf, d_M, STREAM);
+}
+
+int dmp_eigh_top8(dmp_ctx* ctx, const float* d_M, int L, float* d_mds, void* stream) {
+  CHECK_CAP(L, 1);
+  DMP_ARG(d_M && d_mds && L >= 8, "bad argument (L must be >= 8)");
+  return eigh_top8(ctx, d_M, L, d_mds, STREAM);
+}
+
+int dmp_coords_from_mds(dmp_ctx* ctx, const float* d_mat1d, const float* d_mds, int L, float* d_ca,
+                        void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_mat1d && d_mds && d_ca, "null argument");
+  return coords_from_mds(ctx, d_mat1d, d_mds, L, d_ca, STREAM);
+}
+
+int dmp_pair_distances(dmp_ctx* ctx, const float* d_ca, int L, int clamp, float* d_dmap,
+                       void* stream) {
+  DMP_ARG(ctx && d_ca && d_dmap && L >= 1, "bad argument");
+  return pair_distances(d_ca, L, clamp, d_dmap, STREAM);
+}
+
+int dmp_refine_coords(dmp_ctx* ctx, float* d_ca, int L, int steps, void* stream) {
+  DMP_ARG(ctx && d_ca && L >= 2 && L <= 2048 && steps >= 0, "bad argument");
+  return refine_coords(d_ca, L, steps, STREAM);
+}
+
+int dmp_ca_to_backbone(dmp_ctx* ctx, const float* d_ca, const float* d_conf_logit, int L,
+                       float* d_coords, float* d_conf_out, void* stream) {
+  DMP_ARG(ctx && d_ca && d_conf_logit && d_coords && d_conf_out && L >= 3, "bad argument (L must be >= 3)");
+  return ca_to_backbone(d_ca, d_conf_logit, L, d_coords, d_conf_out, STREAM);
+}
+
+int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca, int Lt,
+                int nloops, int refine_steps, float* d_coords, float* d_conf, void* stream) {
+  CHECK_CAP(L, N);
+  CHECK_W();
+  DMP_ARG(d_msa && d_coords && d_conf, "null argument");
+  DMP_ARG(N >= 1 && L >= 8, "need N >= 1 and L >= 8 (got N=%d L=%d)", N, L);
+  DMP_ARG(d_template_ca == nullptr || Lt == L,
+          "template has %d CA atoms but the alignment has %d columns", Lt, L);
+  if (nloops < 0) nloops = 0;
+  if (refine_steps < 0) refine_steps = 0;
+  dmp_ctx* c = ctx;
+  hipStream_t s = STREAM;
+  int rc;
+  c->last_L = L;
+  c->last_N = N;
+  c->passes_done = 0;
+  // ---- features
+  if ((rc = msa_weights(c, d_msa, N, L, c->w, s))) return rc;
+  const float *inv = nullptr, *contacts = nullptr;
+  if (N > 1) {
+    if ((rc = cov_build(c, d_msa, c->w, N, L, c->cov, s))) return rc;
+    if ((rc = spd_inverse(c, c->cov, NS * L, s))) return rc;
+    if ((rc = dca_contacts(c, c->cov, L, c->contacts, s))) return rc;
+    inv = c->cov;
+    contacts = c->contacts;
+  }
+  // ---- sequence trunk
+  if ((rc = gru_vertical(c, d_msa, N, L, c->vout, s))) return rc;
+  if ((rc = gru_bidir(c, 0, c->vout, L, c->seq_b, s))) return rc;
+  if ((rc = transpose_f32(c->seq_b, L, WIDTH, c->mat1d, s))) return rc;
+  // ---- pair trunk, static part
+  if ((rc = stem_static(c, c->mat1d, inv, contacts, L, c->z0, s))) return rc;
+  if (d_template_ca) rc = pair_distances(d_template_ca, L, 0, c->dmap, s);
+  else rc = fill_f32(c->dmap, (int64_t)L * L, -1.0f, s);
+  if (rc) return rc;
+  if ((rc = act_clear(c->xa, L, s))) return rc;
+  if ((rc = act_clear(c->xb, L, s))) return rc;
+  // ---- first pass + recycling
+  for (int pass = 0; pass <= nloops; ++pass) {
+    if (pass > 0 && (rc = pair_distances(c->ca, L, 1, c->dmap, s))) return rc;
+    if ((rc = trunk_pass(c, c->z0, c->dmap, L, c->conf, c->gram, s))) return rc;
+    if ((rc = eigh_top8(c, c->gram, L, c->mds, s))) return rc;
+    if ((rc = coords_from_mds(c, c->mat1d, c->mds, L, c->ca, s))) return rc;
+    if (pass == 0 && refine_steps > 0 && (rc = refine_coords(c->ca, L, refine_steps, s))) return rc;
+    if ((rc = select_best(c, c->conf, c->ca, L, pass, c->max_passes, s))) return rc;
+    c->passes_done = pass + 1;
+  }
+  DMP_HIP(hipMemcpyAsync(c->best_ca_snapshot, c->best_ca, sizeof(float) * 3 * L,
+                         hipMemcpyDeviceToDevice, s));
+  if (refine_steps > 0 && (rc = refine_coords(c->best_ca, L, refine_steps, s))) return rc;
+  return ca_to_backbone(c->best_ca, c->best_conf, L, d_coords, d_conf, s);
+}
+
+int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t capacity, void* stream) {
+  DMP_ARG(ctx && name && d_dst, "null argument");
+  const int64_t L = ctx->last_L, N = ctx->last_N;
+  const int64_t P = std::min(ctx->passes_done, ctx->max_passes);
+  const float* src = nullptr;
+  int64_t n = 0;
+  const std::string k(name);
+  if (k == "w") { src = ctx->w; n = N; }
+  else if (k == "contacts") { src = ctx->contacts; n = L * L; }
+  else if (k == "mat1d") { src = ctx->mat1d; n = WIDTH * L; }
+  else if (k == "conf_means") { src = ctx->conf_means; n = P; }
+  else if (k == "ca_pass") { src = ctx->ca_pass; n = P * L * 3; }
+  else if (k == "best_ca") { src = ctx->best_ca_snapshot; n = L * 3; }
+  else if (k == "inv_cov") { src = ctx->cov; n = (int64_t)NS * L * NS * L; }
+  else if (k == "mds") { src = ctx->mds; n = L * 8; }
+  else if (k == "gram") { src = ctx->gram; n = L * L; }
+  else { set_error("unknown debug tensor %s", name); return DMP_ERR_ARG; }
+  if (n > capacity) { set_error("capacity %lld too small for %s (%lld)", (long long)capacity, name, (long long)n); return DMP_ERR_ARG; }
+  if (n > 0) DMP_HIP(hipMemcpyAsync(d_dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, STREAM));
+  return n;
+}
+
+int dmp_profile_enable(dmp_ctx* ctx, int on, int max_launches) {
+  DMP_ARG(ctx != nullptr, "null context");
+  ctx->prof_on = on != 0;
+  ctx->prof_n = 0;
+  while ((int)ctx->prof_ev.size() < 2 * max_launches) {
+    hipEvent_t e;
+    DMP_HIP(hipEventCreate(&e));
+    ctx->prof_ev.push_back((void*)e);
+  }
+  return DMP_OK;
+}
+
+int dmp_profile_conv_ms(dmp_ctx* ctx, float* h_avg_ms, int* h_launches) {
+  DMP_ARG(ctx && h_avg_ms && h_launches, "null argument");
+  double tot = 0.0;
+  const int n = ctx->prof_n / 2;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    DMP_HIP(hipEventElapsedTime(&ms, (hipEvent_t)ctx->prof_ev[2 * i], (hipEvent_t)ctx->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *h_avg_ms = n ? (float)(tot / n) : 0.f;
+  *h_launches = n;
+  ctx->prof_n = 0;
+  return DMP_OK;
+}
+
+int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(block >= 1 && block <= NBLOCK && iters >= 1 && h_ms, "bad argument");
+  hipEvent_t e0, e1;
+  DMP_HIP(hipEventCreate(&e0));
+  DMP_HIP(hipEventCreate(&e1));
+  int rc = conv5x5_maxout_padded(ctx, block, ctx->xa, L, ctx->u, ctx->stats, STREAM, false);  // warm
+  if (rc) return rc;
+  DMP_HIP(hipEventRecord(e0, STREAM));
+  for (int i = 0; i < iters; ++i)
+    if ((rc = conv5x5_maxout_padded(ctx, block, ctx->xa, L, ctx->u, ctx->stats, STREAM, false))) return rc;
+  DMP_HIP(hipEventRecord(e1, STREAM));
+  DMP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  DMP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *h_ms = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return DMP_OK;
+}
+
+}  // extern "C"

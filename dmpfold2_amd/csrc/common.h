@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <algorithm>
 #include "../../include/dmpfold_hip.h"
 
 namespace dmp {
@@ -141,6 +142,10 @@ struct dmp_ctx {
   int passes_done = 0;
   int last_L = 0, last_N = 0;
   int max_passes = 0;
+  // optional HIP-event timing of the conv kernel inside dmp_predict
+  bool prof_on = false;
+  int prof_n = 0;
+  std::vector<void*> prof_ev;
 };
 
 namespace dmp {
@@ -172,7 +177,8 @@ int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const floa
 int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L, float* d_xpad,
                        hipStream_t s);
 int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
-                          double* d_stats, hipStream_t s);
+                          double* d_stats, hipStream_t s, bool reduce);
+int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s);
 int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
                               const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s);
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
@@ -188,7 +194,7 @@ int build_embed(const float* d_mat1d, const float* d_mds, int L, float* d_emb, h
 int transpose_f32(const float* d_in, int R, int C, float* d_out, hipStream_t s);
 int pair_distances(const float* d_ca, int L, int clamp, float* d_dmap, hipStream_t s);
 int fill_f32(float* d, int64_t n, float v, hipStream_t s);
-int select_best(dmp_ctx* c, const float* d_conf, const float* d_ca, int L, int pass,
+int select_best(dmp_ctx* c, const float* d_conf, const float* d_ca, int L, int pass, int rec_cap,
                 hipStream_t s);
 int refine_coords(float* d_ca, int L, int steps, hipStream_t s);
 int ca_to_backbone(const float* d_ca, const float* d_logit, int L, float* d_coords,

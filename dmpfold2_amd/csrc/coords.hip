@@ -1,0 +1,267 @@
+// Coordinate-side kernels: coord_fc, pair distances, best-of selection, the steric/bond
+// minimiser (reference network.py:106-137) and the backbone builder (network.py:141-177).
+// The reference evaluates these as chains of separately rounded float32 tensor ops, so
+// floating-point contraction is switched off for this file.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace dmp {
+
+// ca[i][c] = sum_k g[i][k] * W[c][k]                                     (network.py:255)
+__global__ __launch_bounds__(192) void coord_fc_kernel(const float* __restrict__ g,
+                                                       const float* __restrict__ w, int L,
+                                                       float* __restrict__ ca) {
+  const int i = blockIdx.x;
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int k = lane; k < WIDTH; k += 64) acc = fmaf(g[(int64_t)i * WIDTH + k], w[c * WIDTH + k], acc);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) ca[i * 3 + c] = acc;
+}
+
+int coord_fc(dmp_ctx* c, const float* d_g, int L, float* d_ca, hipStream_t s) {
+  hipLaunchKernelGGL(coord_fc_kernel, dim3(L), dim3(192), 0, s, d_g, c->W.fc, L, d_ca);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// emb[i] = [mat1d[:, i] | mds[i, :]]                                      (network.py:251)
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ mat1d,
+                                                    const float* __restrict__ mds, int L,
+                                                    float* __restrict__ emb) {
+  const int i = blockIdx.x;
+  for (int k = threadIdx.x; k < WIDTH + 8; k += 256)
+    emb[(int64_t)i * (WIDTH + 8) + k] =
+        k < WIDTH ? mat1d[(int64_t)k * L + i] : mds[(int64_t)i * 8 + (k - WIDTH)];
+}
+
+int build_embed(const float* d_mat1d, const float* d_mds, int L, float* d_emb, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel, dim3(L), dim3(256), 0, s, d_mat1d, d_mds, L, d_emb);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int C,
+                                                        float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    if (r0 + r < R && c0 + tx < C) tile[r][tx] = in[(int64_t)(r0 + r) * C + c0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (c0 + r < C && r0 + tx < R) out[(int64_t)(c0 + r) * R + r0 + tx] = tile[tx][r];
+}
+
+int transpose_f32(const float* d_in, int R, int C, float* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, d_in, R, C,
+                     d_out);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// clamp=1: sqrt(max(|ci-cj|^2, 1e-8)) (network.py:272); clamp=0: sqrt(|ci-cj|^2) (predict.py:143)
+__global__ __launch_bounds__(256) void pairdist_kernel(const float* __restrict__ ca, int L, int clamp,
+                                                       float* __restrict__ dmap) {
+  const int i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= L) return;
+  const float dx = ca[j * 3] - ca[i * 3], dy = ca[j * 3 + 1] - ca[i * 3 + 1],
+              dz = ca[j * 3 + 2] - ca[i * 3 + 2];
+  float s = (dx * dx + dy * dy) + dz * dz;
+  if (clamp) s = fmaxf(s, 1e-8f);
+  dmap[(int64_t)i * L + j] = sqrtf(s);
+}
+
+int pair_distances(const float* d_ca, int L, int clamp, float* d_dmap, hipStream_t s) {
+  hipLaunchKernelGGL(pairdist_kernel, dim3(cdiv(L, 256), L), dim3(256), 0, s, d_ca, L, clamp, d_dmap);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+__global__ void fill_kernel(float* __restrict__ d, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = v;
+}
+
+int fill_f32(float* d, int64_t n, float v, hipStream_t s) {
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, d, n, v);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// best-of selection on the device (network.py:302-306: strict '>' on the mean logit)
+__global__ __launch_bounds__(256) void select_best_kernel(const float* __restrict__ conf,
+                                                          const float* __restrict__ ca, int L,
+                                                          int pass, int rec_cap,
+                                                          float* __restrict__ best_mean,
+                                                          float* __restrict__ best_conf,
+                                                          float* __restrict__ best_ca,
+                                                          float* __restrict__ conf_means,
+                                                          float* __restrict__ ca_pass) {
+  __shared__ double red[256];
+  __shared__ int take;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < L; i += 256) acc += (double)conf[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mean = (float)(red[0] / (double)L);
+    if (pass < rec_cap) conf_means[pass] = mean;
+    take = (pass == 0) || (mean > best_mean[0]);
+    if (take) best_mean[0] = mean;
+  }
+  __syncthreads();
+  if (pass < rec_cap)
+    for (int i = threadIdx.x; i < 3 * L; i += 256) ca_pass[(int64_t)pass * 3 * L + i] = ca[i];
+  if (take) {
+    for (int i = threadIdx.x; i < L; i += 256) best_conf[i] = conf[i];
+    for (int i = threadIdx.x; i < 3 * L; i += 256) best_ca[i] = ca[i];
+  }
+}
+
+int select_best(dmp_ctx* c, const float* d_conf, const float* d_ca, int L, int pass, int rec_cap,
+                hipStream_t s) {
+  hipLaunchKernelGGL(select_best_kernel, dim3(1), dim3(256), 0, s, d_conf, d_ca, L, pass, rec_cap,
+                     c->best_mean, c->best_conf, c->best_ca, c->conf_means, c->ca_pass);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// refine_coords: all steps in one launch, coordinates double-buffered in LDS
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void refine_kernel(float* __restrict__ ca, int L, int steps) {
+  extern __shared__ float sm[];          // 2 x 3L
+  float* cur = sm;
+  float* nxt = sm + 3 * L;
+  for (int i = threadIdx.x; i < 3 * L; i += 1024) cur[i] = ca[i];
+  __syncthreads();
+  for (int step = 0; step < steps; ++step) {
+    for (int j = threadIdx.x; j < L; j += 1024) {
+      const float xj = cur[3 * j], yj = cur[3 * j + 1], zj = cur[3 * j + 2];
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      for (int i = 0; i < L; ++i) {
+        const float dx = xj - cur[3 * i], dy = yj - cur[3 * i + 1], dz = zj - cur[3 * i + 2];
+        float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+        d = fminf(fmaxf(d, 0.01f), 10.0f);
+        const float viol = (d < 3.0f) ? (3.0f - d) : 0.0f;
+        const float f = 100.0f * viol;
+        ax += f * (dx / d);
+        ay += f * (dy / d);
+        az += f * (dz / d);
+      }
+      if (j < L - 1) {   // bond to j+1: accels[:-1] += accels_cov
+        const float dx = cur[3 * j + 3] - xj, dy = cur[3 * j + 4] - yj, dz = cur[3 * j + 5] - zj;
+        const float d = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 0.1f);
+        const float f = 100.0f * fminf(d - 3.78f, 3.0f);
+        ax += f * (dx / d);
+        ay += f * (dy / d);
+        az += f * (dz / d);
+      }
+      if (j > 0) {       // bond from j-1: accels[1:] -= accels_cov
+        const float dx = xj - cur[3 * j - 3], dy = yj - cur[3 * j - 2], dz = zj - cur[3 * j - 1];
+        const float d = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 0.1f);
+        const float f = 100.0f * fminf(d - 3.78f, 3.0f);
+        ax -= f * (dx / d);
+        ay -= f * (dy / d);
+        az -= f * (dz / d);
+      }
+      nxt[3 * j] = xj + fminf(fmaxf(ax, -100.0f), 100.0f) * 0.001f;
+      nxt[3 * j + 1] = yj + fminf(fmaxf(ay, -100.0f), 100.0f) * 0.001f;
+      nxt[3 * j + 2] = zj + fminf(fmaxf(az, -100.0f), 100.0f) * 0.001f;
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  for (int i = threadIdx.x; i < 3 * L; i += 1024) ca[i] = cur[i];
+}
+
+int refine_coords(float* d_ca, int L, int steps, hipStream_t s) {
+  if (steps <= 0) return DMP_OK;
+  hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(1024), sizeof(float) * 6 * L, s, d_ca, L, steps);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// backbone from the C-alpha trace + sigmoid of the confidence logits
+// ---------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 ld3(const float* p, int i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 mul(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 dvd(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float nrm(V3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ V3 unit(V3 a) { return dvd(a, fmaxf(nrm(a), 1e-12f)); }
+
+__device__ __forceinline__ V3 ext_at(const float* ca, int L, int t) {
+  // t = 0: virtual N-terminal CA; 1..L: ca[t-1]; L+1: virtual C-terminal CA
+  if (t >= 1 && t <= L) return ld3(ca, t - 1);
+  if (t == 0) {
+    const V3 a0 = ld3(ca, 0), a1 = ld3(ca, 1), a2 = ld3(ca, 2);
+    return add(a0, mul(unit(cross(sub(a0, a1), sub(a2, a1))), 3.82f));
+  }
+  const V3 z0 = ld3(ca, L - 1), z1 = ld3(ca, L - 2), z2 = ld3(ca, L - 3);
+  return add(z0, mul(unit(cross(sub(z0, z1), sub(z2, z1))), 3.82f));
+}
+
+__global__ __launch_bounds__(256) void backbone_kernel(const float* __restrict__ ca,
+                                                       const float* __restrict__ logit, int L,
+                                                       float sxc, float syc,
+                                                       float* __restrict__ coords,
+                                                       float* __restrict__ conf) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= L) return;
+  const V3 e0 = ext_at(ca, L, r), e1 = ext_at(ca, L, r + 1), e2 = ext_at(ca, L, r + 2);
+  const V3 prev = sub(e0, e1), nxt = sub(e2, e1);
+  const V3 mid0 = dvd(add(e1, e0), 2.0f);          // between ext[r] and ext[r+1]
+  const V3 mid1 = dvd(add(e2, e1), 2.0f);          // between ext[r+1] and ext[r+2]
+  const V3 nr = unit(cross(prev, nxt));
+  const V3 n_at = add(sub(mid0, dvd(prev, 8.0f)), dvd(nr, 4.0f));
+  V3 c_at, o_at;
+  if (r < L - 1) {
+    const V3 e3 = ext_at(ca, L, r + 3);
+    const V3 prev1 = sub(e1, e2), nxt1 = sub(e3, e2);
+    const V3 nr1 = unit(cross(prev1, nxt1));
+    c_at = sub(add(mid1, dvd(prev1, 8.0f)), dvd(nr1, 2.0f));
+    o_at = sub(mid1, mul(nr1, 1.8f));
+  } else {
+    c_at = add(sub(mid1, dvd(nxt, 8.0f)), dvd(nr, 2.0f));
+    o_at = add(mid1, mul(nr, 2.0f));
+  }
+  const V3 vn = sub(e1, n_at), vc = sub(e1, c_at);
+  const V3 cr = cross(vn, vc);
+  const V3 vb = add(vn, vc);
+  // Python `const / tensor` is evaluated as tensor.reciprocal() * const
+  const float sx = (1.0f / nrm(vb)) * sxc, sy = (1.0f / nrm(cr)) * syc;
+  const V3 cb = add(add(e1, mul(vb, sx)), mul(cr, sy));
+  float* o = coords + (int64_t)r * 15;
+  o[0] = n_at.x; o[1] = n_at.y; o[2] = n_at.z;
+  o[3] = e1.x;   o[4] = e1.y;   o[5] = e1.z;
+  o[6] = c_at.x; o[7] = c_at.y; o[8] = c_at.z;
+  o[9] = o_at.x; o[10] = o_at.y; o[11] = o_at.z;
+  o[12] = cb.x;  o[13] = cb.y;  o[14] = cb.z;
+  conf[r] = 1.0f / (1.0f + expf(-logit[r]));
+}
+
+int ca_to_backbone(const float* d_ca, const float* d_logit, int L, float* d_coords,
+                   float* d_conf_out, hipStream_t s) {
+  const double ang = 3.14159265358979323846 / 2.0 - asin(1.0 / sqrt(3.0));
+  const float sxc = (float)(1.5 * cos(ang)), syc = (float)(1.5 * sin(ang));
+  hipLaunchKernelGGL(backbone_kernel, dim3(cdiv(L, 256)), dim3(256), 0, s, d_ca, d_logit, L, sxc,
+                     syc, d_coords, d_conf_out);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+}  // namespace dmp

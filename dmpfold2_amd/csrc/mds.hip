@@ -1,0 +1,405 @@
+// Top-8 symmetric eigensolver for the MDS step (reference network.py:247-250: torch.symeig,
+// clamp, V*sqrt(lambda), last 8 columns), entirely on the device in float64:
+//   1. Householder tridiagonalisation  A = Q T Q^T          (one workgroup, A resident in L2)
+//   2. bisection (Sturm counts, 64-way multisection per wave) for the 8 largest eigenvalues of T
+//   3. inverse iteration with pivoted tridiagonal LU for their eigenvectors, Gram-Schmidt inside
+//      clusters of close eigenvalues
+//   4. back-transformation with the stored reflectors, sign rule, scaling by sqrt(max(lambda,1e-8))
+// Sign rule (eigenvector signs are implementation-defined in the reference): the component of
+// largest magnitude (first index on ties) is made positive.
+#include "common.h"
+
+namespace dmp {
+
+constexpr int NEV = 8;
+
+__global__ __launch_bounds__(256) void eig_load_kernel(const float* __restrict__ M, int n,
+                                                       double* __restrict__ A) {
+  const int i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int a = i < j ? i : j, b = i < j ? j : i;    // upper triangle, as symeig(upper=True)
+  A[(int64_t)i * n + j] = (double)M[(int64_t)a * n + b];
+}
+
+__device__ __forceinline__ double block_sum_1024(double v, double* red) {
+  // red: 16 doubles of LDS
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += red[w];
+  return t;
+}
+
+// A (n x n, full symmetric storage) -> d, e, tau and the reflectors V[k][0..n-k-2] (row-wise).
+// block: 1024 threads; dynamic LDS: v[n], p[n] doubles.
+__global__ __launch_bounds__(1024) void tridiag_kernel(double* __restrict__ A, int n,
+                                                       double* __restrict__ d, double* __restrict__ e,
+                                                       double* __restrict__ tau, double* __restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* v = sm;
+  double* p = sm + n;
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = 0; k < n - 1; ++k) {
+    const int m = n - k - 1;                       // length of x = A[k+1:, k]
+    double* A22 = A + (int64_t)(k + 1) * n + (k + 1);
+    // x -> v (LDS), norm of x[1:]
+    double ss = 0.0;
+    for (int i = tid; i < m; i += 1024) {
+      const double xi = A[(int64_t)(k + 1 + i) * n + k];
+      v[i] = xi;
+      if (i > 0) ss += xi * xi;
+    }
+    const double xnorm2 = block_sum_1024(ss, red);
+    const double alpha = v[0];
+    double beta, tk;
+    if (xnorm2 == 0.0) {
+      beta = alpha;
+      tk = 0.0;
+    } else {
+      const double nrm = sqrt(alpha * alpha + xnorm2);
+      beta = alpha >= 0.0 ? -nrm : nrm;
+      tk = (beta - alpha) / beta;
+    }
+    __syncthreads();
+    if (tk != 0.0) {
+      const double sc = 1.0 / (alpha - beta);
+      for (int i = tid; i < m; i += 1024) v[i] = (i == 0) ? 1.0 : v[i] * sc;
+    } else {
+      for (int i = tid; i < m; i += 1024) v[i] = (i == 0) ? 1.0 : 0.0;
+    }
+    if (tid == 0) {
+      d[k] = A[(int64_t)k * n + k];
+      e[k] = beta;
+      tau[k] = tk;
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += 1024) V[(int64_t)k * n + i] = v[i];
+    if (tk != 0.0) {
+      // p = tau * A22 * v : one wave per row, lanes along the row
+      for (int i = wave; i < m; i += 16) {
+        const double* row = A22 + (int64_t)i * n;
+        double acc = 0.0;
+        for (int j = lane; j < m; j += 64) acc += row[j] * v[j];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) p[i] = tk * acc;
+      }
+      __syncthreads();
+      double pv = 0.0;
+      for (int i = tid; i < m; i += 1024) pv += p[i] * v[i];
+      const double dot = block_sum_1024(pv, red);
+      const double a2 = -0.5 * tk * dot;
+      for (int i = tid; i < m; i += 1024) p[i] += a2 * v[i];      // p now holds w
+      __syncthreads();
+      for (int i = wave; i < m; i += 16) {
+        double* row = A22 + (int64_t)i * n;
+        const double vi = v[i], wi = p[i];
+        for (int j = lane; j < m; j += 64) row[j] -= vi * p[j] + wi * v[j];
+      }
+    }
+    __syncthreads();
+    __threadfence_block();
+  }
+  if (tid == 0) {
+    d[n - 1] = A[(int64_t)(n - 1) * n + (n - 1)];
+    e[n - 1] = 0.0;
+  }
+}
+
+__device__ __forceinline__ int sturm_count(const double* d, const double* e2, int n, double x,
+                                           double pivmin) {
+  double q = d[0] - x;
+  if (fabs(q) < pivmin) q = -pivmin;
+  int cnt = q < 0.0;
+  for (int i = 1; i < n; ++i) {
+    q = d[i] - x - e2[i - 1] / q;
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += q < 0.0;
+  }
+  return cnt;
+}
+
+// Bisection + inverse iteration on the tridiagonal matrix.  block: 256.
+// dynamic LDS: dd[n], e2[n], x[n][8] doubles.  Global scratch F: 5 arrays [n][8].
+// Outputs: lam[8] (ascending), Z[n][8] (unit eigenvectors of T).
+__global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__ d,
+                                                      const double* __restrict__ e, int n,
+                                                      double* __restrict__ F,
+                                                      double* __restrict__ lam_out,
+                                                      double* __restrict__ Z) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* dd = sm;
+  double* e2 = sm + n;
+  double* x = sm + 2 * n;              // [n][8]
+  __shared__ double lam[NEV];
+  __shared__ double sh_scal[4];
+  __shared__ double red[4][NEV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // Gershgorin interval and norms
+  double lo = 1e300, hi = -1e300, emax = 0.0, nrm1 = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double di = d[i];
+    const double el = i > 0 ? fabs(e[i - 1]) : 0.0, er = i < n - 1 ? fabs(e[i]) : 0.0;
+    dd[i] = di;
+    e2[i] = (i < n - 1) ? e[i] * e[i] : 0.0;
+    lo = fmin(lo, di - el - er);
+    hi = fmax(hi, di + el + er);
+    emax = fmax(emax, er);
+    nrm1 = fmax(nrm1, fabs(di) + el + er);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, off, 64));
+    hi = fmax(hi, __shfl_xor(hi, off, 64));
+    emax = fmax(emax, __shfl_xor(emax, off, 64));
+    nrm1 = fmax(nrm1, __shfl_xor(nrm1, off, 64));
+  }
+  if (lane == 0) { red[wave][0] = lo; red[wave][1] = hi; red[wave][2] = emax; red[wave][3] = nrm1; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) {
+      red[0][0] = fmin(red[0][0], red[w][0]);
+      red[0][1] = fmax(red[0][1], red[w][1]);
+      red[0][2] = fmax(red[0][2], red[w][2]);
+      red[0][3] = fmax(red[0][3], red[w][3]);
+    }
+    const double span = red[0][1] - red[0][0];
+    sh_scal[0] = red[0][0] - 1e-12 * fabs(span) - 1e-300;
+    sh_scal[1] = red[0][1] + 1e-12 * fabs(span) + 1e-300;
+    sh_scal[2] = 1e-290 * fmax(1.0, red[0][2] * red[0][2]);   // pivmin
+    sh_scal[3] = red[0][3];                                    // ||T||_1
+  }
+  __syncthreads();
+  const double glo = sh_scal[0], ghi = sh_scal[1], pivmin = sh_scal[2], tnorm = sh_scal[3];
+
+  // ---- bisection: wave w finds eigenvalues 2w and 2w+1 of the top 8 (ascending order)
+  for (int q = 0; q < 2; ++q) {
+    const int ev = 2 * wave + q;
+    const int idx = n - NEV + ev;           // 0-based index in the ascending spectrum
+    double a = glo, b = ghi;
+    for (int round = 0; round < 14; ++round) {
+      const double xt = a + (b - a) * ((double)(lane + 1) / 65.0);
+      const int cnt = sturm_count(dd, e2, n, xt, pivmin);
+      const unsigned long long above = __ballot(cnt >= idx + 1);
+      // counts are monotone in x: the lanes with cnt >= idx+1 form a suffix
+      const int first = above ? __ffsll((long long)above) - 1 : 64;
+      const double na = first > 0 ? __shfl(xt, first - 1, 64) : a;
+      const double nb = first < 64 ? __shfl(xt, first < 64 ? first : 63, 64) : b;
+      a = na;
+      b = nb;
+      if (b - a <= 4.0e-16 * fmax(fabs(a), fabs(b)) + 2.0 * pivmin) break;
+    }
+    if (lane == 0) lam[ev] = 0.5 * (a + b);
+  }
+  __syncthreads();
+
+  // ---- inverse iteration: lanes 0..7 of wave 0, one eigenvalue each, in lockstep
+  const double eps = 2.220446049250313e-16;
+  const double ortol = 1e-3 * tnorm;
+  double* fa = F;                      // U diagonal
+  double* fb = F + (int64_t)n * NEV;   // U first super-diagonal
+  double* fc = F + (int64_t)2 * n * NEV;  // multipliers
+  double* fd = F + (int64_t)3 * n * NEV;  // U second super-diagonal
+  double* fp = F + (int64_t)4 * n * NEV;  // interchange flags
+  if (tid == 0) {
+    // separate coincident eigenvalues slightly so the factorizations differ
+    for (int j = 1; j < NEV; ++j) {
+      const double pert = 10.0 * eps * fmax(fabs(lam[j]), tnorm * 1e-3);
+      if (lam[j] - lam[j - 1] < pert) lam[j] = lam[j - 1] + pert;
+    }
+  }
+  __syncthreads();
+  if (tid < NEV) {
+    const double l = lam[tid];
+    const double tiny = eps * fmax(tnorm, 1e-300);
+    // LU with partial pivoting of T - l*I (rows k, k+1 at a time)
+    double ak = dd[0] - l;                                   // current diagonal of row k
+    double bk = n > 1 ? e[0] : 0.0;                          // current super-diagonal of row k
+    for (int k = 0; k < n - 1; ++k) {
+      const double ck = e[k];                                // sub-diagonal entry (row k+1, col k)
+      const double a1 = dd[k + 1] - l;                       // row k+1 diagonal
+      const double b1 = (k < n - 2) ? e[k + 1] : 0.0;        // row k+1 super-diagonal
+      double ua, ub, ud, mult, na1, nb1;
+      double flag;
+      if (fabs(ck) <= fabs(ak)) {
+        flag = 0.0;
+        mult = (ak != 0.0) ? ck / ak : 0.0;
+        ua = ak; ub = bk; ud = 0.0;
+        na1 = a1 - mult * bk;
+        nb1 = b1;
+      } else {
+        flag = 1.0;
+        mult = ak / ck;
+        ua = ck; ub = a1; ud = b1;
+        na1 = bk - mult * a1;
+        nb1 = -mult * b1;
+      }
+      fa[(int64_t)k * NEV + tid] = ua;
+      fb[(int64_t)k * NEV + tid] = ub;
+      fd[(int64_t)k * NEV + tid] = ud;
+      fc[(int64_t)k * NEV + tid] = mult;
+      fp[(int64_t)k * NEV + tid] = flag;
+      ak = na1;
+      bk = nb1;
+    }
+    fa[(int64_t)(n - 1) * NEV + tid] = ak;
+    fb[(int64_t)(n - 1) * NEV + tid] = 0.0;
+    fd[(int64_t)(n - 1) * NEV + tid] = 0.0;
+    // start vector: deterministic, no special structure
+    unsigned s = 0x9E3779B9u * (unsigned)(tid + 1);
+    for (int i = 0; i < n; ++i) {
+      s = s * 1664525u + 1013904223u;
+      x[i * NEV + tid] = ((double)(s >> 8) / 16777216.0) - 0.5;
+    }
+    (void)tiny;
+  }
+  __syncthreads();
+  for (int iter = 0; iter < 5; ++iter) {
+    __threadfence_block();
+    if (tid < NEV) {
+      const double tiny = eps * fmax(tnorm, 1e-300);
+      // forward substitution with the recorded interchanges
+      double yk = x[tid];
+      for (int k = 0; k < n - 1; ++k) {
+        const double mult = fc[(int64_t)k * NEV + tid];
+        const double y1 = x[(k + 1) * NEV + tid];
+        if (fp[(int64_t)k * NEV + tid] == 0.0) {
+          x[k * NEV + tid] = yk;
+          yk = y1 - mult * yk;
+        } else {
+          x[k * NEV + tid] = y1;
+          yk = yk - mult * y1;
+        }
+      }
+      x[(n - 1) * NEV + tid] = yk;
+      // back substitution
+      double x1 = 0.0, x2 = 0.0;
+      for (int k = n - 1; k >= 0; --k) {
+        double t = x[k * NEV + tid] - fb[(int64_t)k * NEV + tid] * x1 - fd[(int64_t)k * NEV + tid] * x2;
+        double ak = fa[(int64_t)k * NEV + tid];
+        if (fabs(ak) < tiny) ak = ak < 0.0 ? -tiny : tiny;
+        t /= ak;
+        x[k * NEV + tid] = t;
+        x2 = x1;
+        x1 = t;
+      }
+    }
+    __syncthreads();
+    // modified Gram-Schmidt inside clusters + normalisation, all threads
+    for (int j = 0; j < NEV; ++j) {
+      for (int i = j - 1; i >= 0; --i) {
+        if (lam[i + 1] - lam[i] > ortol) break;          // cluster chain ends
+        double part = 0.0;
+        for (int r = tid; r < n; r += 256) part += x[r * NEV + i] * x[r * NEV + j];
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        __syncthreads();
+        if (lane == 0) red[wave][0] = part;
+        __syncthreads();
+        const double dot = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        for (int r = tid; r < n; r += 256) x[r * NEV + j] -= dot * x[r * NEV + i];
+        __syncthreads();
+      }
+      double part = 0.0;
+      for (int r = tid; r < n; r += 256) part += x[r * NEV + j] * x[r * NEV + j];
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      __syncthreads();
+      if (lane == 0) red[wave][0] = part;
+      __syncthreads();
+      const double nrm = sqrt(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+      const double sc = nrm > 0.0 ? 1.0 / nrm : 0.0;
+      for (int r = tid; r < n; r += 256) x[r * NEV + j] *= sc;
+      __syncthreads();
+    }
+  }
+  for (int r = tid; r < n * NEV; r += 256) Z[r] = x[r];
+  if (tid < NEV) lam_out[tid] = lam[tid];
+}
+
+// Z <- Q Z with Q = H_0 H_1 ... H_{n-2}; then sign rule and scaling.  block: 256.
+// dynamic LDS: z[n][8] doubles.
+__global__ __launch_bounds__(256) void backtransform_kernel(const double* __restrict__ V,
+                                                            const double* __restrict__ tau,
+                                                            const double* __restrict__ lam,
+                                                            const double* __restrict__ Z, int n,
+                                                            float* __restrict__ mds) {
+  extern __shared__ __attribute__((aligned(16))) double z[];
+  __shared__ double red[4][NEV];
+  __shared__ double bestv[4][NEV];
+  __shared__ int besti[4][NEV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid & 7, rl = tid >> 3;            // column, row lane (32 row lanes)
+  for (int r = tid; r < n * NEV; r += 256) z[r] = Z[r];
+  __syncthreads();
+  for (int k = n - 2; k >= 0; --k) {
+    const double tk = tau[k];
+    if (tk == 0.0) continue;
+    const int m = n - k - 1;
+    const double* vk = V + (int64_t)k * n;
+    double part = 0.0;
+    for (int i = rl; i < m; i += 32) part += vk[i] * z[(k + 1 + i) * NEV + c];
+    part += __shfl_xor(part, 8, 64);
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lane < NEV) red[wave][lane] = part;
+    __syncthreads();
+    const double s = tk * (red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    for (int i = rl; i < m; i += 32) z[(k + 1 + i) * NEV + c] -= s * vk[i];
+    __syncthreads();
+  }
+  // sign rule: largest |component| positive, first index on ties
+  double bv = -1.0;
+  int bi = 0x7fffffff;
+  for (int i = rl; i < n; i += 32) {
+    const double a = fabs(z[i * NEV + c]);
+    if (a > bv) { bv = a; bi = i; }
+  }
+  for (int off = 8; off < 64; off <<= 1) {
+    const double ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane < NEV) { bestv[wave][lane] = bv; besti[wave][lane] = bi; }
+  __syncthreads();
+  bv = bestv[0][c]; bi = besti[0][c];
+  for (int w = 1; w < 4; ++w) {
+    const double ov = bestv[w][c];
+    const int oi = besti[w][c];
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  const double sgn = z[bi * NEV + c] < 0.0 ? -1.0 : 1.0;
+  const float lf = (float)lam[c];
+  const float scale = sqrtf(fmaxf(fmaxf(lf, 0.0f), 1e-8f));
+  for (int i = rl; i < n; i += 32) mds[(int64_t)i * NEV + c] = (float)(sgn * z[i * NEV + c]) * scale;
+}
+
+int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) {
+  const int n = L;
+  double* A = c->eig_a;
+  double* ws = c->eig_ws;
+  double* d = ws;
+  double* e = ws + n;
+  double* tau = ws + 2 * n;
+  double* lam = ws + 3 * n;                 // 8
+  double* Z = ws + 3 * n + 16;              // n*8
+  double* F = Z + (int64_t)n * NEV;         // 5*n*8
+  double* V = F + (int64_t)5 * n * NEV;     // n*n
+  hipLaunchKernelGGL(eig_load_kernel, dim3(cdiv(n, 256), n), dim3(256), 0, s, d_M, n, A);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tridiag_kernel, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, A, n, d, e, tau,
+                     V);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(256), sizeof(double) * (2 + NEV) * n, s, d, e, n,
+                     F, lam, Z);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(backtransform_kernel, dim3(1), dim3(256), sizeof(double) * NEV * n, s, V, tau,
+                     lam, Z, n, d_mds);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+}  // namespace dmp

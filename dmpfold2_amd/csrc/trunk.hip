@@ -1,0 +1,550 @@
+// Pair trunk (reference network.py:12-103, 194-207): 1x1 maxout stem, 16 residual blocks of
+// 5x5 conv (128->512) + 4-way maxout + InstanceNorm + scSE, 2-channel head.
+//
+// Activations between blocks live in a zero-bordered layout [128][P][P], P = 16*ceil(L/16)+4,
+// interior at [2, 2+L): the 5x5 halo reads need no bounds checks and the conv tiles of
+// 16x16 pixels never straddle the border logic.  The pre-norm maxout output `u` is dense.
+#include "common.h"
+
+namespace dmp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------
+// layout helpers
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_pad_kernel(const float* __restrict__ dense, int L, int P,
+                                                      float* __restrict__ xpad) {
+  const int c = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= P) return;
+  const int yy = y - 2, xx = x - 2;
+  float v = 0.f;
+  if (yy >= 0 && yy < L && xx >= 0 && xx < L) v = dense[((int64_t)c * L + yy) * L + xx];
+  xpad[((int64_t)c * P + y) * P + x] = v;
+}
+
+__global__ __launch_bounds__(256) void act_unpad_kernel(const float* __restrict__ xpad, int L, int P,
+                                                        float* __restrict__ dense) {
+  const int c = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= L) return;
+  dense[((int64_t)c * L + y) * L + x] = xpad[((int64_t)c * P + y + 2) * P + x + 2];
+}
+
+int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s) {
+  const int P = act_pitch(L);
+  hipLaunchKernelGGL(act_pad_kernel, dim3(cdiv(P, 256), P, CW), dim3(256), 0, s, d_dense, L, P,
+                     d_xpad);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+int act_unpad(const float* d_xpad, int L, float* d_dense, hipStream_t s) {
+  const int P = act_pitch(L);
+  hipLaunchKernelGGL(act_unpad_kernel, dim3(cdiv(L, 256), L, CW), dim3(256), 0, s, d_xpad, L, P,
+                     d_dense);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+int act_clear(float* d_xpad, int L, hipStream_t s) {
+  const int P = act_pitch(L);
+  DMP_HIP(hipMemsetAsync(d_xpad, 0, sizeof(float) * CW * (size_t)P * P, s));
+  return DMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// stem, input-independent part (once per structure)
+//   Z0[o,i,j] = b_o + sum_{c<512} W[o,c] m[c,i] m[c,j]
+//             + sum_{a,b} W[o,512+21a+b] inv[21i+a, 21j+b] + W[o,953] contacts[i,j]
+// GEMM per row i: M = 384 output channels (A = W^T[k][o]), N = 64 columns j, K = 954, the B
+// operand is generated on the fly from m / inv / contacts.  f32 MFMA 32x32x2.
+// grid: (ceil(L/64), L)   block: 256 (wave w owns channel blocks 3w..3w+2)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_static_kernel(const float* __restrict__ wT,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ m,
+                                                          const float* __restrict__ inv,
+                                                          const float* __restrict__ contacts, int L,
+                                                          float* __restrict__ z0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kk = lane >> 5, li = lane & 31;
+  const int i = blockIdx.y, j0 = blockIdx.x * 64;
+  const int jq[2] = {j0 + li, j0 + 32 + li};
+  const bool ok[2] = {jq[0] < L, jq[1] < L};
+  const int64_t D = (int64_t)L * NS;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
+
+  const float* wbase = wT + wave * 96 + li;
+  auto step = [&](int k, float b0, float b1) {
+    const float* wk = wbase + (int64_t)k * STEM_OUT;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float av = wk[a * 32];
+      acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a][0], 0, 0, 0);
+      acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[a][1], 0, 0, 0);
+    }
+  };
+  // outer-product channels
+#pragma unroll 4
+  for (int p = 0; p < 256; ++p) {
+    const int k = 2 * p + kk;
+    const float mi = m[(int64_t)k * L + i];
+    const float b0 = ok[0] ? mi * m[(int64_t)k * L + jq[0]] : 0.f;
+    const float b1 = ok[1] ? mi * m[(int64_t)k * L + jq[1]] : 0.f;
+    step(k, b0, b1);
+  }
+  if (inv != nullptr) {
+    // coupling channels 512 .. 952 (k = 512 + 21a + b), contact channel 953
+#pragma unroll 2
+    for (int p = 256; p < 477; ++p) {
+      const int k = 2 * p + kk;
+      float b0 = 0.f, b1 = 0.f;
+      if (k < 953) {
+        const int ab = k - 512;
+        const int a = ab / NS, b = ab - a * NS;
+        const float* row = inv + ((int64_t)i * NS + a) * D + b;
+        if (ok[0]) b0 = row[(int64_t)jq[0] * NS];
+        if (ok[1]) b1 = row[(int64_t)jq[1] * NS];
+      } else {
+        if (ok[0]) b0 = contacts[(int64_t)i * L + jq[0]];
+        if (ok[1]) b1 = contacts[(int64_t)i * L + jq[1]];
+      }
+      step(k, b0, b1);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!ok[q]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = wave * 96 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        z0[((int64_t)o * L + i) * L + jq[q]] = acc[a][q][r] + bias[o];
+      }
+    }
+}
+
+int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const float* d_contacts,
+                int L, float* d_z0, hipStream_t s) {
+  const Weights& W = c->W;
+  hipLaunchKernelGGL(stem_static_kernel, dim3(cdiv(L, 64), L), dim3(256), 0, s, W.stemT, W.stem_b,
+                     d_mat1d, d_inv, d_contacts, L, d_z0);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// stem, per-pass part: + W[o,954]*dmap, max over triples, InstanceNorm
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_maxout_kernel(const float* __restrict__ z0,
+                                                          const float* __restrict__ wd,
+                                                          const float* __restrict__ dmap, int64_t LL,
+                                                          float* __restrict__ u) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= LL) return;
+  const int g = blockIdx.y;
+  const float d = dmap[p];
+  const float v0 = z0[(int64_t)(3 * g) * LL + p] + wd[3 * g] * d;
+  const float v1 = z0[(int64_t)(3 * g + 1) * LL + p] + wd[3 * g + 1] * d;
+  const float v2 = z0[(int64_t)(3 * g + 2) * LL + p] + wd[3 * g + 2] * d;
+  u[(int64_t)g * LL + p] = fmaxf(fmaxf(v0, v1), v2);
+}
+
+constexpr int STAT_SLICES = 8;
+// part[slice][c][2] = (sum, sum of squares) of u[c] over one slice of the pixels
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ u, int64_t LL,
+                                                            double* __restrict__ part) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x, sl = blockIdx.y;
+  const int64_t per = (LL + STAT_SLICES - 1) / STAT_SLICES;
+  const int64_t lo = sl * per, hi = (lo + per < LL) ? lo + per : LL;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t p = lo + threadIdx.x; p < hi; p += 256) {
+    const double v = (double)u[(int64_t)c * LL + p];
+    s1 += v;
+    s2 += v * v;
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[((int64_t)sl * CW + c) * 2 + 0] = red[0][0];
+    part[((int64_t)sl * CW + c) * 2 + 1] = red[1][0];
+  }
+}
+
+// stats[c] = sum over partials, in a fixed order
+__global__ void stats_reduce_kernel(const double* __restrict__ part, int nparts,
+                                    double* __restrict__ stats) {
+  const int c = threadIdx.x;  // 128 threads
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = 0; t < nparts; ++t) {
+    s1 += part[((int64_t)t * CW + c) * 2 + 0];
+    s2 += part[((int64_t)t * CW + c) * 2 + 1];
+  }
+  stats[c * 2 + 0] = s1;
+  stats[c * 2 + 1] = s2;
+}
+
+// InstanceNorm2d (eps 1e-5, biased variance) folded to y = u*alpha + beta' per channel
+__global__ void norm_coeff_kernel(const double* __restrict__ stats, double count,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  float* __restrict__ ab) {
+  const int c = threadIdx.x;
+  const double mean = stats[c * 2] / count;
+  double var = stats[c * 2 + 1] / count - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+  const float alpha = invstd * gamma[c];
+  ab[c * 2 + 0] = alpha;
+  ab[c * 2 + 1] = beta[c] - (float)mean * alpha;
+}
+
+__global__ __launch_bounds__(256) void stem_norm_kernel(const float* __restrict__ u,
+                                                        const float* __restrict__ ab, int L, int P,
+                                                        float* __restrict__ xpad) {
+  const int c = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= L) return;
+  const float v = u[((int64_t)c * L + y) * L + x];
+  xpad[((int64_t)c * P + y + 2) * P + x + 2] = v * ab[c * 2] + ab[c * 2 + 1];
+}
+
+int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L, float* d_xpad,
+                       hipStream_t s) {
+  const Weights& W = c->W;
+  const int64_t LL = (int64_t)L * L;
+  const int P = act_pitch(L);
+  hipLaunchKernelGGL(stem_maxout_kernel, dim3((unsigned)cdiv64(LL, 256), CW), dim3(256), 0, s, d_z0,
+                     W.stem_wd, d_dmap, LL, c->u);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(channel_stats_kernel, dim3(CW, STAT_SLICES), dim3(256), 0, s, c->u, LL,
+                     c->part);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(CW), 0, s, c->part, STAT_SLICES, c->stats);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, c->stats, (double)LL,
+                     W.stem_gamma, W.stem_beta, c->ab);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(stem_norm_kernel, dim3(cdiv(L, 256), L, CW), dim3(256), 0, s, c->u, c->ab, L,
+                     P, d_xpad);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// conv 5x5 (128 -> 512) + bias + max over channel quadruples, with per-channel sums
+//
+// Implicit GEMM on the f32 matrix cores: D[conv channel, pixel] += W[ch, (c,tap)] * X[(c,tap), pixel]
+//   M = 128 conv channels per workgroup (4 x 32-row MFMA blocks), 4 workgroups ("splits") cover 512
+//   N = 256 pixels = one 16x16 tile, as eight 4x8 patches of 32 pixels (MFMA N blocks)
+//   K = 3200 = 64 stages of (2 input channels x 25 taps); one 32x32x2 MFMA consumes a channel pair
+// Each wave owns 2 pixel patches x 4 channel blocks = 8 accumulators (128 registers).
+// Per stage the workgroup stages a 2 x 20 x 20 input halo tile and a 25 x 2 x 128 weight slab in
+// LDS (double buffered, one barrier per stage).  MFMA rows (reg&3) are 4 consecutive conv
+// channels = one maxout group, so the 4-way max is register-local.
+// ---------------------------------------------------------------------------------------
+constexpr int HALO = CONV_TILE + 4;       // 20
+constexpr int IN_PITCH = 24;              // row pitch in LDS: 4 rows x 8 columns hit 32 distinct banks
+constexpr int NTAP = 25;
+constexpr int MCH = 128;                  // conv channels per workgroup
+constexpr int NCHUNK = CW / CONV_CC;      // 64
+constexpr int W_STAGE = NTAP * CONV_CC * MCH;          // 6400 floats
+constexpr int IN_STAGE = CONV_CC * HALO * IN_PITCH;    // 960 floats
+
+__global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __restrict__ xpad,
+                                                                const float* __restrict__ wpack,
+                                                                const float* __restrict__ bias, int L,
+                                                                int P, int tiles, int nwork,
+                                                                float* __restrict__ u,
+                                                                double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float w_lds[2][W_STAGE];
+  __shared__ float in_lds[2][IN_STAGE];
+  // XCD-aware remap: block b runs on XCD b % 8; give each XCD a contiguous range of work items
+  // so the 4 channel splits of a tile and neighbouring tiles share one L2.
+  const int id = blockIdx.x;
+  const int per = gridDim.x >> 3;
+  const int work = (id & 7) * per + (id >> 3);
+  if (work >= nwork) return;
+  const int tile = work >> 2, split = work & 3;
+  const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 5, li = lane & 31;
+  const int64_t PP = (int64_t)P * P;
+
+  // staging assignments
+  const float4* wsrc = reinterpret_cast<const float4*>(wpack + (int64_t)split * NCHUNK * W_STAGE);
+  int in_off[4], in_dst[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + e * 256;   // < 800 valid
+    const int cc = idx / (HALO * HALO), rem = idx % (HALO * HALO);
+    const int yy = rem / HALO, xx = rem % HALO;
+    in_off[e] = (idx < CONV_CC * HALO * HALO) ? (int)(cc * PP + (int64_t)(ty0 + yy) * P + tx0 + xx) : -1;
+    in_dst[e] = cc * HALO * IN_PITCH + yy * IN_PITCH + xx;
+  }
+  float4 wreg[7];
+  float ireg[4];
+  auto prefetch = [&](int chunk) {
+    const float4* ws = wsrc + (int64_t)chunk * (W_STAGE / 4);
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+      const int idx = tid + e * 256;
+      if (idx < W_STAGE / 4) wreg[e] = ws[idx];
+    }
+    const float* xs = xpad + (int64_t)chunk * CONV_CC * PP;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (in_off[e] >= 0) ireg[e] = xs[in_off[e]];
+  };
+  auto commit = [&](int buf) {
+    float4* wd = reinterpret_cast<float4*>(w_lds[buf]);
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+      const int idx = tid + e * 256;
+      if (idx < W_STAGE / 4) wd[idx] = wreg[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (in_off[e] >= 0) in_lds[buf][in_dst[e]] = ireg[e];
+  };
+
+  // fragment addresses
+  int b_off[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int nb = 2 * wave + q;
+    const int y = (nb >> 1) * 4 + (li >> 3), x = (nb & 1) * 8 + (li & 7);
+    b_off[q] = kk * HALO * IN_PITCH + y * IN_PITCH + x;
+  }
+  const int a_off = kk * MCH + li;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.f;
+
+  prefetch(0);
+  commit(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < NCHUNK) prefetch(chunk + 1);
+    const float* wl = w_lds[buf] + a_off;
+    const float* il = in_lds[buf];
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int dy = tap / 5, dx = tap % 5;
+      float a[4], b[2];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) a[mb] = wl[tap * CONV_CC * MCH + mb * 32];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * IN_PITCH + dx];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
+    }
+    if (chunk + 1 < NCHUNK) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, 4-way max, store, per-channel partial sums
+  float* sred = w_lds[0];   // [wave][32 channels][2]
+  const float* bsp = bias + split * MCH;
+  const int64_t LL = (int64_t)L * L;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int cl = mb * 32 + 8 * g4 + 4 * kk;      // first conv channel of the group (local)
+      const int gch = split * 32 + (cl >> 2);         // maxout channel
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v = acc[mb][q][4 * g4] + bsp[cl];
+        v = fmaxf(v, acc[mb][q][4 * g4 + 1] + bsp[cl + 1]);
+        v = fmaxf(v, acc[mb][q][4 * g4 + 2] + bsp[cl + 2]);
+        v = fmaxf(v, acc[mb][q][4 * g4 + 3] + bsp[cl + 3]);
+        const int nb = 2 * wave + q;
+        const int y = ty0 + (nb >> 1) * 4 + (li >> 3), x = tx0 + (nb & 1) * 8 + (li & 7);
+        if (y < L && x < L) {
+          u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 32);
+        s2 += __shfl_xor(s2, off, 32);
+      }
+      if (li == 0) {
+        const int chl = (cl >> 2);                    // 0..31 within the split
+        sred[(wave * 32 + chl) * 2 + 0] = s1;
+        sred[(wave * 32 + chl) * 2 + 1] = s2;
+      }
+    }
+  __syncthreads();
+  if (tid < 64) {
+    const int chl = tid >> 1, which = tid & 1;
+    double t = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) t += (double)sred[(wv * 32 + chl) * 2 + which];
+    part[((int64_t)tile * CW + split * 32 + chl) * 2 + which] = t;
+  }
+}
+
+int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s) {
+  const int tiles = act_tiles(L);
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(CW), 0, s, c->part, tiles * tiles, d_stats);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
+                          double* d_stats, hipStream_t s, bool reduce) {
+  const BlockW& B = c->W.blk[block - 1];
+  const int tiles = act_tiles(L), P = act_pitch(L);
+  const int nwork = tiles * tiles * CONV_SPLIT;
+  const int grid = round_up(nwork, 8);
+  hipLaunchKernelGGL(conv5x5_maxout_kernel, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
+                     P, tiles, nwork, d_u, c->part);
+  DMP_LAUNCH_CHECK();
+  return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// InstanceNorm + scSE + residual (network.py:32, 37-82, 99-101), one thread per pixel:
+//   y_c = u_c*alpha_c + beta'_c ;  s = sigmoid(sum_c ws_c y_c + bs)
+//   out_c = (y_c*cse_c + y_c*s) + x_c
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_scse_residual_kernel(
+    const float* __restrict__ u, const float* __restrict__ ab, const float* __restrict__ cse,
+    const float* __restrict__ sse_w, float sse_b, const float* __restrict__ xin, int L, int P,
+    float* __restrict__ xout) {
+  __shared__ float sh_a[CW], sh_b[CW], sh_g[CW], sh_w[CW];
+  if (threadIdx.x < CW) {
+    sh_a[threadIdx.x] = ab[threadIdx.x * 2];
+    sh_b[threadIdx.x] = ab[threadIdx.x * 2 + 1];
+    sh_g[threadIdx.x] = cse[threadIdx.x];
+    sh_w[threadIdx.x] = sse_w[threadIdx.x];
+  }
+  __syncthreads();
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= L) return;
+  const int64_t LL = (int64_t)L * L, PP = (int64_t)P * P;
+  const int64_t p = (int64_t)y * L + x, pp = (int64_t)(y + 2) * P + x + 2;
+  float yv[CW];
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    yv[c] = u[c * LL + p] * sh_a[c] + sh_b[c];
+    dot = fmaf(sh_w[c], yv[c], dot);
+  }
+  const float sg = sigmoid_f(dot + sse_b);
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const float t = __fadd_rn(__fmul_rn(yv[c], sh_g[c]), __fmul_rn(yv[c], sg));
+    xout[c * PP + pp] = __fadd_rn(t, xin[c * PP + pp]);
+  }
+}
+
+int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
+                              const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s) {
+  const BlockW& B = c->W.blk[block - 1];
+  const int P = act_pitch(L);
+  hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, d_stats, (double)L * (double)L,
+                     B.gamma, B.beta, c->ab);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(norm_scse_residual_kernel, dim3(cdiv(L, 256), L), dim3(256), 0, s, d_u, c->ab,
+                     B.cse, B.sse_w, B.sse_b, d_xpad_in, L, P, d_xpad_out);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// head 1x1 conv (128 -> 2), row means of channel 1, Gram matrix of |sym(channel 0)|
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ xpad,
+                                                   const float* __restrict__ hw, float b0, float b1,
+                                                   int L, int P, float* __restrict__ head0,
+                                                   float* __restrict__ conf) {
+  __shared__ float sw[2 * CW];
+  __shared__ double red[256];
+  sw[threadIdx.x] = hw[threadIdx.x];
+  __syncthreads();
+  const int i = blockIdx.x;
+  const int64_t PP = (int64_t)P * P;
+  double rsum = 0.0;
+  for (int j = threadIdx.x; j < L; j += 256) {
+    const float* px = xpad + (int64_t)(i + 2) * P + j + 2;
+    float o0 = 0.f, o1 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < CW; ++c) {
+      const float v = px[c * PP];
+      o0 = fmaf(sw[c], v, o0);
+      o1 = fmaf(sw[CW + c], v, o1);
+    }
+    head0[(int64_t)i * L + j] = o0 + b0;
+    rsum += (double)(o1 + b1);
+  }
+  red[threadIdx.x] = rsum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) conf[i] = (float)(red[0] / (double)L);
+}
+
+// dm = |(h + h^T)/2| ; M_ij = 0.5*((dm_0j^2 + dm_i0^2) - dm_ij^2), every step rounded to f32
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ h0, int L,
+                                                   float* __restrict__ M) {
+  const int i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= L) return;
+  auto dm = [&](int a, int b) {
+    return fabsf(__fmul_rn(__fadd_rn(h0[(int64_t)a * L + b], h0[(int64_t)b * L + a]), 0.5f));
+  };
+  const float d0j = dm(0, j), di0 = dm(i, 0), dij = dm(i, j);
+  const float t = __fadd_rn(__fmul_rn(d0j, d0j), __fmul_rn(di0, di0));
+  M[(int64_t)i * L + j] = __fmul_rn(0.5f, __fadd_rn(t, -__fmul_rn(dij, dij)));
+}
+
+int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
+                     hipStream_t s) {
+  const Weights& W = c->W;
+  const int P = act_pitch(L);
+  hipLaunchKernelGGL(head_kernel, dim3(L), dim3(256), 0, s, d_xpad, W.head_w, W.head_b[0],
+                     W.head_b[1], L, P, c->head0, d_conf);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_kernel, dim3(cdiv(L, 256), L), dim3(256), 0, s, c->head0, L, d_M);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+}  // namespace dmp

@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's prediction interface on the HIP engine.
+
+`aln_to_coords` and `run_dmpfold` keep the names, argument meaning, return types and
+error behaviour of the reference (dmpfold/predict.py:74-158 and 160-208); all
+arithmetic happens in libdmpfold_hip.so through the C ABI of include/dmpfold_hip.h.
+PyTorch is used only for device memory and the current stream.
+
+Differences from the reference, all additive or forced by the environment:
+  * there is no CPU path: `device` must name a GPU ("cuda", "cuda:1", an int, or a
+    torch.device).  The default is "cuda" (the reference defaults to "cpu");
+  * packed weights are cached per (device, weights file) instead of being rebuilt on
+    every call (the reference constructs and loads a fresh network each time);
+  * eigenvector signs of the MDS step follow a fixed rule (see include/dmpfold_hip.h);
+  * missing trained weights raise FileNotFoundError (no download: predict.py:64-71).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib
+
+default_device = "cuda"
+default_iterations = 10
+default_minsteps = 100
+
+MAX_SEQS = 3000     # predict.py:130-132
+
+_RESNAMES = {0: "ALA", 1: "ARG", 2: "ASN", 3: "ASP", 4: "CYS", 5: "GLN", 6: "GLU", 7: "GLY",
+             8: "HIS", 9: "ILE", 10: "LEU", 11: "LYS", 12: "MET", 13: "PHE", 14: "PRO",
+             15: "SER", 16: "THR", 17: "TRP", 18: "TYR", 19: "VAL"}
+
+
+# ---------------------------------------------------------------------------
+# host-side parsing (pure Python / C-ABI host helper, no GPU needed)
+# ---------------------------------------------------------------------------
+def read_aln(input_file):
+    """Lines not starting with '>', right-stripped (predict.py:100-104)."""
+    rows = []
+    with open(input_file, "r") as fh:
+        for line in fh.readlines():
+            if not line.startswith(">"):
+                rows.append(line.rstrip())
+    return rows
+
+
+def encode_aln(rows):
+    """Residue letters -> uint8 codes (N, L), capped at 3000 rows (predict.py:124-132).
+    Ragged input raises ValueError from the reshape, as in the reference."""
+    nseqs = len(rows)
+    length = len(rows[0])
+    text = np.frombuffer("".join(rows).encode("latin-1"), dtype=np.uint8)
+    codes = np.empty_like(text)
+    lib = _lib.load()
+    _lib.check(lib.dmp_msa_encode(text.ctypes.data, text.size, codes.ctypes.data))
+    alnmat = codes.reshape(nseqs, length)
+    if nseqs > MAX_SEQS:
+        alnmat = alnmat[:MAX_SEQS]
+    return alnmat
+
+
+def read_template_ca(template):
+    """CA atoms of ATOM records, fixed PDB columns (predict.py:106-117)."""
+    xyz = []
+    with open(template, "r") as fh:
+        for line in fh:
+            if line[:4] == "ATOM" and line[12:16] == " CA ":
+                xyz.append(np.array([float(line[30:38]), float(line[38:46]), float(line[46:54])],
+                                    dtype=np.float32))
+    return np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+
+
+def _resolve_device(device):
+    dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+    if dev.type != "cuda":
+        raise RuntimeError(
+            f"dmpfold2_amd runs on AMD GPUs only (got device '{device}'); there is no CPU path")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible to PyTorch-ROCm; dmpfold2_amd has no CPU fallback")
+    return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def default_weight_files():
+    modeldir = os.path.join(os.path.dirname(os.path.realpath(__file__)), "trained_model")
+    return [os.path.join(modeldir, f"FINAL_fullmap_e2e_model_part{p}.pt") for p in ("1", "2")]
+
+
+def load_state_dict(weights_file=None):
+    """The reference's weight files: one pickled state_dict, or the two-part default that is
+    merged with dict.update (predict.py:81-96)."""
+    if weights_file is None:
+        parts = default_weight_files()
+        if not os.path.isfile(parts[0]):
+            raise FileNotFoundError(
+                f"trained model not found at {parts[0]}; the reference would download it, this "
+                "build does not: place the two FINAL_fullmap_e2e_model_part*.pt files there or "
+                "pass weights_file=/-w")
+        sd = torch.load(parts[0], map_location="cpu")
+        sd.update(torch.load(parts[1], map_location="cpu"))
+    else:
+        sd = torch.load(weights_file, map_location="cpu")
+    return sd
+
+
+# ---------------------------------------------------------------------------
+# engine: one dmp_ctx per GPU
+# ---------------------------------------------------------------------------
+class Engine:
+    """Owns one `dmp_ctx` (device buffers + packed weights) on one GPU."""
+
+    def __init__(self, device, max_L, max_N):
+        self.lib = _lib.load()
+        self.device = _resolve_device(device)
+        self.max_L = int(max_L)
+        self.max_N = int(min(max_N, MAX_SEQS))
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dmp_ctx_create(self.device.index, self.max_L, self.max_N,
+                                               C.byref(self._ctx)))
+        self.weights_tag = None
+
+    def close(self):
+        if self._ctx:
+            self.lib.dmp_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    @property
+    def device_bytes(self):
+        return int(self.lib.dmp_ctx_device_bytes(self._ctx))
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_weights(self, state_dict, tag=None):
+        """Strict load like load_state_dict (predict.py:98): unknown, missing or mis-shaped
+        tensors raise RuntimeError."""
+        for key, val in state_dict.items():
+            arr = np.ascontiguousarray(
+                val.detach().cpu().float().numpy() if isinstance(val, torch.Tensor) else val,
+                dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _lib.check(self.lib.dmp_weights_set(self._ctx, key.encode(), arr.ctypes.data, shape,
+                                                arr.ndim), RuntimeError)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dmp_weights_finalize(self._ctx), RuntimeError)
+        self.weights_tag = tag
+
+    def predict(self, alnmat, template_ca=None, iterations=default_iterations,
+                minsteps=default_minsteps):
+        """codes (N, L) uint8 -> (coords (L,5,3), confs (L,)) float32 tensors on the GPU."""
+        alnmat = np.ascontiguousarray(alnmat, dtype=np.uint8)
+        n, L = alnmat.shape
+        if L < 8:
+            raise RuntimeError(f"alignment has {L} columns; the network needs at least 8 "
+                               "(MDS embedding width, reference network.py:250-253)")
+        with torch.cuda.device(self.device):
+            d_msa = torch.from_numpy(alnmat).to(self.device)
+            coords = torch.empty((L, 5, 3), dtype=torch.float32, device=self.device)
+            confs = torch.empty((L,), dtype=torch.float32, device=self.device)
+            d_tpl, lt = None, 0
+            if template_ca is not None:
+                d_tpl = torch.as_tensor(template_ca, dtype=torch.float32).reshape(-1, 3).to(self.device)
+                lt = d_tpl.shape[0]
+                if lt != L:
+                    raise RuntimeError(f"Sizes of tensors must match: template has {lt} CA atoms, "
+                                       f"alignment has {L} columns")
+            _lib.check(self.lib.dmp_predict(
+                self._ctx, d_msa.data_ptr(), n, L,
+                d_tpl.data_ptr() if d_tpl is not None else None, lt,
+                int(max(iterations, 0)), int(max(minsteps, 0)),
+                coords.data_ptr(), confs.data_ptr(), self.stream()))
+            # d_msa / d_tpl are stream-ordered temporaries: keep them alive until the work is queued
+            self._keep = (d_msa, d_tpl)
+        return coords, confs
+
+    def fetch(self, name, numel):
+        out = torch.empty((int(numel),), dtype=torch.float32, device=self.device)
+        n = _lib.check(self.lib.dmp_debug_fetch(self._ctx, name.encode(), out.data_ptr(),
+                                                int(numel), self.stream()))
+        return out[:n]
+
+
+_ENGINES = {}
+
+
+def get_engine(device, L, N, weights_file=None, state_dict=None):
+    """Cached engine for `device`, grown when an alignment exceeds its capacity; weights are
+    packed once per (engine, weights file)."""
+    dev = _resolve_device(device)
+    eng = _ENGINES.get(dev.index)
+    if eng is None or L > eng.max_L or min(N, MAX_SEQS) > eng.max_N:
+        old = eng
+        max_L = max(L, old.max_L if old else 0)
+        max_N = max(min(N, MAX_SEQS), old.max_N if old else 0)
+        if old is not None:
+            old.close()
+        eng = Engine(dev, max_L, max_N)
+        _ENGINES[dev.index] = eng
+    if state_dict is not None:
+        eng.set_weights(state_dict, tag=None)
+    else:
+        files = [weights_file] if weights_file is not None else default_weight_files()
+        tag = tuple((f, os.path.getmtime(f)) for f in files if os.path.isfile(f))
+        if eng.weights_tag != tag or not tag:
+            eng.set_weights(load_state_dict(weights_file), tag=tag)
+    return eng
+
+
+# ---------------------------------------------------------------------------
+# the reference's public functions
+# ---------------------------------------------------------------------------
+def aln_to_coords(input_file, device=default_device, template=None, iterations=default_iterations,
+                  minsteps=default_minsteps, weights_file=None, return_alnmat=False):
+    """Alignment file -> (coords (L,5,3) [N, CA, C, O, CB], confs (L,)) on `device`,
+    plus the uint8 alignment matrix when `return_alnmat` is set (predict.py:74-158)."""
+    dev = _resolve_device(device)
+    aln = read_aln(input_file)
+    template_ca = read_template_ca(template) if template is not None else None
+    alnmat = encode_aln(aln)
+    nseqs, length = alnmat.shape
+    eng = get_engine(dev, length, nseqs, weights_file=weights_file)
+    coords, confs = eng.predict(alnmat, template_ca, iterations, minsteps)
+    if return_alnmat:
+        return coords, confs, alnmat
+    return coords, confs
+
+
+def pdb_text(coords, confs, alnmat):
+    """The PDB text of predict.py:195-208 from host copies of the outputs."""
+    coords = coords.detach().cpu()
+    confs = confs.detach().cpu()
+    lines = ["REMARK  CONF:  " + repr(confs.mean().item())]
+    atoms = (" N  ", " CA ", " C  ", " O  ", " CB ")
+    atomnum = 1
+    for ri in range(coords.size(0)):
+        code = int(alnmat[0, ri])
+        for ai, an in enumerate(atoms):
+            if code != 7 or ai != 4:          # glycine has no CB
+                lines.append("ATOM   %4d %s %s  %4d    %8.3f%8.3f%8.3f  1.00%6.2f" % (
+                    atomnum, an, _RESNAMES[code], ri + 1, coords[ri, ai, 0].item(),
+                    coords[ri, ai, 1].item(), coords[ri, ai, 2].item(), confs[ri]))
+                atomnum += 1
+    lines.append("END")
+    return "\n".join(lines) + "\n"
+
+
+def run_dmpfold(argv=None):
+    """Command-line entry point with the reference's flags (predict.py:160-208)."""
+    parser = argparse.ArgumentParser(description=(
+        "DMPfold2 end-to-end structure prediction on AMD MI355X (HIP engine). "
+        "Prints a PDB format model file."))
+    parser.add_argument("-i", "--input_file", type=str, required=True,
+                        help="input sequence alignment in aln format")
+    parser.add_argument("-d", "--device", type=str, default=default_device, required=False,
+                        help="device to run on (cuda, cuda:1, ...)")
+    parser.add_argument("-t", "--template", type=str, required=False,
+                        help="use a PDB file as a template")
+    parser.add_argument("-n", "--iterations", type=int, default=default_iterations, required=False,
+                        help="number of iteration cycles")
+    parser.add_argument("-m", "--minsteps", type=int, default=default_minsteps, required=False,
+                        help="number of minimization steps")
+    parser.add_argument("-w", "--model_weights", type=str, required=False,
+                        help="use a custom set of model weights")
+    args = parser.parse_args(argv)
+    coords, confs, alnmat = aln_to_coords(args.input_file, device=args.device,
+                                          template=args.template, iterations=args.iterations,
+                                          minsteps=args.minsteps, weights_file=args.model_weights,
+                                          return_alnmat=True)
+    sys.stdout.write(pdb_text(coords, confs, alnmat))

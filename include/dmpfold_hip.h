@@ -151,9 +151,15 @@ int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d
 /* ---- introspection for tests and the benchmark ------------------------------------------- */
 /* After dmp_predict: copy an internal tensor to d_dst (device).  Names: "w", "contacts",
  * "mat1d", "conf_means" (P floats), "ca_pass" (P x L x 3), "best_ca" (L x 3, before the final
- * refinement).  Returns the number of floats written or a negative status. */
+ * refinement), "inv_cov" (21L x 21L), "mds" (L x 8) and "gram" (L x L) of the last pass.  Returns the number of floats written or a negative status. */
 int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t capacity,
                         void* stream);
+/* Optional HIP-event timing of every conv5x5 launch inside dmp_predict / dmp_trunk_pass (events
+ * are recorded on the caller's stream around each launch; up to max_launches per read-out).
+ * dmp_profile_conv_ms returns the mean launch duration since the last read-out (the caller
+ * must have synchronised the stream) and resets the counter. */
+int dmp_profile_enable(dmp_ctx* ctx, int on, int max_launches);
+int dmp_profile_conv_ms(dmp_ctx* ctx, float* h_avg_ms, int* h_launches);
 /* Time the pair-trunk convolution kernel alone with HIP events on `stream`: runs `iters`
  * launches of block `block` at length L on internal buffers, returns average ms per launch. */
 int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, void* stream);

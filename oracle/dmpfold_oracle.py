@@ -194,30 +194,50 @@ def cse_gate(weights, k):
 def pair_trunk(weights, resinp, capture=None, tag=""):
     """Stem + 16 maxout/scSE residual blocks + head   (network.py:12-103,
     194-207).  resinp: (1, 955, L, L) -> (1, 2, L, L)."""
-    L = resinp.shape[-1]
-    x = F.conv2d(resinp, weights["resnet.0.lin.weight"], weights["resnet.0.lin.bias"])
-    x = x.view(1, 128, 3, L, L).max(dim=2)[0]
-    x = F.instance_norm(x, weight=weights["resnet.0.norm.weight"],
-                        bias=weights["resnet.0.norm.bias"], eps=1e-5)
+    x = stem(weights, resinp)
     if capture is not None:
         capture[tag + "stem"] = x
     for k in range(1, 17):
-        p = f"resnet.{k}"
-        u = F.conv2d(x, weights[p + ".layer1.lin.weight"], weights[p + ".layer1.lin.bias"],
-                     padding=2)
-        u = u.view(1, 128, 4, L, L).max(dim=2)[0]
-        y = F.instance_norm(u, weight=weights[p + ".layer1.norm.weight"],
-                            bias=weights[p + ".layer1.norm.bias"], eps=1e-5)
-        # cSE: per-channel gate from the spatial mean of y
-        m = y.mean(dim=(2, 3))
-        gate = torch.sigmoid(torch.relu(m @ weights[p + ".scSE.cSE.fc.0.weight"].t())
-                             @ weights[p + ".scSE.cSE.fc.2.weight"].t())
-        # sSE: per-pixel gate from a 1x1 conv over channels
-        s = torch.sigmoid(F.conv2d(y, weights[p + ".scSE.sSE.conv.weight"],
-                                   weights[p + ".scSE.sSE.conv.bias"]))
-        x = y * gate.view(1, 128, 1, 1) + y * s + x
+        x = block_finish(weights, k, block_conv(weights, k, x), x)
         if capture is not None and k in (1, 16):
             capture[tag + f"block{k}"] = x
+    return head(weights, x)
+
+
+def stem(weights, resinp):
+    """network.py:25-32 with pool 3, kernel 1: conv, max over channel triples, InstanceNorm."""
+    L = resinp.shape[-1]
+    x = F.conv2d(resinp, weights["resnet.0.lin.weight"], weights["resnet.0.lin.bias"])
+    x = x.view(1, 128, 3, L, L).max(dim=2)[0]
+    return F.instance_norm(x, weight=weights["resnet.0.norm.weight"],
+                           bias=weights["resnet.0.norm.bias"], eps=1e-5)
+
+
+def block_conv(weights, k, x):
+    """network.py:25-31 for block k: 5x5 conv (pad 2) + max over channel quadruples."""
+    L = x.shape[-1]
+    p = f"resnet.{k}"
+    u = F.conv2d(x, weights[p + ".layer1.lin.weight"], weights[p + ".layer1.lin.bias"], padding=2)
+    return u.view(1, 128, 4, L, L).max(dim=2)[0]
+
+
+def block_finish(weights, k, u, x):
+    """network.py:32 + 37-82 + 99-101: InstanceNorm, scSE gates, residual add."""
+    p = f"resnet.{k}"
+    y = F.instance_norm(u, weight=weights[p + ".layer1.norm.weight"],
+                        bias=weights[p + ".layer1.norm.bias"], eps=1e-5)
+    # cSE: per-channel gate from the spatial mean of y
+    m = y.mean(dim=(2, 3))
+    gate = torch.sigmoid(torch.relu(m @ weights[p + ".scSE.cSE.fc.0.weight"].t())
+                         @ weights[p + ".scSE.cSE.fc.2.weight"].t())
+    # sSE: per-pixel gate from a 1x1 conv over channels
+    s = torch.sigmoid(F.conv2d(y, weights[p + ".scSE.sSE.conv.weight"],
+                               weights[p + ".scSE.sSE.conv.bias"]))
+    return y * gate.view(1, 128, 1, 1) + y * s + x
+
+
+def head(weights, x):
+    """network.py:207: 1x1 conv 128 -> 2."""
     return F.conv2d(x, weights["resnet.17.weight"], weights["resnet.17.bias"])
 
 

@@ -1,0 +1,141 @@
+"""Thin helper for the GPU tests: call C-ABI stage functions with torch tensors."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from dmpfold2_amd import _lib
+from dmpfold2_amd.predict import Engine
+
+
+class Stages:
+    def __init__(self, state_dict, max_L=128, max_N=512, device="cuda:0"):
+        self.eng = Engine(device, max_L, max_N)
+        self.eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in state_dict.items()})
+        self.lib = self.eng.lib
+        self.dev = self.eng.device
+
+    def _s(self):
+        return self.eng.stream()
+
+    def f32(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def to(self, a, dtype=torch.float32):
+        return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(self.dev).contiguous()
+
+    def call(self, name, *args):
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                assert a.is_contiguous() and a.device.type == "cuda"
+                conv.append(a.data_ptr())
+            else:
+                conv.append(a)
+        rc = getattr(self.lib, name)(self.eng.ctx, *conv, self._s())
+        _lib.check(rc)
+        return rc
+
+    # ---- stages ----------------------------------------------------------------------
+    def msa_weights(self, alnmat):
+        m = self.to(alnmat, torch.uint8)
+        n, L = m.shape
+        w = self.f32(n)
+        self.call("dmp_msa_weights", m, n, L, w)
+        return w
+
+    def cov_build(self, alnmat, w):
+        m = self.to(alnmat, torch.uint8)
+        n, L = m.shape
+        cov = self.f32(21 * L, 21 * L)
+        self.call("dmp_cov_build", m, w, n, L, cov)
+        return cov
+
+    def spd_inverse(self, a):
+        a = a.clone()
+        self.call("dmp_spd_inverse", a, a.shape[0])
+        return a
+
+    def dca_contacts(self, inv, L):
+        out = self.f32(L, L)
+        self.call("dmp_dca_contacts", inv, L, out)
+        return out
+
+    def gru_vertical(self, alnmat):
+        m = self.to(alnmat, torch.uint8)
+        n, L = m.shape
+        out = self.f32(L, 512)
+        self.call("dmp_gru_vertical", m, n, L, out)
+        return out
+
+    def gru_bidir(self, which, x):
+        T = x.shape[0]
+        out = self.f32(T, 512)
+        self.call("dmp_gru_bidir", which, x, T, out)
+        return out
+
+    def stem_static(self, mat1d, inv, contacts):
+        L = mat1d.shape[1]
+        z0 = self.f32(384, L, L)
+        self.call("dmp_stem_static", mat1d, inv, contacts, L, z0)
+        return z0
+
+    def stem_update(self, z0, dmap):
+        L = dmap.shape[0]
+        x = self.f32(128, L, L)
+        self.call("dmp_stem_update", z0, dmap, L, x)
+        return x
+
+    def conv(self, block, x):
+        L = x.shape[-1]
+        u = self.f32(128, L, L)
+        st = torch.empty((128, 2), dtype=torch.float64, device=self.dev)
+        self.call("dmp_block_conv5x5_maxout", block, x, L, u, st)
+        return u, st
+
+    def norm(self, block, u, st, x):
+        L = x.shape[-1]
+        out = self.f32(128, L, L)
+        self.call("dmp_block_norm_scse_residual", block, u, st, x, L, out)
+        return out
+
+    def head_gram(self, x):
+        L = x.shape[-1]
+        conf, M = self.f32(L), self.f32(L, L)
+        self.call("dmp_head_gram", x, L, conf, M)
+        return conf, M
+
+    def trunk_pass(self, z0, dmap):
+        L = dmap.shape[0]
+        conf, M = self.f32(L), self.f32(L, L)
+        self.call("dmp_trunk_pass", z0, dmap, L, conf, M)
+        return conf, M
+
+    def eigh_top8(self, M):
+        L = M.shape[0]
+        out = self.f32(L, 8)
+        self.call("dmp_eigh_top8", M, L, out)
+        return out
+
+    def coords_from_mds(self, mat1d, mds):
+        L = mds.shape[0]
+        ca = self.f32(L, 3)
+        self.call("dmp_coords_from_mds", mat1d, mds, L, ca)
+        return ca
+
+    def pair_distances(self, ca, clamp=1):
+        L = ca.shape[0]
+        d = self.f32(L, L)
+        self.call("dmp_pair_distances", ca, L, clamp, d)
+        return d
+
+    def refine(self, ca, steps):
+        ca = ca.clone()
+        self.call("dmp_refine_coords", ca, ca.shape[0], steps)
+        return ca
+
+    def backbone(self, ca, logit):
+        L = ca.shape[0]
+        coords, conf = self.f32(L, 5, 3), self.f32(L)
+        self.call("dmp_ca_to_backbone", ca, logit, L, coords, conf)
+        return coords, conf

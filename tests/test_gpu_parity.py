@@ -1,0 +1,342 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the goldens.
+
+Every test feeds a HIP stage the ORACLE's input for that stage, so one stage's error never
+hides in another's.  Tolerances (SURVEY.md section 8c / BASELINE.json north_star):
+  integer / index work        bit exact
+  covariance, inverse, APC    relative 1e-5 of the tensor's scale
+  GRU states                  absolute 1e-5
+  trunk activations           absolute 1e-4 * max(1, scale)
+  end to end (m = 0)          CA-RMSD <= 1e-3 Angstrom, |dconf| < 1e-4
+"""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, golden_rows, ca_rmsd
+
+pytestmark = pytest.mark.gpu
+
+import dmpfold_oracle as O          # noqa: E402  (test infrastructure)
+
+
+@pytest.fixture(scope="module")
+def st(synth_sd):
+    from abi import Stages
+    return Stages(synth_sd, max_L=128, max_N=3000)
+
+
+@pytest.fixture(scope="module")
+def pf():
+    return load_golden("pf10963_n0_m0")
+
+
+@pytest.fixture(scope="module")
+def ocap(pf, oracle_weights):
+    """Oracle stage tensors for PF10963, n=0 m=0."""
+    cap = {}
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    O.predict(pf["alnmat"], oracle_weights, None, 0, 0, "canonical", cap)
+    return cap
+
+
+def scale_tol(ref, rel):
+    return rel * max(1.0, float(np.abs(ref).max()))
+
+
+# ---------------------------------------------------------------------------- features
+@pytest.mark.parametrize("name", ["pf10963_n0_m0", "synth_L40_N64_n2_m0", "synth_L24_N3050_n1_m0",
+                                  "alphabet_L16_N12_n0_m0", "template_L96_N50_n1_m0"])
+def test_msa_weights_bit_exact(st, name):
+    g = load_golden(name)
+    w = st.msa_weights(g["alnmat"]).cpu().numpy()
+    assert np.array_equal(w, g["w"])
+    assert np.array_equal(w, O.reweight(g["alnmat"]))
+
+
+def test_msa_weights_ragged_sizes(st):
+    rng = np.random.default_rng(1)
+    for n, L in [(1, 9), (2, 8), (65, 13), (130, 127), (257, 33)]:
+        a = rng.integers(0, 22, size=(n, L)).astype(np.uint8)
+        a[n // 2] = a[0]                       # force at least one close pair
+        assert np.array_equal(st.msa_weights(a).cpu().numpy(), O.reweight(a))
+
+
+def test_covariance_inverse_contacts(st, pf, ocap):
+    w = st.to(ocap["w"].numpy())
+    cov = st.cov_build(pf["alnmat"], w).cpu().numpy()
+    ref = ocap["cov_reg"].numpy()
+    assert np.abs(cov - ref).max() <= scale_tol(ref, 1e-5)
+    inv = st.spd_inverse(st.to(ref)).cpu().numpy()
+    iref = ocap["inv_cov"].numpy()
+    assert np.abs(inv - iref).max() <= scale_tol(iref, 1e-5)
+    con = st.dca_contacts(st.to(iref), pf["alnmat"].shape[1]).cpu().numpy()
+    cref = ocap["contacts"].numpy()
+    assert np.abs(con - cref).max() <= scale_tol(cref, 1e-5)
+    assert np.abs(con - pf["contacts"]).max() <= scale_tol(cref, 1e-5)     # golden from the reference
+
+
+def test_spd_inverse_identity_property(st):
+    rng = np.random.default_rng(3)
+    for D in (21 * 9, 21 * 13 + 0, 300):
+        B = rng.standard_normal((D, D + 40)).astype(np.float32)
+        A = (B @ B.T) / (D + 40) + 0.3 * np.eye(D, dtype=np.float32)
+        inv = st.spd_inverse(st.to(A)).cpu().numpy().astype(np.float64)
+        assert np.abs(inv @ A.astype(np.float64) - np.eye(D)).max() < 5e-5
+
+
+# ---------------------------------------------------------------------------- sequence trunk
+def test_gru_vertical(st, pf, oracle_weights):
+    idx = torch.from_numpy(pf["alnmat"].astype(np.int64))
+    x = oracle_weights["embed.weight"][idx]
+    ref = O._gru(oracle_weights, "vgru", x, 22, 512, 2, False, False)[-1].numpy()
+    got = st.gru_vertical(pf["alnmat"]).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-5
+    assert np.abs(got - pf["vgru_last"]).max() < 1e-5                      # golden
+
+
+def test_gru_vertical_deep_and_truncated(st, oracle_weights):
+    g = load_golden("synth_L24_N3050_n1_m0")
+    a = g["alnmat"]                                                        # 3000 x 24 after the cap
+    x = oracle_weights["embed.weight"][torch.from_numpy(a.astype(np.int64))]
+    ref = O._gru(oracle_weights, "vgru", x, 22, 512, 2, False, False)[-1].numpy()
+    assert np.abs(st.gru_vertical(a).cpu().numpy() - ref).max() < 1e-5
+
+
+def test_gru_bidir(st, pf, ocap, oracle_weights):
+    vin = torch.from_numpy(pf["vgru_last"])
+    ref = O._gru(oracle_weights, "hgru", vin.unsqueeze(1), 512, 256, 2, True, False)[:, 0].numpy()
+    got = st.gru_bidir(0, st.to(pf["vgru_last"])).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-5
+    assert np.abs(got.T - pf["mat1d"]).max() < 1e-5
+    emb = torch.cat((ocap["mat1d"].t(), ocap["p0.mds"]), dim=1)
+    ref = O._gru(oracle_weights, "coord_gru", emb.unsqueeze(0), 520, 256, 3, True, True)[0].numpy()
+    got = st.gru_bidir(1, st.to(emb.numpy())).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-5
+
+
+# ---------------------------------------------------------------------------- pair trunk
+def _resinp(ocap, pf, dmap):
+    L = pf["alnmat"].shape[1]
+    m = ocap["mat1d"]
+    pair = (m.unsqueeze(1) * m.unsqueeze(2)).unsqueeze(0)
+    inv = ocap["inv_cov"].view(L, 21, L, 21).transpose(1, 2).reshape(L, L, 441)
+    f2d = torch.cat((inv, ocap["contacts"][:, :, None]), dim=2).permute(2, 0, 1).unsqueeze(0)
+    return torch.cat((pair, f2d, dmap.view(1, 1, L, L)), dim=1)
+
+
+def test_stem(st, pf, ocap, oracle_weights):
+    L = pf["alnmat"].shape[1]
+    dmap = torch.zeros(L, L) - 1
+    ref = O.stem(oracle_weights, _resinp(ocap, pf, dmap))[0].numpy()
+    z0 = st.stem_static(st.to(ocap["mat1d"].numpy()), st.to(ocap["inv_cov"].numpy()),
+                        st.to(ocap["contacts"].numpy()))
+    got = st.stem_update(z0, st.to(dmap.numpy())).cpu().numpy()
+    assert np.abs(got - ref).max() <= scale_tol(ref, 1e-4)
+    # a different distance channel re-uses the same static part
+    ca = torch.from_numpy(np.random.default_rng(0).standard_normal((L, 3)).astype(np.float32) * 8)
+    dmap2 = O.pair_distances(ca)
+    ref2 = O.stem(oracle_weights, _resinp(ocap, pf, dmap2))[0].numpy()
+    got2 = st.stem_update(z0, st.pair_distances(st.to(ca.numpy()))).cpu().numpy()
+    assert np.abs(got2 - ref2).max() <= scale_tol(ref2, 1e-4)
+
+
+def test_stem_single_sequence(st, oracle_weights):
+    """N = 1: zero DCA features (predict.py:139) -> d_inv = d_contacts = NULL."""
+    L = 30
+    m = torch.from_numpy(np.random.default_rng(5).standard_normal((512, L)).astype(np.float32) * 0.2)
+    pair = (m.unsqueeze(1) * m.unsqueeze(2)).unsqueeze(0)
+    dmap = torch.zeros(L, L) - 1
+    resinp = torch.cat((pair, torch.zeros(1, 442, L, L), dmap.view(1, 1, L, L)), dim=1)
+    ref = O.stem(oracle_weights, resinp)[0].numpy()
+    z0 = st.stem_static(st.to(m.numpy()), None, None)
+    got = st.stem_update(z0, st.to(dmap.numpy())).cpu().numpy()
+    assert np.abs(got - ref).max() <= scale_tol(ref, 1e-4)
+
+
+@pytest.mark.parametrize("block", [1, 7, 16])
+def test_block(st, ocap, oracle_weights, block):
+    x = ocap["p0.stem"] if block == 1 else ocap["p0.block1"]
+    u_ref = O.block_conv(oracle_weights, block, x)
+    u, stats = st.conv(block, st.to(x[0].numpy()))
+    assert np.abs(u.cpu().numpy() - u_ref[0].numpy()).max() <= scale_tol(u_ref.numpy(), 1e-5)
+    s_ref = torch.stack((u_ref[0].double().sum(dim=(1, 2)), (u_ref[0].double() ** 2).sum(dim=(1, 2))), 1)
+    assert np.abs(stats.cpu().numpy() - s_ref.numpy()).max() <= 1e-5 * float(s_ref.abs().max())
+    out_ref = O.block_finish(oracle_weights, block, u_ref, x)[0].numpy()
+    out = st.norm(block, st.to(u_ref[0].numpy()), st.to(s_ref.numpy(), torch.float64),
+                  st.to(x[0].numpy())).cpu().numpy()
+    assert np.abs(out - out_ref).max() <= scale_tol(out_ref, 1e-5)
+
+
+@pytest.mark.parametrize("L", [17, 33, 96])
+def test_block_odd_sizes(st, oracle_weights, L):
+    x = torch.from_numpy(np.random.default_rng(L).standard_normal((1, 128, L, L)).astype(np.float32))
+    u_ref = O.block_conv(oracle_weights, 2, x)
+    u, stats = st.conv(2, st.to(x[0].numpy()))
+    assert np.abs(u.cpu().numpy() - u_ref[0].numpy()).max() <= scale_tol(u_ref.numpy(), 1e-5)
+    out_ref = O.block_finish(oracle_weights, 2, u_ref, x)[0].numpy()
+    out = st.norm(2, u, stats, st.to(x[0].numpy())).cpu().numpy()
+    assert np.abs(out - out_ref).max() <= scale_tol(out_ref, 1e-4)
+
+
+def test_head_gram_and_trunk_pass(st, pf, ocap, oracle_weights):
+    x = ocap["p0.block16"]
+    y = O.head(oracle_weights, x)
+    dm, conf, M = O.head_to_gram(y)
+    gconf, gM = st.head_gram(st.to(x[0].numpy()))
+    assert np.abs(gconf.cpu().numpy() - conf[0].numpy()).max() < 1e-4
+    assert np.abs(gM.cpu().numpy() - M[0].numpy()).max() <= scale_tol(M.numpy(), 1e-5)
+    assert np.abs(gM.cpu().numpy() - gM.cpu().numpy().T).max() == 0.0        # exactly symmetric
+    # whole pass on internal buffers
+    L = pf["alnmat"].shape[1]
+    z0 = st.stem_static(st.to(ocap["mat1d"].numpy()), st.to(ocap["inv_cov"].numpy()),
+                        st.to(ocap["contacts"].numpy()))
+    tconf, tM = st.trunk_pass(z0, st.to((torch.zeros(L, L) - 1).numpy()))
+    assert np.abs(tconf.cpu().numpy() - ocap["p0.conf"].numpy()).max() < 1e-4
+    assert np.abs(tM.cpu().numpy() - ocap["p0.M"].numpy()).max() <= scale_tol(ocap["p0.M"].numpy(), 1e-4)
+
+
+# ---------------------------------------------------------------------------- coordinates
+def test_eigh_top8(st, ocap):
+    M = ocap["p0.M"]
+    ref = O.mds_top8(M.unsqueeze(0), "canonical")[0].numpy()
+    got = st.eigh_top8(st.to(M.numpy())).cpu().numpy()
+    # float64 solve on the device vs float32 LAPACK in the oracle: compare with the float64 truth too
+    lam, vec = torch.linalg.eigh(M.double(), UPLO="U")
+    vec = O.canonical_signs(vec)
+    truth = (vec * lam.clamp(min=1e-8).sqrt())[:, -8:].numpy()
+    assert np.abs(got - truth).max() <= 2e-5 * max(1.0, np.abs(truth).max())
+    assert np.abs(got - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_eigh_top8_structured(st):
+    """A genuine 3-D distance geometry Gram matrix: 3 large eigenvalues, the rest ~0 / negative."""
+    rng = np.random.default_rng(11)
+    for L in (8, 31, 96):
+        P = rng.standard_normal((L, 3)) * 10
+        D = np.linalg.norm(P[:, None] - P[None], axis=2)
+        M = (0.5 * (D[0:1, :] ** 2 + D[:, 0:1] ** 2 - D ** 2)).astype(np.float32)
+        got = st.eigh_top8(st.to(M)).cpu().numpy().astype(np.float64)
+        lam, vec = np.linalg.eigh(M.astype(np.float64))
+        lam8 = np.maximum(lam[-8:], 1e-8)
+        # the three big columns reproduce the Gram matrix; every column has the right norm
+        assert np.abs(np.linalg.norm(got, axis=0) - np.sqrt(lam8)).max() < 1e-3
+        G3 = got[:, -3:] @ got[:, -3:].T
+        assert np.abs(G3 - M).max() < 1e-2
+        assert (got[np.abs(got).argmax(axis=0), np.arange(8)] > 0).all()      # sign rule
+
+
+def test_coords_from_mds(st, ocap, oracle_weights):
+    ref = O.coords_from_mds(oracle_weights, ocap["mat1d"], ocap["p0.mds"].unsqueeze(0))[0].numpy()
+    got = st.coords_from_mds(st.to(ocap["mat1d"].numpy()), st.to(ocap["p0.mds"].numpy())).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-4
+
+
+def test_pair_distances(st):
+    ca = torch.from_numpy(np.random.default_rng(2).standard_normal((50, 3)).astype(np.float32) * 7)
+    ref = O.pair_distances(ca).numpy()
+    got = st.pair_distances(st.to(ca.numpy()), 1).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-5
+    assert np.allclose(np.diag(got), 1e-4)
+    got0 = st.pair_distances(st.to(ca.numpy()), 0).cpu().numpy()
+    assert np.all(np.diag(got0) == 0.0)
+
+
+def test_refine_known_answer(st):
+    k = load_golden("kat_refine_backbone")
+    ca = st.to(k["ca_in"])
+    for steps, tol in ((1, 1e-5), (10, 1e-5), (100, 1e-4), (1000, 1e-3)):
+        got = st.refine(ca, steps).cpu().numpy()
+        assert np.abs(got - k[f"refined_{steps}"]).max() < tol, steps
+    got = st.refine(st.to(k["ca_noisy"]), 100).cpu().numpy()
+    assert np.abs(got - k["refined_noisy_100"]).max() < 1e-3
+
+
+def test_backbone_known_answer(st):
+    k = load_golden("kat_refine_backbone")
+    L = k["ca_in"].shape[0]
+    logit = np.linspace(-3, 3, L).astype(np.float32)
+    coords, conf = st.backbone(st.to(k["ca_in"]), st.to(logit))
+    assert np.abs(coords.cpu().numpy().reshape(-1, 3) - k["backbone"]).max() < 1e-4
+    assert np.abs(conf.cpu().numpy() - 1 / (1 + np.exp(-logit))).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------- end to end
+E2E = ["pf10963_n0_m0", "pf10963_n3_m0", "synth_L40_N64_n2_m0", "synth_L24_N3050_n1_m0",
+       "alphabet_L16_N12_n0_m0", "template_L96_N50_n1_m0"]
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_end_to_end_m0(st, name, tmp_path, weights_file):
+    """Full dmp_predict vs the reference's captured outputs: CA-RMSD <= 1e-3 A, |dconf| < 1e-4."""
+    g = load_golden(name)
+    tpl = g["template_ca"] if "template_ca" in g else None
+    coords, confs = st.eng.predict(g["alnmat"], tpl, int(g["iterations"]), int(g["minsteps"]))
+    coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
+    P = int(g["iterations"]) + 1
+    means = st.eng.fetch("conf_means", P).cpu().numpy()
+    assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
+    assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= 1e-3
+    assert np.abs(confs - g["confs"]).max() < 1e-4
+    assert np.abs(coords - g["coords"]).max() < 2e-2
+
+
+def test_end_to_end_single_sequence_with_refinement(st):
+    g = load_golden("synth_L30_N1_n1_m3")
+    coords, confs = st.eng.predict(g["alnmat"], None, 1, 3)
+    tol = max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
+    assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= tol
+    assert np.abs(confs.cpu().numpy() - g["confs"]).max() < 1e-4
+
+
+def test_end_to_end_with_refinement_within_noise_floor(st):
+    """m > 0 on synthetic weights is chaotic in the reference itself (see tests/golden/REPORT.txt):
+    the bound is max(1e-3, 3 x the reference's own 8-vs-1-thread deviation)."""
+    g = load_golden("pf10963_n2_m5")
+    coords, confs = st.eng.predict(g["alnmat"], None, 2, 5)
+    tol = max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
+    assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= tol
+    assert np.abs(confs.cpu().numpy() - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
+
+
+def test_python_api_and_cli(weights_file, tmp_path):
+    from dmpfold2_amd import aln_to_coords, run_dmpfold
+    g = load_golden("pf10963_n0_m0")
+    aln = tmp_path / "pf.aln"
+    aln.write_text("\n".join(golden_rows(g)) + "\n")
+    coords, confs, alnmat = aln_to_coords(str(aln), device="cuda:0", iterations=0, minsteps=0,
+                                          weights_file=weights_file, return_alnmat=True)
+    assert coords.shape == (82, 5, 3) and confs.shape == (82,) and coords.is_cuda
+    assert alnmat.dtype == np.uint8 and np.array_equal(alnmat, g["alnmat"])
+    assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= 1e-3
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        run_dmpfold(["-i", str(aln), "-d", "cuda:0", "-n", "0", "-m", "0", "-w", weights_file])
+    lines = buf.getvalue().splitlines()
+    ref_text = O.pdb_text(torch.from_numpy(g["coords"]), torch.from_numpy(g["confs"]), g["alnmat"])
+    ref_lines = ref_text.splitlines()
+    assert len(lines) == len(ref_lines) and lines[-1] == "END" and lines[0].startswith("REMARK  CONF:  ")
+    # same records; coordinates agree to the printed 3 decimals up to the 1e-3 tolerance
+    for a, b in zip(lines[1:-1], ref_lines[1:-1]):
+        assert a[:30] == b[:30]
+        for lo in (30, 38, 46):
+            assert abs(float(a[lo:lo + 8]) - float(b[lo:lo + 8])) <= 0.011
+
+
+def test_errors(st, weights_file, tmp_path):
+    from dmpfold2_amd import aln_to_coords
+    ragged = tmp_path / "ragged.aln"
+    ragged.write_text("ACDEFGHIKL\nACDEFGHIK\n")
+    with pytest.raises(ValueError):
+        aln_to_coords(str(ragged), device="cuda:0", weights_file=weights_file)
+    short = tmp_path / "short.aln"
+    short.write_text("ACDEF\nACDEF\n")
+    with pytest.raises(RuntimeError):
+        aln_to_coords(str(short), device="cuda:0", weights_file=weights_file)
+    with pytest.raises(RuntimeError):
+        aln_to_coords(str(short), device="cpu", weights_file=weights_file)
+    with pytest.raises(FileNotFoundError):
+        aln_to_coords(str(tmp_path / "missing.aln"), device="cuda:0", weights_file=weights_file)
