@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Benchmark of the alignment -> structure hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+
+A "step" is one complete prediction (features, sequence trunk, 11 pair-trunk passes with
+recycling, MDS, coordinate GRU, 2 x 100 minimiser steps, backbone) of one synthetic target of
+the north-star configuration L=300, N_seq=2000, iterations=10, minsteps=100, with the residue
+codes already resident in HBM and the packed weights loaded (model construction / weight load is
+excluded).  For N > 1 the driver starts one process per GPU
+(torch.distributed.run); every rank predicts its own targets - independent alignments are the
+only parallel axis of this path, so there is no data-path collective, only the timing barrier.
+
+Rank 0 prints ONE JSON line: structures/s for the whole job, the roofline of the dominant kernel
+(conv5x5_maxout, f32 MFMA bound) measured with HIP events around every launch inside the timed
+region, and (N = 1 only) the CPU oracle timed on this host on a bounded sample of the workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+L_NS, N_NS, ITERS, MINSTEPS = 300, 2000, 10, 100
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+CONV_FLOP_PER_LAUNCH = 2.0 * 128 * 512 * 25 * L_NS * L_NS     # one block's 5x5 conv
+
+
+def cpu_baseline():
+    """Time the CPU oracle (a port of the reference's operator sequence, validated against the
+    reference in tests/) on a bounded sample of the NS workload and extrapolate linearly:
+      vgru     first 250 of the 2000 alignment rows (x8; cost is linear in rows)
+      features reweight + fast_dca on 500 of the 2000 rows for the covariance (x4 on that part)
+               and the full 6300 x 6300 inverse
+      trunk    1 of the 11 pair-trunk passes incl. MDS and coordinate GRU (x11)
+    """
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dmpfold_oracle as O
+    from dmpfold2_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.synth_weights(0, coord_scale=5.0)
+    W = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    alnmat = O.encode_aln(synth.synth_msa(L_NS, N_NS, 0))
+    L = L_NS
+    with torch.no_grad():
+        t0 = time.time()
+        sub = alnmat[:250]
+        x = W["embed.weight"][torch.from_numpy(sub.astype(np.int64))]
+        v = O._gru(W, "vgru", x, 22, 512, 2, False, False)
+        t_vgru = (time.time() - t0) * (N_NS / 250.0)
+        t0 = time.time()
+        w500 = O.reweight(alnmat[:500])
+        t_rw = (time.time() - t0) * (N_NS / 500.0) ** 2
+        t0 = time.time()
+        O.fast_dca(alnmat[:500], w500)
+        t_dca500 = time.time() - t0
+        t0 = time.time()
+        torch.inverse(torch.eye(21 * L) + 0.01 * torch.rand(21 * L, 21 * L))
+        t_inv = time.time() - t0
+        # covariance GEMM scales with rows; the inverse and the relayouts do not
+        t_dca = t_inv + (t_dca500 - t_inv) * 4.0 if t_dca500 > t_inv else t_dca500 * 4.0
+        mat1d = O._gru(W, "hgru", v[-1].unsqueeze(1), 512, 256, 2, True, False)[:, 0].t().contiguous()
+        f2d = torch.randn(L, L, 442) * 0.05
+        pair = (mat1d.unsqueeze(1) * mat1d.unsqueeze(2)).unsqueeze(0)
+        static = torch.cat((pair, f2d.permute(2, 0, 1).unsqueeze(0)), dim=1)
+        dmap = torch.zeros(1, 1, L, L) - 1
+        t0 = time.time()
+        y = O.pair_trunk(W, torch.cat((static, dmap), dim=1))
+        dm, conf, M = O.head_to_gram(y)
+        mds = O.mds_top8(M, "canonical")
+        ca = O.coords_from_mds(W, mat1d, mds)
+        t_pass = time.time() - t0
+        t0 = time.time()
+        O.refine_coords(ca[0], 20)
+        t_ref = (time.time() - t0) * (2 * MINSTEPS / 20.0)
+    total = t_vgru + t_rw + t_dca + (ITERS + 1) * t_pass + t_ref
+    return {"value": 1.0 / total, "unit": "structures/s", "cores": cores, "kind": "port",
+            "sample": ("oracle (PyTorch-CPU port) on this host: vgru on 250/2000 rows x8, reweight+"
+                       "fast_dca on 500/2000 rows (GEMM part x4) + full 6300^2 inverse, 1/11 trunk "
+                       "passes x11, 20/200 minimiser steps x10; est. %.1f s per structure "
+                       "(vgru %.1f, features %.1f, trunk passes %.1f)"
+                       % (total, t_vgru, t_rw + t_dca, (ITERS + 1) * t_pass))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    from dmpfold2_amd import synth, _lib
+    from dmpfold2_amd.predict import Engine, encode_aln
+    lib = _lib.load()
+    eng = Engine(device, L_NS, N_NS)
+    sd = synth.synth_weights(0, coord_scale=5.0)
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+
+    # one synthetic target per step and rank, resident in HBM before the clock starts
+    total_steps = args.warmup + args.steps
+    targets = []
+    for s in range(total_steps):
+        rows = synth.synth_msa(L_NS, N_NS, seed=1000 * rank + s)
+        targets.append(torch.from_numpy(encode_aln(rows)).to(device))
+    outs = []
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for s in range(args.warmup):
+        outs.append(eng.predict_device(targets[s], None, ITERS, MINSTEPS))
+    sync_all()
+    _lib.check(lib.dmp_profile_enable(eng.ctx, 1, 16 * (ITERS + 1) * max(args.steps, 1)))
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        outs.append(eng.predict_device(targets[s], None, ITERS, MINSTEPS))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    conv_ms, conv_n = C.c_float(), C.c_int()
+    _lib.check(lib.dmp_profile_conv_ms(eng.ctx, C.byref(conv_ms), C.byref(conv_n)))
+    _lib.check(lib.dmp_profile_enable(eng.ctx, 0, 0))
+    ok = all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in outs)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item() > 0.5)
+
+    if rank == 0:
+        achieved = CONV_FLOP_PER_LAUNCH / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "conv5x5_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "structures/s at L=300, N_seq=2000, 10 iters+100 min",
+            "value": world * args.steps / elapsed,
+            "unit": "structures/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "finite_outputs": ok,
+            "config": {"workload": "single synthetic target L=300 N_seq=2000, iterations=10, "
+                                   "minsteps=100 per step and GPU (BASELINE.json metric config)",
+                       "L": L_NS, "n_seq": N_NS, "iterations": ITERS, "minsteps": MINSTEPS,
+                       "weights": "synthetic seed 0 (reference state_dict shapes)",
+                       "parallelism": f"replicas x{world}, no collective on the data path"},
+            "roofline": {"kernel": "conv5x5_maxout_kernel (5x5 conv 128->512 + bias + 4-way maxout)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": traffic, "launches_timed": conv_n.value,
+                         "avg_launch_ms": conv_ms.value,
+                         "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,12 +164,19 @@ class Engine:
                 minsteps=default_minsteps):
         """codes (N, L) uint8 -> (coords (L,5,3), confs (L,)) float32 tensors on the GPU."""
         alnmat = np.ascontiguousarray(alnmat, dtype=np.uint8)
-        n, L = alnmat.shape
+        with torch.cuda.device(self.device):
+            d_msa = torch.from_numpy(alnmat).to(self.device)
+        return self.predict_device(d_msa, template_ca, iterations, minsteps)
+
+    def predict_device(self, d_msa, template_ca=None, iterations=default_iterations,
+                       minsteps=default_minsteps):
+        """Same as `predict` for residue codes already resident on the GPU (uint8 (N, L))."""
+        assert d_msa.dtype == torch.uint8 and d_msa.is_contiguous() and d_msa.device == self.device
+        n, L = d_msa.shape
         if L < 8:
             raise RuntimeError(f"alignment has {L} columns; the network needs at least 8 "
                                "(MDS embedding width, reference network.py:250-253)")
         with torch.cuda.device(self.device):
-            d_msa = torch.from_numpy(alnmat).to(self.device)
             coords = torch.empty((L, 5, 3), dtype=torch.float32, device=self.device)
             confs = torch.empty((L,), dtype=torch.float32, device=self.device)
             d_tpl, lt = None, 0
