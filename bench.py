@@ -44,7 +44,11 @@ def cpu_baseline():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dmpfold_oracle as O
     from dmpfold2_amd import synth
-    cores = os.cpu_count() or 1
+    # PyTorch-CPU collapses when given every hardware thread of the 256-thread GPU host (37x
+    # slower than 8 threads); a sweep there (tools/gpu_diag.py --cpu-sweep: 8/16/32/64/128)
+    # put the optimum at 16 threads for the GRU and 16-32 for the convolutions.
+    # DMP_CPU_THREADS overrides.
+    cores = int(os.environ.get("DMP_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
     sd = synth.synth_weights(0, coord_scale=5.0)
     W = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
@@ -144,6 +148,7 @@ def main():
     conv_ms, conv_n = C.c_float(), C.c_int()
     _lib.check(lib.dmp_profile_conv_ms(eng.ctx, C.byref(conv_ms), C.byref(conv_n)))
     _lib.check(lib.dmp_profile_enable(eng.ctx, 0, 0))
+    eng.sync_check()
     ok = all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in outs)
 
     if distributed:

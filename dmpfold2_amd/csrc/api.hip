@@ -97,10 +97,18 @@ static int pack_weights(dmp_ctx* c) {
   auto& pool = W.allocs;
   int rc;
   // vertical GRU
-  if ((rc = upload(pool, bytes, &W.v_wih0T, transposed(H["vgru.weight_ih_l0"], 1536, 22, 2)))) return rc;
-  if ((rc = upload(pool, bytes, &W.v_whh0T, transposed(H["vgru.weight_hh_l0"], 1536, 512)))) return rc;
-  if ((rc = upload(pool, bytes, &W.v_wih1T, transposed(H["vgru.weight_ih_l1"], 1536, 512)))) return rc;
-  if ((rc = upload(pool, bytes, &W.v_whh1T, transposed(H["vgru.weight_hh_l1"], 1536, 512)))) return rc;
+  auto gate4 = [](const std::vector<float>& w, int K, int Kpad) {
+    // w is [3*512][K] (rows r | z | n); returns [Kpad][512][4] = {r, z, n, 0}
+    std::vector<float> p((size_t)Kpad * 512 * 4, 0.f);
+    for (int k = 0; k < K; ++k)
+      for (int j = 0; j < 512; ++j)
+        for (int g = 0; g < 3; ++g) p[((size_t)k * 512 + j) * 4 + g] = w[((size_t)g * 512 + j) * K + k];
+    return p;
+  };
+  if ((rc = upload(pool, bytes, &W.v_wx[0], gate4(H["vgru.weight_ih_l0"], 22, 24)))) return rc;
+  if ((rc = upload(pool, bytes, &W.v_wh[0], gate4(H["vgru.weight_hh_l0"], 512, 512)))) return rc;
+  if ((rc = upload(pool, bytes, &W.v_wx[1], gate4(H["vgru.weight_ih_l1"], 512, 512)))) return rc;
+  if ((rc = upload(pool, bytes, &W.v_wh[1], gate4(H["vgru.weight_hh_l1"], 512, 512)))) return rc;
   for (int l = 0; l < 2; ++l) {
     const auto& bi = H["vgru.bias_ih_l" + std::to_string(l)];
     const auto& bh = H["vgru.bias_hh_l" + std::to_string(l)];
@@ -275,6 +283,8 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(seq_b, L * WIDTH);
   A_(emb, L * (WIDTH + 8));
   A_(mat1d, L * WIDTH);
+  A_(seq_hx, 2 * 2 * HID2);
+  A_(seq_abort, 1);
   A_(z0, (int64_t)STEM_OUT * LL);
   A_(dmap, LL);
   A_(u, (int64_t)CW * LL);
@@ -299,7 +309,20 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(ca_pass, (int64_t)c->max_passes * L * 3);
 #undef A_
   if (rc) { dmp_ctx_destroy(c); return rc; }
+  if (hipMemset(c->seq_abort, 0, sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
   *out = c;
+  return DMP_OK;
+}
+
+int dmp_sync_check(dmp_ctx* ctx, void* stream) {
+  DMP_ARG(ctx != nullptr, "null context");
+  DMP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int flag = 0;
+  DMP_HIP(hipMemcpy(&flag, ctx->seq_abort, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) {
+    set_error("sequence-GRU workgroup hand-off timed out (results invalid)");
+    return DMP_ERR_HIP;
+  }
   return DMP_OK;
 }
 
@@ -484,7 +507,7 @@ int dmp_pair_distances(dmp_ctx* ctx, const float* d_ca, int L, int clamp, float*
 }
 
 int dmp_refine_coords(dmp_ctx* ctx, float* d_ca, int L, int steps, void* stream) {
-  DMP_ARG(ctx && d_ca && L >= 2 && L <= 2048 && steps >= 0, "bad argument");
+  DMP_ARG(ctx && d_ca && L >= 2 && L <= 1280 && steps >= 0, "bad argument");
   return refine_coords(d_ca, L, steps, STREAM);
 }
 

@@ -69,8 +69,9 @@ struct Weights {
   bool ready = false;
   std::map<std::string, std::vector<float>> host;          // raw tensors by key
   std::map<std::string, std::vector<int64_t>> shapes;
-  // vertical GRU (transposed: [k][3*512])
-  float *v_wih0T = nullptr, *v_whh0T = nullptr, *v_wih1T = nullptr, *v_whh1T = nullptr;
+  // vertical GRU, gate-interleaved [k][512][4] = {W_r[j,k], W_z[j,k], W_n[j,k], 0}
+  float* v_wx[2] = {nullptr, nullptr};   // input weights (layer 0: K = 22 padded to 24)
+  float* v_wh[2] = {nullptr, nullptr};   // hidden weights
   float *v_b0 = nullptr, *v_b1 = nullptr;  // [4][512]: r(bi+bh), z(bi+bh), in(bi), hn(bh)
   GruDirW hgru[2][2];                      // [layer][dir]
   GruDirW cgru[3][2];
@@ -115,6 +116,8 @@ struct dmp_ctx {
   float* seq_b = nullptr;   // [L][512]
   float* emb = nullptr;     // [L][520]
   float* mat1d = nullptr;   // [512][L]
+  unsigned long long* seq_hx = nullptr;  // [2][2][256] hand-off granules of the sequence GRU
+  int* seq_abort = nullptr;              // [1] set if a hand-off timed out
   // pair trunk
   float* z0 = nullptr;      // [384][L][L]
   float* dmap = nullptr;    // [L][L]

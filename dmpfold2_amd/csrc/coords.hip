@@ -136,17 +136,24 @@ int select_best(dmp_ctx* c, const float* d_conf, const float* d_ca, int L, int p
 // ---------------------------------------------------------------------------------------
 // refine_coords: all steps in one launch, coordinates double-buffered in LDS
 // ---------------------------------------------------------------------------------------
+// T threads share a residue j, each summing the steric term over a contiguous slice of the
+// partners i; the slices are then added in order, followed by the two bond terms.
 __global__ __launch_bounds__(1024) void refine_kernel(float* __restrict__ ca, int L, int steps) {
-  extern __shared__ float sm[];          // 2 x 3L
+  extern __shared__ float sm[];          // 2 x 3L coordinates + T x 3L partial sums
   float* cur = sm;
   float* nxt = sm + 3 * L;
+  float* part = sm + 6 * L;
+  const int T = L >= 1024 ? 1 : (1024 / L > 8 ? 8 : 1024 / L);
+  const int chunk = (L + T - 1) / T;
   for (int i = threadIdx.x; i < 3 * L; i += 1024) cur[i] = ca[i];
   __syncthreads();
   for (int step = 0; step < steps; ++step) {
-    for (int j = threadIdx.x; j < L; j += 1024) {
+    for (int idx = threadIdx.x; idx < T * L; idx += 1024) {
+      const int j = idx % L, sub = idx / L;
+      const int i0 = sub * chunk, i1 = (i0 + chunk < L) ? i0 + chunk : L;
       const float xj = cur[3 * j], yj = cur[3 * j + 1], zj = cur[3 * j + 2];
       float ax = 0.f, ay = 0.f, az = 0.f;
-      for (int i = 0; i < L; ++i) {
+      for (int i = i0; i < i1; ++i) {
         const float dx = xj - cur[3 * i], dy = yj - cur[3 * i + 1], dz = zj - cur[3 * i + 2];
         float d = sqrtf((dx * dx + dy * dy) + dz * dz);
         d = fminf(fmaxf(d, 0.01f), 10.0f);
@@ -155,6 +162,19 @@ __global__ __launch_bounds__(1024) void refine_kernel(float* __restrict__ ca, in
         ax += f * (dx / d);
         ay += f * (dy / d);
         az += f * (dz / d);
+      }
+      part[(sub * L + j) * 3] = ax;
+      part[(sub * L + j) * 3 + 1] = ay;
+      part[(sub * L + j) * 3 + 2] = az;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < L; j += 1024) {
+      const float xj = cur[3 * j], yj = cur[3 * j + 1], zj = cur[3 * j + 2];
+      float ax = part[3 * j], ay = part[3 * j + 1], az = part[3 * j + 2];
+      for (int sub = 1; sub < T; ++sub) {
+        ax += part[(sub * L + j) * 3];
+        ay += part[(sub * L + j) * 3 + 1];
+        az += part[(sub * L + j) * 3 + 2];
       }
       if (j < L - 1) {   // bond to j+1: accels[:-1] += accels_cov
         const float dx = cur[3 * j + 3] - xj, dy = cur[3 * j + 4] - yj, dz = cur[3 * j + 5] - zj;
@@ -184,7 +204,9 @@ __global__ __launch_bounds__(1024) void refine_kernel(float* __restrict__ ca, in
 
 int refine_coords(float* d_ca, int L, int steps, hipStream_t s) {
   if (steps <= 0) return DMP_OK;
-  hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(1024), sizeof(float) * 6 * L, s, d_ca, L, steps);
+  const int T = L >= 1024 ? 1 : (1024 / L > 8 ? 8 : 1024 / L);
+  hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(1024), sizeof(float) * (6 + 3 * T) * L, s, d_ca, L,
+                     steps);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

@@ -115,31 +115,47 @@ int cov_build(dmp_ctx* c, const uint8_t* d_msa, const float* d_w, int N, int L, 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gj_diag_kernel(const float* __restrict__ A, int D, int k0,
                                                       int bs, float* __restrict__ P) {
-  __shared__ float S[GJ_NB * GJ_NB];
+  // Symmetric sweep operator (Goodnight): sweeping every pivot of an SPD block in place gives
+  // -inverse and keeps the matrix symmetric, so a step only needs the pivot ROW broadcast.
+  // Thread (j, ih) keeps rows ih*64 .. ih*64+63 of column j in 64 registers (static indexing:
+  // the pivot loop is unrolled over the row-in-half index); the pivot row goes through LDS.
+  __shared__ float rowk[2][GJ_NB];
   const int tid = threadIdx.x;
   const int j = tid & 127, ih = tid >> 7;
-  for (int e = tid; e < GJ_NB * GJ_NB; e += 256) {
-    const int r = e >> 7, cc = e & 127;
-    S[e] = (r < bs && cc < bs) ? A[(int64_t)(k0 + r) * D + k0 + cc] : (r == cc ? 1.f : 0.f);
-  }
-  __syncthreads();
-  float f[64];
-  for (int k = 0; k < bs; ++k) {
-    const float p = 1.0f / S[k * GJ_NB + k];
-    const float rk = (j == k) ? p : S[k * GJ_NB + j] * p;
+  float sreg[64];
 #pragma unroll
-    for (int r = 0; r < 64; ++r) f[r] = S[(ih * 64 + r) * GJ_NB + k];
-    __syncthreads();
+  for (int r = 0; r < 64; ++r) {
+    const int i = ih * 64 + r;
+    sreg[r] = (i < bs && j < bs) ? A[(int64_t)(k0 + i) * D + k0 + j] : (i == j ? 1.f : 0.f);
+  }
+#pragma unroll 1
+  for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
     for (int r = 0; r < 64; ++r) {
-      const int i = ih * 64 + r;
-      float* e = &S[i * GJ_NB + j];
-      if (i == k) *e = rk;
-      else *e = (j == k) ? -f[r] * p : *e - f[r] * rk;
+      const int k = kh * 64 + r;
+      if (k < bs) {                                   // uniform
+        float* rk = rowk[k & 1];
+        if (ih == kh) rk[j] = sreg[r];                // publish row k (column j's element)
+        __syncthreads();
+        const float invd = 1.0f / rk[k];
+        const bool jk = (j == k);
+        const float bj = rk[j] * invd;                // new a_kj
+        const float mul = jk ? -invd : bj;            // column k: a_ik/d ; elsewhere a_ij - a_ik*b_j
+#pragma unroll
+        for (int rr = 0; rr < 64; ++rr) {
+          const float aik = rk[ih * 64 + rr];         // a_ik = a_ki by symmetry
+          sreg[rr] = fmaf(-aik, mul, jk ? 0.f : sreg[rr]);
+        }
+        if (ih == kh) sreg[r] = jk ? -invd : bj;      // the pivot row itself
+      }
     }
-    __syncthreads();
   }
-  for (int e = tid; e < GJ_NB * GJ_NB; e += 256) P[e] = S[e];
+  // P = inverse = -swept matrix; padding rows/columns of a partial block become identity again
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int i = ih * 64 + r;
+    P[i * GJ_NB + j] = (i < bs && j < bs) ? -sreg[r] : (i == j ? 1.f : 0.f);
+  }
 }
 
 // C[i][kk] = A[i][k0+kk] (zero for rows inside the block); also zero R's block columns

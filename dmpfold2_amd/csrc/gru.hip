@@ -1,221 +1,136 @@
-// GRU kernels.
-//  * gru_vertical: the 2-layer GRU that runs DOWN the alignment (reference network.py:189,
-//    223-224: time axis = N sequences, batch = L columns).  One launch per time step computes
-//    layer 0 at step t and layer 1 at step t-1 (both read the same h0 state), as f32-MFMA
-//    GEMMs  gates^T[j, b] = sum_k W^T[k, j] * X^T[k, b]  with the hidden index on the MFMA M
-//    axis and the batch (alignment column) on the N axis, so weights, state reads and state
-//    writes are all 128-byte coalesced.  The one-hot layer-0 input is generated in registers.
-//  * gru_bidir: bidirectional multi-layer GRU along the sequence with batch 1 (hgru,
-//    network.py:190/225; coord_gru, network.py:211/253).
+// gru_bidir: bidirectional multi-layer GRU along the sequence with batch 1 (hgru, reference
+// network.py:190/225; coord_gru, network.py:211/253).  The vertical GRU is in vgru.hip.
 // Gate maths follow ATen's gru_cell: r,z = sigmoid(gi+gh), n = tanh(gi_n + r*gh_n),
 // h' = (h - n)*z + n.
 #include "common.h"
 
 namespace dmp {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-struct VStepArgs {
-  const uint8_t* codes;     // row t of the alignment (L bytes) or nullptr
-  const float* wxT[2];      // [layer]: x-part weights, [Kx][1536]
-  const float* whT[2];      // [layer]: h-part weights, [512][1536]
-  const float* bias[2];     // [layer]: [4][512]
-  const float* h0_prev;     // [512][Lb]
-  float* h0_next;
-  const float* h1_prev;
-  float* h1_next;
-  int L, Lb;
-  int do_l0, do_l1;
-};
+// Weight-stationary cluster: each direction is run by SEQ_G workgroups; workgroup g keeps the
+// 96 rows of W_hh that produce hidden units [32g, 32g+32) in registers (96 floats per lane)
+// for the whole sequence.  Per time step a workgroup computes its 32 new state values,
+// publishes them as 8-byte {epoch, value} granules (one agent-scope store each, the data is
+// the flag) and gathers the other 224 by sweeping the granule array until every tag equals
+// the step's epoch.  The protocol does not depend on where the workgroups run; putting the
+// 8 workgroups of a direction on one XCD (block id % 8) only shortens the hand-off.
+constexpr int SEQ_G = 8;
+typedef unsigned long long u64;
 
-// grid: (Lb/32, 16, 2)   block: 256 (4 waves split K)
-__global__ __launch_bounds__(256) void vgru_step_kernel(VStepArgs a) {
-  __shared__ float red[4][4][16][64];
-  const int layer = blockIdx.z;
-  if (layer == 0 && !a.do_l0) return;
-  if (layer == 1 && !a.do_l1) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kk = lane >> 5, li = lane & 31;
-  const int b0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-  const int Lb = a.Lb;
-
-  f32x16 acc_r, acc_z, acc_in, acc_hn;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_in[r] = 0.f; acc_hn[r] = 0.f; }
-
-  const float* wx = a.wxT[layer] + j0 + li;
-  const float* wh = a.whT[layer] + j0 + li;
-  const float* hprev = (layer == 0) ? a.h0_prev : a.h1_prev;
-
-  // ---- input part
-  if (layer == 0) {
-    const int b = b0 + li;
-    const int code = (b < a.L) ? (int)a.codes[b] : 0;
-    // K = 24 (22 real + 2 zero rows): 12 k-pairs, 3 per wave
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const int k = 2 * (wave + 4 * p) + kk;
-      const float x = (code == k) ? 1.0f : 0.0f;
-      const float* wk = wx + (int64_t)k * 1536;
-      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[0], x, acc_r, 0, 0, 0);
-      acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[512], x, acc_z, 0, 0, 0);
-      acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[1024], x, acc_in, 0, 0, 0);
-    }
-  } else {
-    const float* xin = a.h0_prev + b0 + li;
-#pragma unroll 8
-    for (int p = 0; p < 64; ++p) {
-      const int k = 2 * (wave + 4 * p) + kk;
-      const float x = xin[(int64_t)k * Lb];
-      const float* wk = wx + (int64_t)k * 1536;
-      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[0], x, acc_r, 0, 0, 0);
-      acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[512], x, acc_z, 0, 0, 0);
-      acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[1024], x, acc_in, 0, 0, 0);
-    }
-  }
-  // ---- recurrent part
-  {
-    const float* hin = hprev + b0 + li;
-#pragma unroll 8
-    for (int p = 0; p < 64; ++p) {
-      const int k = 2 * (wave + 4 * p) + kk;
-      const float x = hin[(int64_t)k * Lb];
-      const float* wk = wh + (int64_t)k * 1536;
-      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[0], x, acc_r, 0, 0, 0);
-      acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[512], x, acc_z, 0, 0, 0);
-      acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[1024], x, acc_hn, 0, 0, 0);
-    }
-  }
-  // ---- reduce the 4 K-slices through LDS, then gate maths on a quarter of the tile per wave
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    red[wave][0][r][lane] = acc_r[r];
-    red[wave][1][r][lane] = acc_z[r];
-    red[wave][2][r][lane] = acc_in[r];
-    red[wave][3][r][lane] = acc_hn[r];
-  }
-  __syncthreads();
-  const float* bias = a.bias[layer];
-  float* hnext = (layer == 0) ? a.h0_next : a.h1_next;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = wave * 4 + q;
-    float s[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      s[g] = (red[0][g][r][lane] + red[1][g][r][lane]) + (red[2][g][r][lane] + red[3][g][r][lane]);
-    const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-    const int b = b0 + li;
-    const float rg = sigmoidf_(s[0] + bias[j]);
-    const float zg = sigmoidf_(s[1] + bias[512 + j]);
-    const float ng = tanhf((s[2] + bias[1024 + j]) + rg * (s[3] + bias[1536 + j]));
-    const float hp = hprev[(int64_t)j * Lb + b];
-    hnext[(int64_t)j * Lb + b] = (hp - ng) * zg + ng;
-  }
-}
-
-// out[l][j] = hT[j][l]
-__global__ __launch_bounds__(256) void vgru_out_kernel(const float* __restrict__ hT, int L, int Lb,
-                                                       float* __restrict__ out) {
-  __shared__ float tile[32][33];
-  const int l0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) tile[r][tx] = hT[(int64_t)(j0 + r) * Lb + l0 + tx];
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8)
-    if (l0 + r < L) out[(int64_t)(l0 + r) * WIDTH + j0 + tx] = tile[tx][r];
-}
-
-int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s) {
-  const int Lb = round_up(L, 32);
-  const size_t hbytes = sizeof(float) * WIDTH * Lb;
-  DMP_HIP(hipMemsetAsync(c->hT[0][0], 0, hbytes, s));
-  DMP_HIP(hipMemsetAsync(c->hT[1][0], 0, hbytes, s));
-  const Weights& W = c->W;
-  VStepArgs a{};
-  a.wxT[0] = W.v_wih0T; a.whT[0] = W.v_whh0T; a.bias[0] = W.v_b0;
-  a.wxT[1] = W.v_wih1T; a.whT[1] = W.v_whh1T; a.bias[1] = W.v_b1;
-  a.L = L; a.Lb = Lb;
-  dim3 grid(Lb / 32, WIDTH / 32, 2);
-  for (int t = 0; t <= N; ++t) {
-    a.codes = (t < N) ? d_msa + (int64_t)t * L : nullptr;
-    a.do_l0 = (t < N);
-    a.do_l1 = (t >= 1);
-    a.h0_prev = c->hT[0][t & 1];
-    a.h0_next = c->hT[0][(t + 1) & 1];
-    a.h1_prev = c->hT[1][(t + 1) & 1];   // layer 1 runs step t-1: parity (t-1)&1
-    a.h1_next = c->hT[1][t & 1];
-    hipLaunchKernelGGL(vgru_step_kernel, grid, dim3(256), 0, s, a);
-  }
-  DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vgru_out_kernel, dim3(Lb / 32, WIDTH / 32), dim3(256), 0, s,
-                     c->hT[1][N & 1], L, Lb, d_out);
-  DMP_LAUNCH_CHECK();
-  return DMP_OK;
-}
-
-// ---------------------------------------------------------------------------------------
-// bidirectional sequence GRU, batch 1
-// ---------------------------------------------------------------------------------------
 struct SeqArgs {
   const float* G;        // [T][1536] input projections incl. b_ih (fwd | rev)
   const float* whh[2];   // [768][256]
   const float* bhh[2];   // [768]
   float* out;            // [T][512]
+  u64* hx;               // [2 dir][2 parity][256] granules, zeroed before every launch
+  int* abort_flag;       // set if a hand-off ever times out
   int T;
 };
 
-// grid: 2 (direction)   block: 1024
-__global__ __launch_bounds__(1024) void seq_gru_kernel(SeqArgs a) {
+// grid: 8 * SEQ_G blocks (only ids with id % 8 < 2 work: direction = id % 8)   block: 256
+__global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
   __shared__ __attribute__((aligned(16))) float h[HID2];
-  __shared__ float gh[3 * HID2];
-  const int dir = blockIdx.x;
+  __shared__ int sh_abort;
+  const int dir = blockIdx.x & 7, g = blockIdx.x >> 3;
+  if (dir >= 2) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rs = lane >> 4, kc = lane & 15;
+  const int rgp = lane >> 4, kg = lane & 15;
+  const int u0 = 32 * g + 8 * wave + 2 * rgp;            // this lane group's two hidden units
   const float* whh = a.whh[dir];
-  const float* bhh = a.bhh[dir];
-  if (tid < HID2) h[tid] = 0.f;
-  __syncthreads();
-  for (int step = 0; step < a.T; ++step) {
-    const int t = dir ? (a.T - 1 - step) : step;
-    float hv[16];
+  float wreg[3][2][16];
+  float bh[3][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(&h[kc * 16 + q * 4]);
-      hv[q * 4 + 0] = v.x; hv[q * 4 + 1] = v.y; hv[q * 4 + 2] = v.z; hv[q * 4 + 3] = v.w;
-    }
-#pragma unroll 4
-    for (int it = 0; it < 12; ++it) {
-      const int row = wave * 48 + it * 4 + rs;
-      const float4* wr = reinterpret_cast<const float4*>(whh + (int64_t)row * HID2 + kc * 16);
-      float sacc = 0.f;
+  for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const int row = gate * HID2 + u0 + uu;
+      const float4* wr = reinterpret_cast<const float4*>(whh + (int64_t)row * HID2 + kg * 16);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 w4 = wr[q];
-        sacc = fmaf(w4.x, hv[q * 4 + 0], sacc);
-        sacc = fmaf(w4.y, hv[q * 4 + 1], sacc);
-        sacc = fmaf(w4.z, hv[q * 4 + 2], sacc);
-        sacc = fmaf(w4.w, hv[q * 4 + 3], sacc);
+        wreg[gate][uu][q * 4 + 0] = w4.x; wreg[gate][uu][q * 4 + 1] = w4.y;
+        wreg[gate][uu][q * 4 + 2] = w4.z; wreg[gate][uu][q * 4 + 3] = w4.w;
       }
-      sacc += __shfl_xor(sacc, 8, 16);
-      sacc += __shfl_xor(sacc, 4, 16);
-      sacc += __shfl_xor(sacc, 2, 16);
-      sacc += __shfl_xor(sacc, 1, 16);
-      if (kc == 0) gh[row] = sacc + bhh[row];
+      bh[gate][uu] = a.bhh[dir][row];
     }
-    __syncthreads();
-    if (tid < HID2) {
-      const float* g = a.G + (int64_t)t * 1536 + dir * 768;
-      const float rg = sigmoidf_(g[tid] + gh[tid]);
-      const float zg = sigmoidf_(g[HID2 + tid] + gh[HID2 + tid]);
-      const float ng = tanhf(g[2 * HID2 + tid] + rg * gh[2 * HID2 + tid]);
-      const float hn = (h[tid] - ng) * zg + ng;
-      h[tid] = hn;
-      a.out[(int64_t)t * 512 + dir * HID2 + tid] = hn;
+  if (tid < HID2) h[tid] = 0.f;
+  if (tid == 0) sh_abort = 0;
+  __syncthreads();
+  u64* hx_dir = a.hx + (int64_t)dir * 2 * HID2;
+  for (int step = 0; step < a.T; ++step) {
+    const int t = dir ? (a.T - 1 - step) : step;
+    const unsigned epoch = (unsigned)step + 1u;
+    u64* hx = hx_dir + (step & 1) * HID2;
+    // input projections of this step for the two units (needed by lanes kg == 0 only)
+    float gi[3][2];
+    if (kg == 0) {
+      const float* gp = a.G + (int64_t)t * 1536 + dir * 768 + u0;
+#pragma unroll
+      for (int gate = 0; gate < 3; ++gate) { gi[gate][0] = gp[gate * HID2]; gi[gate][1] = gp[gate * HID2 + 1]; }
     }
-    __syncthreads();
+    float hv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(&h[kg * 16 + q * 4]);
+      hv[q * 4 + 0] = v.x; hv[q * 4 + 1] = v.y; hv[q * 4 + 2] = v.z; hv[q * 4 + 3] = v.w;
+    }
+    const float hp0 = h[u0], hp1 = h[u0 + 1];
+    float acc[3][2];
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc = fmaf(wreg[gate][uu][q], hv[q], sacc);
+        acc[gate][uu] = sacc;
+      }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+      for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) acc[gate][uu] += __shfl_xor(acc[gate][uu], off, 16);
+    if (kg == 0) {
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const float rg = sigmoidf_(gi[0][uu] + (acc[0][uu] + bh[0][uu]));
+        const float zg = sigmoidf_(gi[1][uu] + (acc[1][uu] + bh[1][uu]));
+        const float ng = tanhf(gi[2][uu] + rg * (acc[2][uu] + bh[2][uu]));
+        const float hp = uu ? hp1 : hp0;
+        const float hn = (hp - ng) * zg + ng;
+        a.out[(int64_t)t * 512 + dir * HID2 + u0 + uu] = hn;
+        __hip_atomic_store(&hx[u0 + uu], ((u64)epoch << 32) | (u64)__float_as_uint(hn),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();                 // every wave has read h for this step
+    if (wave == 0) {
+      // sweep the 256 granules of this step (4 per lane) until all carry this epoch
+      unsigned vals[4];
+      bool dead = false;
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u64 x = __hip_atomic_load(&hx[lane + 64 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          vals[q] = (unsigned)x;
+          ok = ok && ((unsigned)(x >> 32) == epoch);
+        }
+        if (__all(ok)) break;
+        if (spins > 2000000u) { dead = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (dead) {
+        if (lane == 0) { sh_abort = 1; atomicExch(a.abort_flag, 1); }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[lane + 64 * q] = __uint_as_float(vals[q]);
+      }
+    }
+    __syncthreads();                 // h holds the new state
+    if (sh_abort) break;
   }
 }
 
@@ -240,7 +155,10 @@ int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hip
     a.whh[0] = w[0].whh; a.whh[1] = w[1].whh;
     a.bhh[0] = w[0].bhh; a.bhh[1] = w[1].bhh;
     a.out = out; a.T = T;
-    hipLaunchKernelGGL(seq_gru_kernel, dim3(2), dim3(1024), 0, s, a);
+    a.hx = (u64*)c->seq_hx;
+    a.abort_flag = c->seq_abort;
+    DMP_HIP(hipMemsetAsync(c->seq_hx, 0, sizeof(u64) * 2 * 2 * HID2, s));
+    hipLaunchKernelGGL(seq_gru_kernel, dim3(8 * SEQ_G), dim3(256), 0, s, a);
     DMP_LAUNCH_CHECK();
     in = out;
   }

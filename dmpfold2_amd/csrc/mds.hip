@@ -35,6 +35,35 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red) {
   return t;
 }
 
+// column walks with 8 independent loads in flight per thread (the plain loops are latency bound)
+__device__ __forceinline__ double col_dot(const double* __restrict__ col, int n, const double* v,
+                                          int i0, int i1) {
+  double acc = 0.0;
+  int i = i0;
+  for (; i + 8 <= i1; i += 8) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = col[(int64_t)(i + u) * n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += a[u] * v[i + u];
+  }
+  for (; i < i1; ++i) acc += col[(int64_t)i * n] * v[i];
+  return acc;
+}
+
+__device__ __forceinline__ void col_rank2(double* __restrict__ col, int n, const double* v,
+                                          const double* w, double vj, double wj, int i0, int i1) {
+  int i = i0;
+  for (; i + 8 <= i1; i += 8) {
+    double a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = col[(int64_t)(i + u) * n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) col[(int64_t)(i + u) * n] = a[u] - (v[i + u] * wj + w[i + u] * vj);
+  }
+  for (; i < i1; ++i) col[(int64_t)i * n] -= v[i] * wj + w[i] * vj;
+}
+
 // A (n x n, full symmetric storage) -> d, e, tau and the reflectors V[k][0..n-k-2] (row-wise).
 // block: 1024 threads; dynamic LDS: v[n], p[n] doubles.
 __global__ __launch_bounds__(1024) void tridiag_kernel(double* __restrict__ A, int n,
@@ -43,8 +72,9 @@ __global__ __launch_bounds__(1024) void tridiag_kernel(double* __restrict__ A, i
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* v = sm;
   double* p = sm + n;
+  double* part = sm + 2 * n;           // 1024 doubles
   __shared__ double red[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   for (int k = 0; k < n - 1; ++k) {
     const int m = n - k - 1;                       // length of x = A[k+1:, k]
     double* A22 = A + (int64_t)(k + 1) * n + (k + 1);
@@ -81,13 +111,27 @@ __global__ __launch_bounds__(1024) void tridiag_kernel(double* __restrict__ A, i
     __syncthreads();
     for (int i = tid; i < m; i += 1024) V[(int64_t)k * n + i] = v[i];
     if (tk != 0.0) {
-      // p = tau * A22 * v : one wave per row, lanes along the row
-      for (int i = wave; i < m; i += 16) {
-        const double* row = A22 + (int64_t)i * n;
-        double acc = 0.0;
-        for (int j = lane; j < m; j += 64) acc += row[j] * v[j];
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) p[i] = tk * acc;
+      // Thread = (column j, row group g): consecutive threads touch consecutive columns of a row
+      // (coalesced), each walks its share of the rows with independent loads in flight.
+      // p = tau * A22 * v, using A22 = A22^T.
+      const int G = m >= 1024 ? 1 : 1024 / m;
+      const int chunk = (m + G - 1) / G;
+      if (m <= 1024) {
+        if (tid < G * m) {
+          const int j = tid % m, g = tid / m;
+          const int i0 = g * chunk, i1 = (i0 + chunk < m) ? i0 + chunk : m;
+          part[g * m + j] = col_dot(A22 + j, n, v, i0, i1);
+        }
+        __syncthreads();
+        if (tid < m) {
+          double sacc = 0.0;
+          for (int g = 0; g < G; ++g) sacc += part[g * m + tid];
+          p[tid] = tk * sacc;
+        }
+      } else {
+        for (int j = tid; j < m; j += 1024) {
+          p[j] = tk * col_dot(A22 + j, n, v, 0, m);
+        }
       }
       __syncthreads();
       double pv = 0.0;
@@ -96,10 +140,18 @@ __global__ __launch_bounds__(1024) void tridiag_kernel(double* __restrict__ A, i
       const double a2 = -0.5 * tk * dot;
       for (int i = tid; i < m; i += 1024) p[i] += a2 * v[i];      // p now holds w
       __syncthreads();
-      for (int i = wave; i < m; i += 16) {
-        double* row = A22 + (int64_t)i * n;
-        const double vi = v[i], wi = p[i];
-        for (int j = lane; j < m; j += 64) row[j] -= vi * p[j] + wi * v[j];
+      if (m <= 1024) {
+        if (tid < G * m) {
+          const int j = tid % m, g = tid / m;
+          const int i0 = g * chunk, i1 = (i0 + chunk < m) ? i0 + chunk : m;
+          const double vj = v[j], wj = p[j];
+          col_rank2(A22 + j, n, v, p, vj, wj, i0, i1);
+        }
+      } else {
+        for (int j = tid; j < m; j += 1024) {
+          const double vj = v[j], wj = p[j];
+          col_rank2(A22 + j, n, v, p, vj, wj, 0, m);
+        }
       }
     }
     __syncthreads();
@@ -390,8 +442,8 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
   double* V = F + (int64_t)5 * n * NEV;     // n*n
   hipLaunchKernelGGL(eig_load_kernel, dim3(cdiv(n, 256), n), dim3(256), 0, s, d_M, n, A);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tridiag_kernel, dim3(1), dim3(1024), sizeof(double) * 2 * n, s, A, n, d, e, tau,
-                     V);
+  hipLaunchKernelGGL(tridiag_kernel, dim3(1), dim3(1024), sizeof(double) * (2 * n + 1024), s, A, n, d,
+                     e, tau, V);
   DMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(256), sizeof(double) * (2 + NEV) * n, s, d, e, n,
                      F, lam, Z);

@@ -191,16 +191,23 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 }
 
 // stats[c] = sum over partials, in a fixed order
-__global__ void stats_reduce_kernel(const double* __restrict__ part, int nparts,
-                                    double* __restrict__ stats) {
-  const int c = threadIdx.x;  // 128 threads
+// grid: 128 channels, block: 64 (one wave); lane l sums partials l, l+64, ... then a fixed tree
+__global__ __launch_bounds__(64) void stats_reduce_kernel(const double* __restrict__ part, int nparts,
+                                                          double* __restrict__ stats) {
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int t = 0; t < nparts; ++t) {
+  for (int t = threadIdx.x; t < nparts; t += 64) {
     s1 += part[((int64_t)t * CW + c) * 2 + 0];
     s2 += part[((int64_t)t * CW + c) * 2 + 1];
   }
-  stats[c * 2 + 0] = s1;
-  stats[c * 2 + 1] = s2;
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  if (threadIdx.x == 0) {
+    stats[c * 2 + 0] = s1;
+    stats[c * 2 + 1] = s2;
+  }
 }
 
 // InstanceNorm2d (eps 1e-5, biased variance) folded to y = u*alpha + beta' per channel
@@ -238,7 +245,7 @@ int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L
   hipLaunchKernelGGL(channel_stats_kernel, dim3(CW, STAT_SLICES), dim3(256), 0, s, c->u, LL,
                      c->part);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(CW), 0, s, c->part, STAT_SLICES, c->stats);
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, STAT_SLICES, c->stats);
   DMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, c->stats, (double)LL,
                      W.stem_gamma, W.stem_beta, c->ab);
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
 
 int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s) {
   const int tiles = act_tiles(L);
-  hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(CW), 0, s, c->part, tiles * tiles, d_stats);
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, tiles * tiles, d_stats);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
@@ -524,6 +531,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ xpa
 // dm = |(h + h^T)/2| ; M_ij = 0.5*((dm_0j^2 + dm_i0^2) - dm_ij^2), every step rounded to f32
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ h0, int L,
                                                    float* __restrict__ M) {
+#pragma clang fp contract(off)
   const int i = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= L) return;

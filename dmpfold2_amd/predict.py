@@ -195,6 +195,10 @@ class Engine:
             self._keep = (d_msa, d_tpl)
         return coords, confs
 
+    def sync_check(self):
+        """Wait for the queued work and raise if a device-side fault was recorded."""
+        _lib.check(self.lib.dmp_sync_check(self._ctx, self.stream()))
+
     def fetch(self, name, numel):
         out = torch.empty((int(numel),), dtype=torch.float32, device=self.device)
         n = _lib.check(self.lib.dmp_debug_fetch(self._ctx, name.encode(), out.data_ptr(),

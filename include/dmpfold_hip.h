@@ -148,6 +148,10 @@ int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d
                 int Lt, int nloops, int refine_steps, float* d_coords, float* d_conf,
                 void* stream);
 
+/* Synchronise `stream` and report device-side faults recorded since the context was created
+ * (the bounded spin of the sequence-GRU workgroup hand-off).  0 = all results valid. */
+int dmp_sync_check(dmp_ctx* ctx, void* stream);
+
 /* ---- introspection for tests and the benchmark ------------------------------------------- */
 /* After dmp_predict: copy an internal tensor to d_dst (device).  Names: "w", "contacts",
  * "mat1d", "conf_means" (P floats), "ca_pass" (P x L x 3), "best_ca" (L x 3, before the final

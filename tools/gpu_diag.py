@@ -147,8 +147,28 @@ def timings(L, N, n=10, m=100):
     timed(f"predict n={n} m={m}", lambda: st.eng.predict(a, None, n, m))
 
 
+def cpu_sweep():
+    """How many PyTorch-CPU threads does the oracle want on this host?"""
+    sd = synth.synth_weights(0, coord_scale=5.0)
+    W = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    a = O.encode_aln(synth.synth_msa(300, 100, 0))
+    x = W["embed.weight"][torch.from_numpy(a.astype(np.int64))]
+    xin = torch.randn(1, 128, 300, 300)
+    for nt in (8, 16, 32, 64, 128):
+        if nt > (os.cpu_count() or 1):
+            break
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            t = time.time(); O._gru(W, "vgru", x, 22, 512, 2, False, False); tv = time.time() - t
+            t = time.time(); O.block_conv(W, 1, xin); tc = time.time() - t
+            t = time.time(); O.block_conv(W, 2, xin); tc = min(tc, time.time() - t)
+        print(f"cpu threads {nt:4d}: vgru 100 rows {tv:7.2f} s   one 5x5 conv block {tc:7.3f} s", flush=True)
+
+
 if __name__ == "__main__":
-    if "--time" in sys.argv:
+    if "--cpu-sweep" in sys.argv:
+        cpu_sweep()
+    elif "--time" in sys.argv:
         i = sys.argv.index("--time")
         timings(int(sys.argv[i + 1]), int(sys.argv[i + 2]))
     else:
