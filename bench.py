@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="targets in flight per GPU (one context + HIP stream each); a step is one "
+                         "batch of this many targets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -116,19 +119,19 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from dmpfold2_amd import synth, _lib
-    from dmpfold2_amd.predict import Engine, encode_aln
+    from dmpfold2_amd.predict import Pipeline, encode_aln
     lib = _lib.load()
-    eng = Engine(device, L_NS, N_NS)
+    S = max(1, args.streams)
     sd = synth.synth_weights(0, coord_scale=5.0)
-    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    pipe = Pipeline(device, L_NS, N_NS, {k: torch.from_numpy(np.array(v)) for k, v in sd.items()},
+                    streams=S)
 
-    # one synthetic target per step and rank, resident in HBM before the clock starts
-    total_steps = args.warmup + args.steps
+    # S synthetic targets per step and rank, all resident in HBM before the clock starts
+    total = (args.warmup + args.steps) * S
     targets = []
-    for s in range(total_steps):
-        rows = synth.synth_msa(L_NS, N_NS, seed=1000 * rank + s)
+    for i in range(total):
+        rows = synth.synth_msa(L_NS, N_NS, seed=100000 * rank + i)
         targets.append(torch.from_numpy(encode_aln(rows)).to(device))
-    outs = []
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -136,19 +139,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for s in range(args.warmup):
-        outs.append(eng.predict_device(targets[s], None, ITERS, MINSTEPS))
+    outs = pipe.run(targets[:args.warmup * S], ITERS, MINSTEPS)
     sync_all()
-    _lib.check(lib.dmp_profile_enable(eng.ctx, 1, 16 * (ITERS + 1) * max(args.steps, 1)))
+    for e in pipe.engines:
+        _lib.check(lib.dmp_profile_enable(e.ctx, 1, 16 * (ITERS + 1) * (args.steps + 1)))
     t0 = time.perf_counter()
-    for s in range(args.warmup, total_steps):
-        outs.append(eng.predict_device(targets[s], None, ITERS, MINSTEPS))
+    outs += pipe.run(targets[args.warmup * S:], ITERS, MINSTEPS)
     sync_all()
     elapsed = time.perf_counter() - t0
-    conv_ms, conv_n = C.c_float(), C.c_int()
-    _lib.check(lib.dmp_profile_conv_ms(eng.ctx, C.byref(conv_ms), C.byref(conv_n)))
-    _lib.check(lib.dmp_profile_enable(eng.ctx, 0, 0))
-    eng.sync_check()
+    conv_tot, conv_cnt = 0.0, 0
+    for e in pipe.engines:
+        ms, n = C.c_float(), C.c_int()
+        _lib.check(lib.dmp_profile_conv_ms(e.ctx, C.byref(ms), C.byref(n)))
+        _lib.check(lib.dmp_profile_enable(e.ctx, 0, 0))
+        conv_tot += ms.value * n.value
+        conv_cnt += n.value
+    conv_ms = conv_tot / conv_cnt if conv_cnt else 0.0
+    pipe.sync_check()
     ok = all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in outs)
 
     if distributed:
@@ -160,7 +167,7 @@ def main():
         ok = bool(flag.item() > 0.5)
 
     if rank == 0:
-        achieved = CONV_FLOP_PER_LAUNCH / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
+        achieved = CONV_FLOP_PER_LAUNCH / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "conv5x5_pmc.json")
         if os.path.exists(pmc):
@@ -170,7 +177,7 @@ def main():
                 traffic = None
         line = {
             "metric": "structures/s at L=300, N_seq=2000, 10 iters+100 min",
-            "value": world * args.steps / elapsed,
+            "value": world * args.steps * S / elapsed,
             "unit": "structures/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -182,16 +189,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "finite_outputs": ok,
-            "config": {"workload": "single synthetic target L=300 N_seq=2000, iterations=10, "
-                                   "minsteps=100 per step and GPU (BASELINE.json metric config)",
+            "config": {"workload": "synthetic targets L=300 N_seq=2000, iterations=10, minsteps=100 "
+                                   "(BASELINE.json metric config); one step = one batch of "
+                                   f"{S} independent targets per GPU",
                        "L": L_NS, "n_seq": N_NS, "iterations": ITERS, "minsteps": MINSTEPS,
+                       "targets_per_step_per_gpu": S,
                        "weights": "synthetic seed 0 (reference state_dict shapes)",
-                       "parallelism": f"replicas x{world}, no collective on the data path"},
+                       "parallelism": f"replicas x{world}, no collective on the data path; "
+                                      f"{S} HIP streams per GPU"},
             "roofline": {"kernel": "conv5x5_maxout_kernel (5x5 conv 128->512 + bias + 4-way maxout)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": traffic, "launches_timed": conv_n.value,
-                         "avg_launch_ms": conv_ms.value,
+                         "traffic": traffic, "launches_timed": conv_cnt,
+                         "avg_launch_ms": conv_ms,
                          "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -41,6 +41,12 @@ SIGNATURES = {
     "dmp_refine_coords": (_i, [_vp, _fp, _i, _i, _vp]),
     "dmp_ca_to_backbone": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_predict": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i, _fp, _fp, _vp]),
+    "dmp_predict_begin": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i, _vp]),
+    "dmp_predict_pass": (_i, [_vp, _vp]),
+    "dmp_predict_end": (_i, [_vp, _fp, _fp, _vp]),
+    "dmp_lane_create": (_i, [C.POINTER(_vp)]),
+    "dmp_lane_destroy": (None, [_vp]),
+    "dmp_ctx_set_lane": (_i, [_vp, _vp]),
     "dmp_sync_check": (_i, [_vp, _vp]),
     "dmp_debug_fetch": (_i64, [_vp, C.c_char_p, _fp, _i64, _vp]),
     "dmp_profile_enable": (_i, [_vp, _i, _i]),

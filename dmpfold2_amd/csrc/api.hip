@@ -215,10 +215,18 @@ static int trunk_pass(dmp_ctx* c, const float* z0, const float* dmap, int L, flo
   float* oth = c->xb;
   if ((rc = stem_update_padded(c, z0, dmap, L, cur, s))) return rc;
   for (int k = 1; k <= NBLOCK; ++k) {
+    if (c->lane && c->lane->last) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->lane->last, 0));
     if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
       DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n], s));
     }
     if ((rc = conv5x5_maxout_padded(c, k, cur, L, c->u, c->stats, s, false))) return rc;
+    if (c->lane) {
+      dmp_lane* ln = c->lane;
+      void* e = ln->ev[ln->next];
+      ln->next = (ln->next + 1) % dmp_lane::RING;
+      DMP_HIP(hipEventRecord((hipEvent_t)e, s));
+      ln->last = e;
+    }
     if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
       DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n + 1], s));
       c->prof_n += 2;
@@ -519,9 +527,18 @@ int dmp_ca_to_backbone(dmp_ctx* ctx, const float* d_ca, const float* d_conf_logi
 
 int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca, int Lt,
                 int nloops, int refine_steps, float* d_coords, float* d_conf, void* stream) {
+  int rc = dmp_predict_begin(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps, stream);
+  if (rc) return rc;
+  while (ctx->passes_done <= ctx->run_nloops)
+    if ((rc = dmp_predict_pass(ctx, stream))) return rc;
+  return dmp_predict_end(ctx, d_coords, d_conf, stream);
+}
+
+int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
+                      int Lt, int nloops, int refine_steps, void* stream) {
   CHECK_CAP(L, N);
   CHECK_W();
-  DMP_ARG(d_msa && d_coords && d_conf, "null argument");
+  DMP_ARG(d_msa != nullptr, "null argument");
   DMP_ARG(N >= 1 && L >= 8, "need N >= 1 and L >= 8 (got N=%d L=%d)", N, L);
   DMP_ARG(d_template_ca == nullptr || Lt == L,
           "template has %d CA atoms but the alignment has %d columns", Lt, L);
@@ -533,6 +550,8 @@ int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d
   c->last_L = L;
   c->last_N = N;
   c->passes_done = 0;
+  c->run_nloops = nloops;
+  c->run_refine = refine_steps;
   // ---- features
   if ((rc = msa_weights(c, d_msa, N, L, c->w, s))) return rc;
   const float *inv = nullptr, *contacts = nullptr;
@@ -553,21 +572,64 @@ int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d
   else rc = fill_f32(c->dmap, (int64_t)L * L, -1.0f, s);
   if (rc) return rc;
   if ((rc = act_clear(c->xa, L, s))) return rc;
-  if ((rc = act_clear(c->xb, L, s))) return rc;
-  // ---- first pass + recycling
-  for (int pass = 0; pass <= nloops; ++pass) {
-    if (pass > 0 && (rc = pair_distances(c->ca, L, 1, c->dmap, s))) return rc;
-    if ((rc = trunk_pass(c, c->z0, c->dmap, L, c->conf, c->gram, s))) return rc;
-    if ((rc = eigh_top8(c, c->gram, L, c->mds, s))) return rc;
-    if ((rc = coords_from_mds(c, c->mat1d, c->mds, L, c->ca, s))) return rc;
-    if (pass == 0 && refine_steps > 0 && (rc = refine_coords(c->ca, L, refine_steps, s))) return rc;
-    if ((rc = select_best(c, c->conf, c->ca, L, pass, c->max_passes, s))) return rc;
-    c->passes_done = pass + 1;
-  }
+  return act_clear(c->xb, L, s);
+}
+
+// one trunk pass (first pass or one recycling iteration) + MDS + coordinate GRU + best-of update
+int dmp_predict_pass(dmp_ctx* ctx, void* stream) {
+  DMP_ARG(ctx != nullptr, "null context");
+  dmp_ctx* c = ctx;
+  DMP_ARG(c->passes_done <= c->run_nloops, "all passes of this prediction were already issued");
+  hipStream_t s = STREAM;
+  const int L = c->last_L, pass = c->passes_done;
+  int rc;
+  if (pass > 0 && (rc = pair_distances(c->ca, L, 1, c->dmap, s))) return rc;
+  if ((rc = trunk_pass(c, c->z0, c->dmap, L, c->conf, c->gram, s))) return rc;
+  if ((rc = eigh_top8(c, c->gram, L, c->mds, s))) return rc;
+  if ((rc = coords_from_mds(c, c->mat1d, c->mds, L, c->ca, s))) return rc;
+  if (pass == 0 && c->run_refine > 0 && (rc = refine_coords(c->ca, L, c->run_refine, s))) return rc;
+  if ((rc = select_best(c, c->conf, c->ca, L, pass, c->max_passes, s))) return rc;
+  c->passes_done = pass + 1;
+  return DMP_OK;
+}
+
+int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) {
+  DMP_ARG(ctx && d_coords && d_conf, "null argument");
+  dmp_ctx* c = ctx;
+  DMP_ARG(c->passes_done == c->run_nloops + 1, "dmp_predict_end before all passes were issued");
+  hipStream_t s = STREAM;
+  const int L = c->last_L;
+  int rc;
   DMP_HIP(hipMemcpyAsync(c->best_ca_snapshot, c->best_ca, sizeof(float) * 3 * L,
                          hipMemcpyDeviceToDevice, s));
-  if (refine_steps > 0 && (rc = refine_coords(c->best_ca, L, refine_steps, s))) return rc;
+  if (c->run_refine > 0 && (rc = refine_coords(c->best_ca, L, c->run_refine, s))) return rc;
   return ca_to_backbone(c->best_ca, c->best_conf, L, d_coords, d_conf, s);
+}
+
+// ---- heavy lane: serialises the conv launches of the contexts that share it -----------------
+int dmp_lane_create(dmp_lane** out) {
+  DMP_ARG(out != nullptr, "out is NULL");
+  dmp_lane* l = new dmp_lane();
+  for (int i = 0; i < dmp_lane::RING; ++i) {
+    hipEvent_t e;
+    hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (err != hipSuccess) { dmp_lane_destroy(l); return hip_fail(err, "hipEventCreate", __FILE__, __LINE__); }
+    l->ev.push_back((void*)e);
+  }
+  *out = l;
+  return DMP_OK;
+}
+
+void dmp_lane_destroy(dmp_lane* l) {
+  if (!l) return;
+  for (void* e : l->ev) (void)hipEventDestroy((hipEvent_t)e);
+  delete l;
+}
+
+int dmp_ctx_set_lane(dmp_ctx* ctx, dmp_lane* lane) {
+  DMP_ARG(ctx != nullptr, "null context");
+  ctx->lane = lane;
+  return DMP_OK;
 }
 
 int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t capacity, void* stream) {

@@ -88,8 +88,19 @@ struct Weights {
 
 }  // namespace dmp
 
+// Shared by the contexts of one process that run concurrently on different streams: the
+// machine-filling conv5x5 launches take turns (cross-stream events), everything else overlaps.
+struct dmp_lane {
+  static constexpr int RING = 64;
+  std::vector<void*> ev;   // hipEvent_t ring
+  int next = 0;
+  void* last = nullptr;    // event recorded after the most recent conv launch
+};
+
 struct dmp_ctx {
   int device = 0;
+  dmp_lane* lane = nullptr;
+  int run_nloops = 0, run_refine = 0;
   int max_L = 0, max_N = 0;
   int64_t bytes = 0;
   dmp::Weights W;

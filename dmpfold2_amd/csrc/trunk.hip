@@ -6,6 +6,10 @@
 // 16x16 pixels never straddle the border logic.  The pre-norm maxout output `u` is dense.
 #include "common.h"
 
+// Element-wise stages mirror separately rounded float32 tensor ops of the reference; fused
+// multiply-adds are written explicitly (fmaf) where they are wanted.
+#pragma clang fp contract(off)
+
 namespace dmp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -475,8 +479,8 @@ __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
   const float sg = sigmoid_f(dot + sse_b);
 #pragma unroll
   for (int c = 0; c < CW; ++c) {
-    const float t = __fadd_rn(__fmul_rn(yv[c], sh_g[c]), __fmul_rn(yv[c], sg));
-    xout[c * PP + pp] = __fadd_rn(t, xin[c * PP + pp]);
+    const float t = yv[c] * sh_g[c] + yv[c] * sg;      // contraction is off for this file
+    xout[c * PP + pp] = t + xin[c * PP + pp];
   }
 }
 
@@ -531,16 +535,15 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ xpa
 // dm = |(h + h^T)/2| ; M_ij = 0.5*((dm_0j^2 + dm_i0^2) - dm_ij^2), every step rounded to f32
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ h0, int L,
                                                    float* __restrict__ M) {
-#pragma clang fp contract(off)
   const int i = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= L) return;
   auto dm = [&](int a, int b) {
-    return fabsf(__fmul_rn(__fadd_rn(h0[(int64_t)a * L + b], h0[(int64_t)b * L + a]), 0.5f));
+    return fabsf((h0[(int64_t)a * L + b] + h0[(int64_t)b * L + a]) * 0.5f);
   };
   const float d0j = dm(0, j), di0 = dm(i, 0), dij = dm(i, j);
-  const float t = __fadd_rn(__fmul_rn(d0j, d0j), __fmul_rn(di0, di0));
-  M[(int64_t)i * L + j] = __fmul_rn(0.5f, __fadd_rn(t, -__fmul_rn(dij, dij)));
+  const float t = d0j * d0j + di0 * di0;
+  M[(int64_t)i * L + j] = 0.5f * (t - dij * dij);
 }
 
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,

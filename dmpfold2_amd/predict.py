@@ -113,11 +113,12 @@ def load_state_dict(weights_file=None):
 class Engine:
     """Owns one `dmp_ctx` (device buffers + packed weights) on one GPU."""
 
-    def __init__(self, device, max_L, max_N):
+    def __init__(self, device, max_L, max_N, stream=None):
         self.lib = _lib.load()
         self.device = _resolve_device(device)
         self.max_L = int(max_L)
         self.max_N = int(min(max_N, MAX_SEQS))
+        self._stream = stream          # optional torch.cuda.Stream owned by this engine
         self._ctx = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dmp_ctx_create(self.device.index, self.max_L, self.max_N,
@@ -144,7 +145,29 @@ class Engine:
         return int(self.lib.dmp_ctx_device_bytes(self._ctx))
 
     def stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        s = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
+
+    def issue_phases(self, d_msa, iterations=default_iterations, minsteps=default_minsteps, out=None):
+        """Generator that enqueues one prediction phase by phase (features + sequence trunk, then
+        each trunk pass, then the final refinement); the caller interleaves several engines by
+        advancing their generators in turn.  The (coords, confs) tensors are appended to `out`."""
+        n, L = d_msa.shape
+        ctx = torch.cuda.stream(self._stream) if self._stream is not None else torch.cuda.device(self.device)
+        with ctx:
+            coords = torch.empty((L, 5, 3), dtype=torch.float32, device=self.device)
+            confs = torch.empty((L,), dtype=torch.float32, device=self.device)
+        nloops = int(max(iterations, 0))
+        _lib.check(self.lib.dmp_predict_begin(self._ctx, d_msa.data_ptr(), n, L, None, 0, nloops,
+                                              int(max(minsteps, 0)), self.stream()))
+        yield "begin"
+        for p in range(nloops + 1):
+            _lib.check(self.lib.dmp_predict_pass(self._ctx, self.stream()))
+            yield p
+        _lib.check(self.lib.dmp_predict_end(self._ctx, coords.data_ptr(), confs.data_ptr(),
+                                            self.stream()))
+        if out is not None:
+            out.append((coords, confs))
 
     def set_weights(self, state_dict, tag=None):
         """Strict load like load_state_dict (predict.py:98): unknown, missing or mis-shaped
@@ -204,6 +227,80 @@ class Engine:
         n = _lib.check(self.lib.dmp_debug_fetch(self._ctx, name.encode(), out.data_ptr(),
                                                 int(numel), self.stream()))
         return out[:n]
+
+
+class Pipeline:
+    """Throughput mode on one GPU: `streams` engines (each its own context and HIP stream) share a
+    lane, so their machine-filling convolutions take turns while the latency-bound kernels of one
+    target (eigensolver, sequence GRUs, minimiser, the vertical GRU's per-row launches) run under
+    the convolutions of another.  One host thread issues all work, pass by pass, round robin; the
+    engines start half a prediction out of phase."""
+
+    def __init__(self, device, max_L, max_N, state_dict, streams=2):
+        self.lib = _lib.load()
+        self.device = _resolve_device(device)
+        self.engines = []
+        self._lane = C.c_void_p()
+        _lib.check(self.lib.dmp_lane_create(C.byref(self._lane)))
+        for _ in range(max(1, int(streams))):
+            with torch.cuda.device(self.device):
+                st = torch.cuda.Stream(device=self.device)
+            eng = Engine(self.device, max_L, max_N, stream=st)
+            eng.set_weights(state_dict)
+            if streams > 1:
+                _lib.check(self.lib.dmp_ctx_set_lane(eng.ctx, self._lane))
+            self.engines.append(eng)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+        if self._lane:
+            self.lib.dmp_lane_destroy(self._lane)
+            self._lane = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, d_msas, iterations=default_iterations, minsteps=default_minsteps):
+        """Enqueue every target (uint8 (N, L) tensors on the GPU); target i runs on engine
+        i % streams.  Returns [(coords, confs)] in input order; nothing is synchronised."""
+        S = len(self.engines)
+        cur = torch.cuda.current_stream(self.device)
+        for e in self.engines:
+            e._stream.wait_stream(cur)
+        results = [[] for _ in d_msas]
+        queues = [[(i, m) for i, m in enumerate(d_msas) if i % S == s] for s in range(S)]
+        gens = [None] * S
+        # engine s idles for s/S of a prediction's phases before its first target
+        delay = [(s * (int(max(iterations, 0)) + 3)) // S for s in range(S)]
+        live = True
+        while live:
+            live = False
+            for s in range(S):
+                if delay[s] > 0:
+                    delay[s] -= 1
+                    live = live or bool(queues[s])
+                    continue
+                if gens[s] is None and queues[s]:
+                    i, m = queues[s].pop(0)
+                    gens[s] = self.engines[s].issue_phases(m, iterations, minsteps, results[i])
+                if gens[s] is not None:
+                    live = True
+                    try:
+                        next(gens[s])
+                    except StopIteration:
+                        gens[s] = None
+        for e in self.engines:
+            cur.wait_stream(e._stream)
+        return [r[0] for r in results]
+
+    def sync_check(self):
+        for e in self.engines:
+            e.sync_check()
 
 
 _ENGINES = {}

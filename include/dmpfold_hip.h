@@ -148,6 +148,24 @@ int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d
                 int Lt, int nloops, int refine_steps, float* d_coords, float* d_conf,
                 void* stream);
 
+/* The same prediction issued in phases, so that one host thread can interleave several contexts
+ * (different streams) pass by pass: begin = features + sequence trunk + static stem, then exactly
+ * nloops + 1 calls of dmp_predict_pass (first pass, then the recycling iterations), then end =
+ * final refinement + backbone.  dmp_predict is begin + (nloops+1) x pass + end. */
+int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
+                      int Lt, int nloops, int refine_steps, void* stream);
+int dmp_predict_pass(dmp_ctx* ctx, void* stream);
+int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream);
+
+/* Throughput mode: contexts of ONE process that run on different streams may share a lane.  The
+ * machine-filling conv5x5 launches of all contexts on a lane then take turns (cross-stream events)
+ * while every other kernel of one target overlaps the convolutions of another.  All contexts of
+ * a lane must be driven by the same host thread.  NULL detaches. */
+typedef struct dmp_lane dmp_lane;
+int dmp_lane_create(dmp_lane** out);
+void dmp_lane_destroy(dmp_lane* lane);
+int dmp_ctx_set_lane(dmp_ctx* ctx, dmp_lane* lane);
+
 /* Synchronise `stream` and report device-side faults recorded since the context was created
  * (the bounded spin of the sequence-GRU workgroup hand-off).  0 = all results valid. */
 int dmp_sync_check(dmp_ctx* ctx, void* stream);

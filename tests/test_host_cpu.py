@@ -1,0 +1,158 @@
+"""CPU-only checks: host-side logic, the C-ABI library (load + exported symbols, host helpers),
+and the world_size-2 sharding path over gloo.  No GPU compute."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_rows
+import dmpfold_oracle as O
+from dmpfold2_amd import _lib, predict, shard, synth
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "dmpfold_hip.h")).read()
+    declared = set(re.findall(r"\b(dmp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"dmp_ctx", "dmp_lane", "dmp_status"}
+    assert len(declared) >= 35
+    lib = C.CDLL(_lib.LIB_PATH)
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    # the ctypes binding covers the same set
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().dmp_abi_version() == 1
+
+
+def test_residue_encoding_all_bytes():
+    """dmp_msa_encode (host helper of the C ABI) == the reference's translate + uint8 wrap
+    (predict.py:124-128) for every byte value."""
+    lib = _lib.load()
+    text = np.arange(256, dtype=np.uint8)
+    out = np.empty_like(text)
+    assert lib.dmp_msa_encode(text.ctypes.data, text.size, out.ctypes.data) == 0
+    assert np.array_equal(out, O._code_table()[text])
+    assert out[ord("A")] == 0 and out[ord("V")] == 19 and out[ord("X")] == 20 and out[ord("-")] == 21
+    assert out[ord("a")] == (ord("a") - 65) % 256
+
+
+@pytest.mark.parametrize("name", ["pf10963_n0_m0", "alphabet_L16_N12_n0_m0", "synth_L24_N3050_n1_m0"])
+def test_host_parse_and_encode_match_reference(name, tmp_path):
+    g = load_golden(name)
+    p = tmp_path / "a.aln"
+    p.write_text(">header lines are skipped\n" + "\n".join(golden_rows(g)) + "  \n")
+    alnmat = predict.encode_aln(predict.read_aln(str(p)))
+    assert alnmat.dtype == np.uint8
+    assert np.array_equal(alnmat, g["alnmat"])          # includes the 3000-row cap
+
+
+def test_ragged_alignment_raises_value_error(tmp_path):
+    p = tmp_path / "r.aln"
+    p.write_text("ACDEFGHIKL\nACDEFGHIK\n")
+    with pytest.raises(ValueError):
+        predict.encode_aln(predict.read_aln(str(p)))
+
+
+def test_template_parser_matches_oracle(tmp_path):
+    g = load_golden("template_L96_N50_n1_m0")
+    p = tmp_path / "t.pdb"
+    with open(p, "w") as fh:
+        fh.write("HEADER test\n")
+        for i, (x, y, z) in enumerate(g["template_ca"]):
+            fh.write("ATOM  %5d  N   ALA A%4d    %8.3f%8.3f%8.3f  1.00  0.00\n" % (2 * i, i + 1, x + 1, y, z))
+            fh.write("ATOM  %5d  CA  ALA A%4d    %8.3f%8.3f%8.3f  1.00  0.00\n" % (2 * i + 1, i + 1, x, y, z))
+    got = predict.read_template_ca(str(p))
+    assert got.shape == (96, 3) and got.dtype == np.float32
+    assert np.array_equal(got, O.read_template_ca(str(p)).numpy())
+
+
+def test_pdb_text_matches_reference_cli_output():
+    g = load_golden("pf10963_default_cli")
+    text = predict.pdb_text(torch.from_numpy(g["coords"]), torch.from_numpy(g["confs"]), g["alnmat"])
+    assert text == bytes(g["cli_stdout"]).decode()
+
+
+def test_pdb_text_rejects_non_standard_first_row():
+    coords, confs = torch.zeros(8, 5, 3), torch.zeros(8)
+    alnmat = np.zeros((1, 8), dtype=np.uint8)
+    alnmat[0, 3] = 20                                     # 'X' in the query: reference raises KeyError
+    with pytest.raises(KeyError):
+        predict.pdb_text(coords, confs, alnmat)
+
+
+def test_no_cpu_path_and_no_download(tmp_path):
+    with pytest.raises(RuntimeError):
+        predict.aln_to_coords(os.path.join(ROOT, "tests", "golden", "PF10963.aln"), device="cpu")
+    if not os.path.isfile(predict.default_weight_files()[0]):
+        with pytest.raises(FileNotFoundError):
+            predict.load_state_dict(None)
+
+
+def test_context_rejects_bad_arguments_without_a_gpu():
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.dmp_ctx_create(0, 4, 10, C.byref(ctx)) < 0          # max_L < 8
+    assert b"max_L" in lib.dmp_last_error()
+    assert lib.dmp_msa_encode(None, 0, None) < 0
+
+
+def test_synthetic_generators_are_deterministic():
+    a = synth.synth_msa(50, 20, seed=3)
+    assert a == synth.synth_msa(50, 20, seed=3) and a != synth.synth_msa(50, 20, seed=4)
+    assert len(a) == 20 and all(len(r) == 50 for r in a) and "-" not in a[0]
+    sd = synth.synth_weights(0, coord_scale=5.0)
+    assert len(sd) == 184 and sum(v.size for v in sd.values()) == 34956278
+    assert np.array_equal(sd["embed.weight"], np.eye(22, dtype=np.float32))
+
+
+def test_partition_targets_is_balanced_and_complete():
+    rng = np.random.default_rng(0)
+    Ls = rng.integers(100, 301, size=256)
+    costs = [shard.estimate_cost(int(L), 2000) for L in Ls]
+    for world in (1, 2, 4, 8):
+        parts = shard.partition_targets(costs, world)
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(256))
+        loads = [sum(costs[i] for i in p) for p in parts]
+        assert max(loads) / (sum(loads) / world) < 1.02
+
+
+_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from dmpfold2_amd import shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+costs = [shard.estimate_cost(100 + 7 * i, 500) for i in range(23)]
+mine = shard.partition_targets(costs, world)[rank]
+dist.barrier()
+t0 = time.perf_counter()
+done = 0
+for i in mine:                      # stand-in for the per-target GPU work: no collective in here
+    done += 1
+elapsed = time.perf_counter() - t0 + 0.01 * (rank + 1)
+total, tmax = shard.job_summary(done, elapsed)
+assert total == 23, total
+assert abs(tmax - max(0.01 * (r + 1) for r in range(world))) < 0.05
+gathered = [None] * world
+dist.all_gather_object(gathered, mine)
+assert sorted(i for p in gathered for i in p) == list(range(23))
+dist.destroy_process_group()
+print("rank", rank, "ok", len(mine))
+"""
+
+
+def test_sharded_job_over_gloo_world_size_2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
