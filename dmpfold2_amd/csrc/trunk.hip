@@ -277,17 +277,31 @@ constexpr int IN_PITCH = 24;              // row pitch in LDS: 4 rows x 8 column
 constexpr int NTAP = 25;
 constexpr int MCH = 128;                  // conv channels per workgroup
 constexpr int NCHUNK = CW / CONV_CC;      // 64
+// Measured at L = 300 (tools/ubench_conv.hip, ms per launch): 0: 2.50, 1: 2.36, 65: 2.26,
+// 193: 2.25; tap-ahead / group-barrier / b128-fragment variants were neutral or slower.  Floors:
+// no staging 2.18, MFMA only 2.09.
+#ifndef CONV_VARIANT
+#define CONV_VARIANT 65
+#endif
 constexpr int W_STAGE = NTAP * CONV_CC * MCH;          // 6400 floats
 constexpr int IN_STAGE = CONV_CC * HALO * IN_PITCH;    // 960 floats
 
+// V: scheduling variant bits (tools/ubench_conv.hip measures them): 1 = branch-free prefetch,
+// 2 = LDS fragments of tap t+1 read before the MFMAs of tap t, 4 = pin that order with
+// sched_group_barrier.
+template <int V>
 __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __restrict__ xpad,
                                                                 const float* __restrict__ wpack,
                                                                 const float* __restrict__ bias, int L,
                                                                 int P, int tiles, int nwork,
                                                                 float* __restrict__ u,
                                                                 double* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float w_lds[2][W_STAGE];
-  __shared__ float in_lds[2][IN_STAGE];
+  // one LDS object (a second one makes hipcc drain vmcnt in front of LDS reads of a DMA pipeline)
+  __shared__ __attribute__((aligned(16))) float smem[2 * W_STAGE + 2 * IN_STAGE];
+  float (*w_lds)[W_STAGE] = reinterpret_cast<float (*)[W_STAGE]>(smem);
+  float (*in_lds)[IN_STAGE] = reinterpret_cast<float (*)[IN_STAGE]>(smem + 2 * W_STAGE);
+  // LDS row pitch of the input tile: 24 (bank-conflict free) or 20 (linear image for LDS-DMA)
+  constexpr int IP = (V & 128) ? HALO : IN_PITCH;
   // XCD-aware remap: block b runs on XCD b % 8; give each XCD a contiguous range of work items
   // so the 4 channel splits of a tile and neighbouring tiles share one L2.
   const int id = blockIdx.x;
@@ -303,39 +317,77 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
 
   // staging assignments
   const float4* wsrc = reinterpret_cast<const float4*>(wpack + (int64_t)split * NCHUNK * W_STAGE);
+  // Every prefetch load is unconditional (a load under a branch makes hipcc wait vmcnt(0) right
+  // behind it): out-of-range slots re-read a valid element and are dropped at the LDS store.
   int in_off[4], in_dst[4];
+  bool in_ok[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int idx = tid + e * 256;   // < 800 valid
-    const int cc = idx / (HALO * HALO), rem = idx % (HALO * HALO);
+    in_ok[e] = idx < CONV_CC * HALO * HALO;
+    const int idc = in_ok[e] ? idx : 0;
+    const int cc = idc / (HALO * HALO), rem = idc % (HALO * HALO);
     const int yy = rem / HALO, xx = rem % HALO;
-    in_off[e] = (idx < CONV_CC * HALO * HALO) ? (int)(cc * PP + (int64_t)(ty0 + yy) * P + tx0 + xx) : -1;
-    in_dst[e] = cc * HALO * IN_PITCH + yy * IN_PITCH + xx;
+    in_off[e] = (int)(cc * PP + (int64_t)(ty0 + yy) * P + tx0 + xx);
+    in_dst[e] = cc * HALO * IP + yy * IP + xx;
   }
+  const int w_last = (tid + 6 * 256 < W_STAGE / 4) ? tid + 6 * 256 : W_STAGE / 4 - 1;
   float4 wreg[7];
   float ireg[4];
   auto prefetch = [&](int chunk) {
     const float4* ws = wsrc + (int64_t)chunk * (W_STAGE / 4);
-#pragma unroll
-    for (int e = 0; e < 7; ++e) {
-      const int idx = tid + e * 256;
-      if (idx < W_STAGE / 4) wreg[e] = ws[idx];
-    }
     const float* xs = xpad + (int64_t)chunk * CONV_CC * PP;
+    if constexpr (V & 64) {
+      // weight slab by LDS-DMA: 25 wave-instructions of 1 KB (lane-linear destination)
+      typedef __attribute__((address_space(1))) const void* gptr_t;
+      typedef __attribute__((address_space(3))) void* lptr_t;
+      float* dst = w_lds[(chunk & 1)] + (size_t)wave * 256;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (in_off[e] >= 0) ireg[e] = xs[in_off[e]];
+      for (int e = 0; e < 6; ++e)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + e * 256), (lptr_t)(dst + e * 1024), 16, 0, 0);
+      if (wave == 0)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + 6 * 256), (lptr_t)(dst + 6 * 1024), 16, 0, 0);
+      if constexpr (V & 128) {
+        // input halo tile as a linear [2][20][20] image: 12.5 wave-instructions of 256 B
+        float* idst = in_lds[(chunk & 1)] + wave * 64;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          __builtin_amdgcn_global_load_lds((gptr_t)(xs + in_off[e]), (lptr_t)(idst + e * 256), 4, 0, 0);
+        if (wave == 0)
+          __builtin_amdgcn_global_load_lds((gptr_t)(xs + in_off[3]), (lptr_t)(idst + 768), 4, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ireg[e] = xs[in_off[e]];
+      }
+    } else if constexpr (V & 1) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) wreg[e] = ws[tid + e * 256];
+      wreg[6] = ws[w_last];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ireg[e] = xs[in_off[e]];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 7; ++e) {
+        const int idx = tid + e * 256;
+        if (idx < W_STAGE / 4) wreg[e] = ws[idx];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (in_ok[e]) ireg[e] = xs[in_off[e]];
+    }
   };
   auto commit = [&](int buf) {
-    float4* wd = reinterpret_cast<float4*>(w_lds[buf]);
+    if constexpr (!(V & 64)) {
+      float4* wd = reinterpret_cast<float4*>(w_lds[buf]);
 #pragma unroll
-    for (int e = 0; e < 7; ++e) {
-      const int idx = tid + e * 256;
-      if (idx < W_STAGE / 4) wd[idx] = wreg[e];
+      for (int e = 0; e < 6; ++e) wd[tid + e * 256] = wreg[e];
+      if (tid + 6 * 256 < W_STAGE / 4) wd[tid + 6 * 256] = wreg[6];
     }
+    if constexpr (!(V & 128)) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (in_off[e] >= 0) in_lds[buf][in_dst[e]] = ireg[e];
+      for (int e = 0; e < 4; ++e)
+        if (in_ok[e]) in_lds[buf][in_dst[e]] = ireg[e];
+    }
   };
 
   // fragment addresses
@@ -344,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
   for (int q = 0; q < 2; ++q) {
     const int nb = 2 * wave + q;
     const int y = (nb >> 1) * 4 + (li >> 3), x = (nb & 1) * 8 + (li & 7);
-    b_off[q] = kk * HALO * IN_PITCH + y * IN_PITCH + x;
+    b_off[q] = kk * HALO * IP + y * IP + x;
   }
   const int a_off = kk * MCH + li;
 
@@ -361,25 +413,73 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
   __syncthreads();
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
     const int buf = chunk & 1;
-    if (chunk + 1 < NCHUNK) prefetch(chunk + 1);
+    if (!(V & 32) && chunk + 1 < NCHUNK) prefetch(chunk + 1);
     const float* wl = w_lds[buf] + a_off;
     const float* il = in_lds[buf];
+    // Fragments of tap t+1 are read from LDS before the 8 MFMAs of tap t are issued (hipcc on its
+    // own waits lgkmcnt(0) in front of every MFMA group and exposes the LDS latency 25 times per
+    // stage); the group barriers pin "6 LDS reads, then 8 MFMAs" per tap.
+    if constexpr (V & 2) {
+      float a[2][4], b[2][2];
 #pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
-      const int dy = tap / 5, dx = tap % 5;
-      float a[4], b[2];
+      for (int mb = 0; mb < 4; ++mb) a[0][mb] = wl[mb * 32];
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) a[mb] = wl[tap * CONV_CC * MCH + mb * 32];
+      for (int q = 0; q < 2; ++q) b[0][q] = il[b_off[q]];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * IN_PITCH + dx];
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const int cur = tap & 1, nxt = cur ^ 1;
+        if (tap + 1 < NTAP) {
+          const int dy = (tap + 1) / 5, dx = (tap + 1) % 5;
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+          for (int mb = 0; mb < 4; ++mb) a[nxt][mb] = wl[(tap + 1) * CONV_CC * MCH + mb * 32];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
+          for (int q = 0; q < 2; ++q) b[nxt][q] = il[b_off[q] + dy * IP + dx];
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mb], b[cur][q], acc[mb][q], 0, 0, 0);
+        if constexpr (V & 4) {
+          if (tap + 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // DS reads of tap+1
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                       // MFMAs of tap
+        }
+      }
+    } else if constexpr (V & 8) {
+      // weights packed so a lane's four channel-block operands are one 16-byte LDS read
+      const float* wl4 = w_lds[buf] + kk * MCH + li * 4;
+#pragma unroll
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const int dy = tap / 5, dx = tap % 5;
+        const float4 av = *reinterpret_cast<const float4*>(wl4 + tap * CONV_CC * MCH);
+        const float a[4] = {av.x, av.y, av.z, av.w};
+        float b[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * IP + dx];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const int dy = tap / 5, dx = tap % 5;
+        float a[4], b[2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) a[mb] = wl[tap * CONV_CC * MCH + mb * 32];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * IP + dx];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
+      }
     }
-    if (chunk + 1 < NCHUNK) commit(buf ^ 1);
-    __syncthreads();
+    if (!(V & 32) && chunk + 1 < NCHUNK) commit(buf ^ 1);
+    if (!(V & 16)) __syncthreads();
   }
 
   // ---- epilogue: bias, 4-way max, store, per-channel partial sums
@@ -441,7 +541,7 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
   const int tiles = act_tiles(L), P = act_pitch(L);
   const int nwork = tiles * tiles * CONV_SPLIT;
   const int grid = round_up(nwork, 8);
-  hipLaunchKernelGGL(conv5x5_maxout_kernel, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
+  hipLaunchKernelGGL(conv5x5_maxout_kernel<CONV_VARIANT>, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
                      P, tiles, nwork, d_u, c->part);
   DMP_LAUNCH_CHECK();
   return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
