@@ -1,6 +1,7 @@
 // extern "C" surface of libdmpfold_hip.so (see include/dmpfold_hip.h): context and weight
 // management, host-side residue encoding, stage-level entry points and the fused dmp_predict.
 #include "common.h"
+#include "conv_bf16.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -167,6 +168,11 @@ static int pack_weights(dmp_ctx* c) {
                   w[((size_t)och * 128 + ich) * 25 + tap];
             }
     if ((rc = upload(pool, bytes, &B.wpack, pk))) return rc;
+    {
+      const std::vector<uint16_t> q = pack_conv_weights_bf16(w.data());
+      if ((rc = dev_alloc(pool, bytes, &B.wq, (int64_t)q.size()))) return rc;
+      DMP_HIP(hipMemcpy(B.wq, q.data(), sizeof(uint16_t) * q.size(), hipMemcpyHostToDevice));
+    }
     if ((rc = upload(pool, bytes, &B.bias, H[p + ".layer1.lin.bias"]))) return rc;
     if ((rc = upload(pool, bytes, &B.gamma, H[p + ".layer1.norm.weight"]))) return rc;
     const auto& beta = H[p + ".layer1.norm.bias"];
@@ -214,6 +220,12 @@ static int trunk_pass(dmp_ctx* c, const float* z0, const float* dmap, int L, flo
   float* cur = c->xa;
   float* oth = c->xb;
   if ((rc = stem_update_padded(c, z0, dmap, L, cur, s))) return rc;
+  if (c->conv_mode == 0) {
+    // bf16 pieces of the stem output; every block's norm kernel then emits the pieces of its output
+    if ((rc = act_split(cur, L, c->xsplit, s))) return rc;
+    c->xsplit_current = true;
+  }
+  struct Reset { dmp_ctx* c; ~Reset() { c->xsplit_current = false; } } reset{c};
   for (int k = 1; k <= NBLOCK; ++k) {
     if (c->lane && c->lane->last) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->lane->last, 0));
     if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
@@ -299,6 +311,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(xa, (int64_t)CW * P * P);
   A_(xb, (int64_t)CW * P * P);
   A_(xdense, (int64_t)CW * LL);
+  A_(xsplit, (int64_t)3 * CW * P * P);
   A_(part, std::max<int64_t>(T * T, 8) * CW * 2);
   A_(stats, CW * 2);
   A_(ab, CW * 2);
@@ -320,6 +333,14 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   if (hipMemset(c->seq_abort, 0, sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
   *out = c;
   return DMP_OK;
+}
+
+int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
+  DMP_ARG(ctx && name, "null argument");
+  const std::string k(name);
+  if (k == "conv_f32_exact") { ctx->conv_mode = value ? 1 : 0; return DMP_OK; }
+  set_error("unknown option %s", name);
+  return DMP_ERR_ARG;
 }
 
 int dmp_sync_check(dmp_ctx* ctx, void* stream) {
@@ -690,10 +711,12 @@ int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, voi
   DMP_HIP(hipEventCreate(&e1));
   int rc = conv5x5_maxout_padded(ctx, block, ctx->xa, L, ctx->u, ctx->stats, STREAM, false);  // warm
   if (rc) return rc;
+  ctx->xsplit_current = true;      // time the convolution alone: the warm call split the input
   DMP_HIP(hipEventRecord(e0, STREAM));
   for (int i = 0; i < iters; ++i)
     if ((rc = conv5x5_maxout_padded(ctx, block, ctx->xa, L, ctx->u, ctx->stats, STREAM, false))) return rc;
   DMP_HIP(hipEventRecord(e1, STREAM));
+  ctx->xsplit_current = false;
   DMP_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
   DMP_HIP(hipEventElapsedTime(&ms, e0, e1));

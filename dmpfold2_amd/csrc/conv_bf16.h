@@ -71,7 +71,7 @@ inline std::vector<uint16_t> pack_conv_weights_bf16(const float* w) {
   return q;
 }
 
-#ifdef __HIPCC__
+#if defined(__HIPCC__) && defined(CONV_BF16_KERNELS)   // kernels: only the unit that launches them
 // LDS-DMA of 16 bytes per lane; destination = wave-uniform LDS byte address + lane*16.  Issued
 // through inline asm so that hipcc does not serialise later LDS reads behind it; completion is
 // waited for with cq_wait_vm<N>().
@@ -239,6 +239,6 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
     }
   }
 }
-#endif  // __HIPCC__
+#endif  // __HIPCC__ && CONV_BF16_KERNELS
 
 }  // namespace dmp

@@ -5,6 +5,8 @@
 // interior at [2, 2+L): the 5x5 halo reads need no bounds checks and the conv tiles of
 // 16x16 pixels never straddle the border logic.  The pre-norm maxout output `u` is dense.
 #include "common.h"
+#define CONV_BF16_KERNELS
+#include "conv_bf16.h"
 
 // Element-wise stages mirror separately rounded float32 tensor ops of the reference; fused
 // multiply-adds are written explicitly (fmaf) where they are wanted.
@@ -535,12 +537,61 @@ int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s) {
   return DMP_OK;
 }
 
+// float32 padded planes [128][P][P] -> exact 3-way bf16 split [3][16][P][P][8] (borders stay 0)
+__global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ xpad, int P,
+                                                        uint16_t* __restrict__ xs) {
+  const int y = blockIdx.y, cgp = blockIdx.z;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= P) return;
+  const int64_t PP = (int64_t)P * P;
+  uint16_t pc[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    uint16_t p3[3];
+    split3_bf16(xpad[(int64_t)(cgp * 8 + e) * PP + (int64_t)y * P + x], p3);
+    pc[0][e] = p3[0]; pc[1][e] = p3[1]; pc[2][e] = p3[2];
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    uint4 v;
+    v.x = pc[p][0] | ((uint32_t)pc[p][1] << 16);
+    v.y = pc[p][2] | ((uint32_t)pc[p][3] << 16);
+    v.z = pc[p][4] | ((uint32_t)pc[p][5] << 16);
+    v.w = pc[p][6] | ((uint32_t)pc[p][7] << 16);
+    reinterpret_cast<uint4*>(xs)[((int64_t)(p * 16 + cgp) * P + y) * P + x] = v;
+  }
+}
+
+int act_split(const float* d_xpad, int L, uint16_t* d_xs, hipStream_t s) {
+  const int P = act_pitch(L);
+  hipLaunchKernelGGL(act_split_kernel, dim3(cdiv(P, 256), P, 16), dim3(256), 0, s, d_xpad, P, d_xs);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
 int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
                           double* d_stats, hipStream_t s, bool reduce) {
   const BlockW& B = c->W.blk[block - 1];
   const int tiles = act_tiles(L), P = act_pitch(L);
   const int nwork = tiles * tiles * CONV_SPLIT;
   const int grid = round_up(nwork, 8);
+  if (c->conv_mode == 0) {
+    // float32 semantics on the bf16 matrix cores (conv_bf16.h)
+    static bool attr_set = false;
+    if (!attr_set) {
+      DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CONVQ_LDS_BYTES));
+      attr_set = true;
+    }
+    if (!c->xsplit_current) {
+      int rc = act_split(d_xpad, L, c->xsplit, s);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(grid), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
+                       B.bias, L, P, tiles, nwork, d_u, c->part);
+    DMP_LAUNCH_CHECK();
+    return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
+  }
   hipLaunchKernelGGL(conv5x5_maxout_kernel<CONV_VARIANT>, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
                      P, tiles, nwork, d_u, c->part);
   DMP_LAUNCH_CHECK();
@@ -555,7 +606,7 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
 __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     const float* __restrict__ u, const float* __restrict__ ab, const float* __restrict__ cse,
     const float* __restrict__ sse_w, float sse_b, const float* __restrict__ xin, int L, int P,
-    float* __restrict__ xout) {
+    float* __restrict__ xout, uint16_t* __restrict__ xs) {
   __shared__ float sh_a[CW], sh_b[CW], sh_g[CW], sh_w[CW];
   if (threadIdx.x < CW) {
     sh_a[threadIdx.x] = ab[threadIdx.x * 2];
@@ -578,9 +629,30 @@ __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
   }
   const float sg = sigmoid_f(dot + sse_b);
 #pragma unroll
-  for (int c = 0; c < CW; ++c) {
-    const float t = yv[c] * sh_g[c] + yv[c] * sg;      // contraction is off for this file
-    xout[c * PP + pp] = t + xin[c * PP + pp];
+  for (int cgp = 0; cgp < CW / 8; ++cgp) {
+    uint16_t pc[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cgp * 8 + e;
+      const float t = yv[c] * sh_g[c] + yv[c] * sg;      // contraction is off for this file
+      const float o = t + xin[c * PP + pp];
+      xout[c * PP + pp] = o;
+      uint16_t p3[3];
+      split3_bf16(o, p3);
+      pc[0][e] = p3[0]; pc[1][e] = p3[1]; pc[2][e] = p3[2];
+    }
+    if (xs != nullptr) {
+      // exact 3-way bf16 split of the new activations, in the layout the bf16x6 convolution reads
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        uint4 v;
+        v.x = pc[p][0] | ((uint32_t)pc[p][1] << 16);
+        v.y = pc[p][2] | ((uint32_t)pc[p][3] << 16);
+        v.z = pc[p][4] | ((uint32_t)pc[p][5] << 16);
+        v.w = pc[p][6] | ((uint32_t)pc[p][7] << 16);
+        reinterpret_cast<uint4*>(xs)[(int64_t)(p * 16 + cgp) * PP + pp] = v;
+      }
+    }
   }
 }
 
@@ -591,8 +663,10 @@ int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const dou
   hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, d_stats, (double)L * (double)L,
                      B.gamma, B.beta, c->ab);
   DMP_LAUNCH_CHECK();
+  // inside a trunk pass the kernel also emits the bf16 pieces the next convolution reads
+  uint16_t* xs = (c->conv_mode == 0 && c->xsplit_current) ? c->xsplit : nullptr;
   hipLaunchKernelGGL(norm_scse_residual_kernel, dim3(cdiv(L, 256), L), dim3(256), 0, s, d_u, c->ab,
-                     B.cse, B.sse_w, B.sse_b, d_xpad_in, L, P, d_xpad_out);
+                     B.cse, B.sse_w, B.sse_b, d_xpad_in, L, P, d_xpad_out, xs);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

@@ -218,6 +218,10 @@ class Engine:
             self._keep = (d_msa, d_tpl)
         return coords, confs
 
+    def set_option(self, name, value):
+        """Additive engine options, e.g. ("conv_f32_exact", 1); see include/dmpfold_hip.h."""
+        _lib.check(self.lib.dmp_ctx_set_option(self._ctx, name.encode(), int(value)))
+
     def sync_check(self):
         """Wait for the queued work and raise if a device-side fault was recorded."""
         _lib.check(self.lib.dmp_sync_check(self._ctx, self.stream()))

@@ -51,6 +51,12 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
 /* bytes of device memory held by the context */
 int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
 
+/* Options (additive, default off).  "conv_f32_exact" = 1: run the 5x5 convolutions on the f32
+ * matrix-core instruction (bitwise an fmaf chain) instead of the default, which computes the same
+ * float32 products from exact 3-way bf16 splits on the bf16 matrix cores (6 partial products,
+ * float32 accumulation; same error as the f32 kernel, 1.9x faster). */
+int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value);
+
 /* ---- weights (the reference's state_dict ABI, network.py:182-215) ---------------------
  * dmp_weights_set: hand over one tensor of GRUResNet(512,128).state_dict() by key, host
  * float32, contiguous, with its shape (replaces load_state_dict, predict.py:98).

@@ -24,9 +24,18 @@ import dmpfold_oracle as O          # noqa: E402  (test infrastructure)
 
 
 @pytest.fixture(scope="module")
-def st(synth_sd):
+def st_engine(synth_sd):
     from abi import Stages
     return Stages(synth_sd, max_L=128, max_N=3000)
+
+
+@pytest.fixture(params=["bf16x6", "f32"])
+def st(request, st_engine):
+    """Every test runs twice: with the default convolution path (float32 products from exact 3-way
+    bf16 splits on the bf16 matrix cores) and with the exact-f32 MFMA path.  Same tolerances."""
+    st_engine.eng.set_option("conv_f32_exact", 1 if request.param == "f32" else 0)
+    yield st_engine
+    st_engine.eng.set_option("conv_f32_exact", 0)
 
 
 @pytest.fixture(scope="module")

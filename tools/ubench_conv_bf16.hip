@@ -4,6 +4,7 @@
 // (w0x0, w0x1, w1x0, w0x2, w1x1, w2x0 - the dropped ones are below 2^-24 relative), which
 // reproduces the float32 convolution to float32 rounding error at 16/6 = 2.67x the f32 MFMA rate.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_conv_bf16.hip -o tools/_bin/ubench_conv_bf16
+#define CONV_BF16_KERNELS
 #include "../dmpfold2_amd/csrc/conv_bf16.h"
 #include <cstdio>
 #include <cstdlib>
