@@ -91,6 +91,10 @@ __device__ __forceinline__ cq_f32x16 cq_mfma(uint4 a, uint4 b, cq_f32x16 c) {
 
 // grid: round_up(tiles*tiles*4, 8) blocks, XCD-aware map as the f32 kernel   block: 256
 // dynamic LDS: CONVQ_LDS_BYTES
+// Scheduling note: hand software-pipelining of the LDS fragment reads (one patch pair ahead, 2-tap
+// DMA distance, with and without sched_group_barrier) measured 5-9 % SLOWER than hipcc's own
+// schedule at 2 waves per SIMD; PMC: MFMA pipe 78 % busy while the clock sits at 1.74 GHz - the
+// kernel runs into the power limit, not into issue stalls.
 __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* __restrict__ xs,
                                                                 const uint16_t* __restrict__ wq,
                                                                 const float* __restrict__ bias, int L, int P,
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
   auto wdma = [&](int g, int tap, int slot) {
     const uint4* src = wq4 + ((int64_t)g * 25 + tap) * 4 * CQ_WSLOT;
     const unsigned dst = w_lds_addr + slot * (CQ_WSLOT * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier LDS reads of the slot are complete
     cq_dma16(src, dst);
     cq_dma16(src + 64, dst + 1024);
     cq_dma16(src + 128, dst + 2048);
