@@ -30,7 +30,7 @@ import torch         # noqa: E402
 
 L_NS, N_NS, ITERS, MINSTEPS = 300, 2000, 10, 100
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1 sparse figure)
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (not the 2:1 sparse figure)
 CONV_FLOP_PER_LAUNCH = 2.0 * 128 * 512 * 25 * L_NS * L_NS     # one block's 5x5 conv
 
 
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="targets in flight per GPU (one context + HIP stream each); a step is one "
                          "batch of this many targets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -198,19 +198,20 @@ def main():
                        "weights": "synthetic seed 0 (reference state_dict shapes)",
                        "parallelism": f"replicas x{world}, no collective on the data path; "
                                       f"{S} HIP streams per GPU"},
-            # The convolution computes float32 products from exact 3-way bf16 splits: 6 bf16 MFMA
-            # products per float32 product, so the matrix-core ceiling for the ALGORITHMIC (float32)
-            # FLOPs is the dense bf16 peak / 6.  The exact-f32 MFMA path (option conv_f32_exact) is
-            # bounded by PEAK_F32_MFMA_TFLOPS instead and measures 130 TFLOP/s (profiles/).
-            "roofline": {"kernel": "conv5x5_bf16x6_kernel (5x5 conv 128->512 + bias + 4-way maxout, "
-                                   "f32 semantics via 6 bf16 MFMA products)",
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / 6.0,
-                         "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+            # The convolution forms each float32 product from 2-way f16 splits of its operands: 3 f16
+            # MFMA products per float32 product, so the matrix-core ceiling for the ALGORITHMIC
+            # (float32) FLOPs is the dense f16 peak / 3.  The exact-f32 MFMA path (option
+            # conv_f32_exact) is bounded by PEAK_F32_MFMA_TFLOPS and measures 130 TFLOP/s, the 3-way
+            # bf16 split (conv_mode 2) 235 TFLOP/s (profiles/).
+            "roofline": {"kernel": "conv5x5_f16x3_kernel (5x5 conv 128->512 + bias + 4-way maxout, "
+                                   "float32 products from 3 f16 MFMA products, float32 accumulate)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
+                         "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA_TFLOPS / 3.0),
                          "traffic": traffic, "launches_timed": conv_cnt,
                          "avg_launch_ms": conv_ms,
                          "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH,
-                         "executed_bf16_tflops": 6.0 * achieved,
-                         "peak_bf16_mfma_tflops": PEAK_BF16_MFMA_TFLOPS,
+                         "executed_f16_tflops": 3.0 * achieved,
+                         "peak_f16_mfma_tflops": PEAK_F16_MFMA_TFLOPS,
                          "peak_f32_mfma_tflops": PEAK_F32_MFMA_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:

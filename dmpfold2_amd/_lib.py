@@ -21,6 +21,7 @@ SIGNATURES = {
     "dmp_ctx_destroy": (None, [_vp]),
     "dmp_ctx_device_bytes": (_i64, [_vp]),
     "dmp_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "dmp_clear_faults": (_i, [_vp, _vp]),
     "dmp_weights_set": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
     "dmp_weights_finalize": (_i, [_vp]),
     "dmp_msa_encode": (_i, [_vp, _i64, _vp]),

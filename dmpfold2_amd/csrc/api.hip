@@ -2,6 +2,7 @@
 // management, host-side residue encoding, stage-level entry points and the fused dmp_predict.
 #include "common.h"
 #include "conv_bf16.h"
+#include "conv_f16.h"
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -172,6 +173,11 @@ static int pack_weights(dmp_ctx* c) {
       const std::vector<uint16_t> q = pack_conv_weights_bf16(w.data());
       if ((rc = dev_alloc(pool, bytes, &B.wq, (int64_t)q.size()))) return rc;
       DMP_HIP(hipMemcpy(B.wq, q.data(), sizeof(uint16_t) * q.size(), hipMemcpyHostToDevice));
+      const float scale = conv_weight_scale_f16(w.data(), w.size());
+      const std::vector<uint16_t> h = pack_conv_weights_f16(w.data(), scale);
+      if ((rc = dev_alloc(pool, bytes, &B.wh, (int64_t)h.size()))) return rc;
+      DMP_HIP(hipMemcpy(B.wh, h.data(), sizeof(uint16_t) * h.size(), hipMemcpyHostToDevice));
+      B.wh_inv_scale = 1.0f / scale;
     }
     if ((rc = upload(pool, bytes, &B.bias, H[p + ".layer1.lin.bias"]))) return rc;
     if ((rc = upload(pool, bytes, &B.gamma, H[p + ".layer1.norm.weight"]))) return rc;
@@ -220,9 +226,9 @@ static int trunk_pass(dmp_ctx* c, const float* z0, const float* dmap, int L, flo
   float* cur = c->xa;
   float* oth = c->xb;
   if ((rc = stem_update_padded(c, z0, dmap, L, cur, s))) return rc;
-  if (c->conv_mode == 0) {
-    // bf16 pieces of the stem output; every block's norm kernel then emits the pieces of its output
-    if ((rc = act_split(cur, L, c->xsplit, s))) return rc;
+  if (c->conv_mode != 1) {
+    // f16 / bf16 pieces of the stem output; every block's norm kernel then emits those of its output
+    if ((rc = act_split(c, cur, L, s))) return rc;
     c->xsplit_current = true;
   }
   struct Reset { dmp_ctx* c; ~Reset() { c->xsplit_current = false; } } reset{c};
@@ -335,10 +341,21 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   return DMP_OK;
 }
 
+int dmp_clear_faults(dmp_ctx* ctx, void* stream) {
+  DMP_ARG(ctx != nullptr, "null context");
+  DMP_HIP(hipMemsetAsync(ctx->seq_abort, 0, sizeof(int), (hipStream_t)stream));
+  return DMP_OK;
+}
+
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   DMP_ARG(ctx && name, "null argument");
   const std::string k(name);
   if (k == "conv_f32_exact") { ctx->conv_mode = value ? 1 : 0; return DMP_OK; }
+  if (k == "conv_mode") {
+    DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
+    ctx->conv_mode = value;
+    return DMP_OK;
+  }
   set_error("unknown option %s", name);
   return DMP_ERR_ARG;
 }
@@ -349,7 +366,10 @@ int dmp_sync_check(dmp_ctx* ctx, void* stream) {
   int flag = 0;
   DMP_HIP(hipMemcpy(&flag, ctx->seq_abort, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) {
-    set_error("sequence-GRU workgroup hand-off timed out (results invalid)");
+    set_error("device-side fault (results invalid):%s%s",
+              (flag & 1) ? " sequence-GRU workgroup hand-off timed out;" : "",
+              (flag & 2) ? " an activation left the f16 range of the split-product convolution "
+                           "(use option conv_f32_exact or conv_mode=2);" : "");
     return DMP_ERR_HIP;
   }
   return DMP_OK;

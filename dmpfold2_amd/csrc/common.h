@@ -58,6 +58,8 @@ struct GruDirW {          // one direction of one layer of a sequence GRU
 struct BlockW {
   float* wpack = nullptr;  // [split 4][chunk 64][tap 25][cc 2][m 128]   (exact-f32 kernel)
   uint16_t* wq = nullptr;  // bf16 pieces, layout in conv_bf16.h          (bf16x6 kernel)
+  uint16_t* wh = nullptr;  // f16 pieces of scale*w, layout in conv_f16.h (f16x3 kernel)
+  float wh_inv_scale = 1.f;
   float* bias = nullptr;   // [512]
   float* gamma = nullptr;  // [128]
   float* beta = nullptr;   // [128]
@@ -138,7 +140,7 @@ struct dmp_ctx {
   float* xb = nullptr;
   float* xdense = nullptr;  // [128][L][L] scratch for the stage-level API
   uint16_t* xsplit = nullptr;  // [3][16][P][P][8] bf16 pieces of the current activations
-  int conv_mode = 0;           // 0: bf16x6 matrix-core path (f32 semantics), 1: exact f32 MFMA
+  int conv_mode = 0;           // 0: f16x3 split products (default), 1: exact f32 MFMA, 2: bf16x6 split
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
@@ -204,7 +206,7 @@ int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, floa
 int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);
 int act_unpad(const float* d_xpad, int L, float* d_dense, hipStream_t s);
 int act_clear(float* d_xpad, int L, hipStream_t s);
-int act_split(const float* d_xpad, int L, uint16_t* d_xs, hipStream_t s);
+int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s);
 // mds.hip
 int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s);
 // coords.hip

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
         __builtin_amdgcn_s_sleep(1);
       }
       if (dead) {
-        if (lane == 0) { sh_abort = 1; atomicExch(a.abort_flag, 1); }
+        if (lane == 0) { sh_abort = 1; atomicOr(a.abort_flag, 1); }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) h[lane + 64 * q] = __uint_as_float(vals[q]);

@@ -7,6 +7,8 @@
 #include "common.h"
 #define CONV_BF16_KERNELS
 #include "conv_bf16.h"
+#define CONV_F16_KERNELS
+#include "conv_f16.h"
 
 // Element-wise stages mirror separately rounded float32 tensor ops of the reference; fused
 // multiply-adds are written explicitly (fmaf) where they are wanted.
@@ -17,6 +19,40 @@ namespace dmp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Eight consecutive channels of one pixel -> the 16-byte operands of the split-product
+// convolutions.  MODE 0: two f16 pieces (conv_f16.h), MODE 2: three bf16 pieces (conv_bf16.h).
+// `slot` is the uint4 index inside one piece plane set, `piece_stride` the uint4 count per piece.
+template <int MODE>
+__device__ __forceinline__ void store_pieces(const float (&o)[8], uint16_t* __restrict__ xs, int64_t slot,
+                                             int64_t piece_stride, int* __restrict__ fault) {
+  constexpr int NP = (MODE == 0) ? 2 : 3;
+  uint16_t pc[NP][8];
+  bool bad = false;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if constexpr (MODE == 0) {
+      uint16_t p2[2];
+      split2_f16(o[e], p2);
+      pc[0][e] = p2[0]; pc[1][e] = p2[1];
+      bad = bad || !(fabsf(o[e]) < 60000.f);          // f16 range (also catches NaN)
+    } else {
+      uint16_t p3[3];
+      split3_bf16(o[e], p3);
+      pc[0][e] = p3[0]; pc[1][e] = p3[1]; pc[2][e] = p3[2];
+    }
+  }
+  if (bad) atomicOr(fault, 2);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    uint4 v;
+    v.x = pc[p][0] | ((uint32_t)pc[p][1] << 16);
+    v.y = pc[p][2] | ((uint32_t)pc[p][3] << 16);
+    v.z = pc[p][4] | ((uint32_t)pc[p][5] << 16);
+    v.w = pc[p][6] | ((uint32_t)pc[p][7] << 16);
+    reinterpret_cast<uint4*>(xs)[p * piece_stride + slot] = v;
+  }
+}
 
 // ---------------------------------------------------------------------------------------
 // layout helpers
@@ -537,34 +573,28 @@ int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s) {
   return DMP_OK;
 }
 
-// float32 padded planes [128][P][P] -> exact 3-way bf16 split [3][16][P][P][8] (borders stay 0)
+// float32 planes [128][P][P] -> the piece planes [pieces][16][P][P][8] the split-product
+// convolutions read (MODE 0: two f16 pieces, MODE 2: three bf16 pieces); borders stay 0.
+template <int MODE>
 __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ xpad, int P,
-                                                        uint16_t* __restrict__ xs) {
+                                                        uint16_t* __restrict__ xs, int* __restrict__ fault) {
   const int y = blockIdx.y, cgp = blockIdx.z;
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x >= P) return;
   const int64_t PP = (int64_t)P * P;
-  uint16_t pc[3][8];
+  float o[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    uint16_t p3[3];
-    split3_bf16(xpad[(int64_t)(cgp * 8 + e) * PP + (int64_t)y * P + x], p3);
-    pc[0][e] = p3[0]; pc[1][e] = p3[1]; pc[2][e] = p3[2];
-  }
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    uint4 v;
-    v.x = pc[p][0] | ((uint32_t)pc[p][1] << 16);
-    v.y = pc[p][2] | ((uint32_t)pc[p][3] << 16);
-    v.z = pc[p][4] | ((uint32_t)pc[p][5] << 16);
-    v.w = pc[p][6] | ((uint32_t)pc[p][7] << 16);
-    reinterpret_cast<uint4*>(xs)[((int64_t)(p * 16 + cgp) * P + y) * P + x] = v;
-  }
+  for (int e = 0; e < 8; ++e) o[e] = xpad[(int64_t)(cgp * 8 + e) * PP + (int64_t)y * P + x];
+  store_pieces<MODE>(o, xs, (int64_t)cgp * PP + (int64_t)y * P + x, 16 * PP, fault);
 }
 
-int act_split(const float* d_xpad, int L, uint16_t* d_xs, hipStream_t s) {
+int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s) {
   const int P = act_pitch(L);
-  hipLaunchKernelGGL(act_split_kernel, dim3(cdiv(P, 256), P, 16), dim3(256), 0, s, d_xpad, P, d_xs);
+  dim3 grid(cdiv(P, 256), P, 16);
+  if (c->conv_mode == 2)
+    hipLaunchKernelGGL(act_split_kernel<2>, grid, dim3(256), 0, s, d_xpad, P, c->xsplit, c->seq_abort);
+  else
+    hipLaunchKernelGGL(act_split_kernel<0>, grid, dim3(256), 0, s, d_xpad, P, c->xsplit, c->seq_abort);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
@@ -575,20 +605,26 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
   const int tiles = act_tiles(L), P = act_pitch(L);
   const int nwork = tiles * tiles * CONV_SPLIT;
   const int grid = round_up(nwork, 8);
-  if (c->conv_mode == 0) {
-    // float32 semantics on the bf16 matrix cores (conv_bf16.h)
+  if (c->conv_mode != 1) {
+    // float32-grade products from f16 / bf16 pieces on the 16-bit matrix cores
     static bool attr_set = false;
     if (!attr_set) {
       DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CONVQ_LDS_BYTES));
+      DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CONVH_LDS_BYTES));
       attr_set = true;
     }
     if (!c->xsplit_current) {
-      int rc = act_split(d_xpad, L, c->xsplit, s);
+      int rc = act_split(c, d_xpad, L, s);
       if (rc) return rc;
     }
-    hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(grid), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
-                       B.bias, L, P, tiles, nwork, d_u, c->part);
+    if (c->conv_mode == 2)
+      hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(grid), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
+                         B.bias, L, P, tiles, nwork, d_u, c->part);
+    else
+      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(grid), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,
+                         B.bias, B.wh_inv_scale, L, P, tiles, nwork, d_u, c->part);
     DMP_LAUNCH_CHECK();
     return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
   }
@@ -603,10 +639,12 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
 //   y_c = u_c*alpha_c + beta'_c ;  s = sigmoid(sum_c ws_c y_c + bs)
 //   out_c = (y_c*cse_c + y_c*s) + x_c
 // ---------------------------------------------------------------------------------------
+// SPLIT: -1 = float32 output only, 0 / 2 = also write f16 / bf16 pieces (store_pieces)
+template <int SPLIT>
 __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     const float* __restrict__ u, const float* __restrict__ ab, const float* __restrict__ cse,
     const float* __restrict__ sse_w, float sse_b, const float* __restrict__ xin, int L, int P,
-    float* __restrict__ xout, uint16_t* __restrict__ xs) {
+    float* __restrict__ xout, uint16_t* __restrict__ xs, int* __restrict__ fault) {
   __shared__ float sh_a[CW], sh_b[CW], sh_g[CW], sh_w[CW];
   if (threadIdx.x < CW) {
     sh_a[threadIdx.x] = ab[threadIdx.x * 2];
@@ -630,29 +668,17 @@ __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
   const float sg = sigmoid_f(dot + sse_b);
 #pragma unroll
   for (int cgp = 0; cgp < CW / 8; ++cgp) {
-    uint16_t pc[3][8];
+    float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = cgp * 8 + e;
       const float t = yv[c] * sh_g[c] + yv[c] * sg;      // contraction is off for this file
-      const float o = t + xin[c * PP + pp];
-      xout[c * PP + pp] = o;
-      uint16_t p3[3];
-      split3_bf16(o, p3);
-      pc[0][e] = p3[0]; pc[1][e] = p3[1]; pc[2][e] = p3[2];
+      o[e] = t + xin[c * PP + pp];
+      xout[c * PP + pp] = o[e];
     }
-    if (xs != nullptr) {
-      // exact 3-way bf16 split of the new activations, in the layout the bf16x6 convolution reads
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        uint4 v;
-        v.x = pc[p][0] | ((uint32_t)pc[p][1] << 16);
-        v.y = pc[p][2] | ((uint32_t)pc[p][3] << 16);
-        v.z = pc[p][4] | ((uint32_t)pc[p][5] << 16);
-        v.w = pc[p][6] | ((uint32_t)pc[p][7] << 16);
-        reinterpret_cast<uint4*>(xs)[(int64_t)(p * 16 + cgp) * PP + pp] = v;
-      }
-    }
+    // inside a trunk pass: also emit the pieces the next block's split-product convolution reads
+    if constexpr (SPLIT == 0) store_pieces<0>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault);
+    if constexpr (SPLIT == 2) store_pieces<2>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault);
   }
 }
 
@@ -663,10 +689,16 @@ int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const dou
   hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, d_stats, (double)L * (double)L,
                      B.gamma, B.beta, c->ab);
   DMP_LAUNCH_CHECK();
-  // inside a trunk pass the kernel also emits the bf16 pieces the next convolution reads
-  uint16_t* xs = (c->conv_mode == 0 && c->xsplit_current) ? c->xsplit : nullptr;
-  hipLaunchKernelGGL(norm_scse_residual_kernel, dim3(cdiv(L, 256), L), dim3(256), 0, s, d_u, c->ab,
-                     B.cse, B.sse_w, B.sse_b, d_xpad_in, L, P, d_xpad_out, xs);
+  // inside a trunk pass the kernel also emits the pieces the next convolution reads
+  const int split = (c->conv_mode != 1 && c->xsplit_current) ? c->conv_mode : -1;
+  dim3 grid(cdiv(L, 256), L);
+#define NORM_LAUNCH(S)                                                                              \
+  hipLaunchKernelGGL(norm_scse_residual_kernel<S>, grid, dim3(256), 0, s, d_u, c->ab, B.cse, B.sse_w, \
+                     B.sse_b, d_xpad_in, L, P, d_xpad_out, c->xsplit, c->seq_abort)
+  if (split == 0) NORM_LAUNCH(0);
+  else if (split == 2) NORM_LAUNCH(2);
+  else NORM_LAUNCH(-1);
+#undef NORM_LAUNCH
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

@@ -51,11 +51,17 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
 /* bytes of device memory held by the context */
 int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
 
-/* Options (additive, default off).  "conv_f32_exact" = 1: run the 5x5 convolutions on the f32
- * matrix-core instruction (bitwise an fmaf chain) instead of the default, which computes the same
- * float32 products from exact 3-way bf16 splits on the bf16 matrix cores (6 partial products,
- * float32 accumulation; same error as the f32 kernel, 1.9x faster). */
+/* Options (additive).  "conv_mode" selects how the 5x5 convolutions form their float32 products:
+ *   0 (default)  each float32 operand split into two f16 pieces, 3 f16 MFMA products, float32
+ *                accumulation - same error against float64 as a float32 convolution, 5.3x the
+ *                f32 matrix-core rate; activations must stay inside the f16 range (|x| < 6e4,
+ *                checked on the device, reported by dmp_sync_check);
+ *   1            the f32 matrix-core instruction (bitwise an fmaf chain);
+ *   2            exact 3-way bf16 split, 6 bf16 MFMA products (no range limit, 2.7x the f32 rate).
+ * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default). */
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value);
+/* Reset the device-side fault word read by dmp_sync_check (enqueued on `stream`). */
+int dmp_clear_faults(dmp_ctx* ctx, void* stream);
 
 /* ---- weights (the reference's state_dict ABI, network.py:182-215) ---------------------
  * dmp_weights_set: hand over one tensor of GRUResNet(512,128).state_dict() by key, host
