@@ -33,8 +33,15 @@ constexpr int CH_HALO = 20, CH_PITCH = 24;
 constexpr int CH_IN_SLOTS = 2 * 2 * CH_HALO * CH_PITCH;               // 1920 16-byte slots
 constexpr int CH_IN_BYTES = CH_IN_SLOTS * 16;                         // 30720
 constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slots per wave and tap
-constexpr int CH_RING = 4;
-constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_RING * CH_WSLOT * 16;   // 63488
+#ifndef CH_RING_SLOTS
+#define CH_RING_SLOTS 4      // per-wave weight ring: 4 slots = DMA two taps ahead, 2 slots = one tap
+#endif
+#ifndef CH_OCC
+#define CH_OCC 2             // workgroups per CU the register budget is compiled for
+#endif
+constexpr int CH_RING = CH_RING_SLOTS;
+constexpr int CH_DIST = CH_RING >= 4 ? 2 : 1;
+constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_RING * CH_WSLOT * 16;   // 63488 (ring 4) / 47104 (ring 2)
 
 __host__ __device__ inline uint16_t ch_f16_bits(float f) {
   const _Float16 h = (_Float16)f;                                     // round to nearest even
@@ -93,7 +100,7 @@ __device__ __forceinline__ ch_f32x16 ch_mfma(uint4 a, uint4 b, ch_f32x16 c) {
 }
 
 // grid: round_up(tiles*tiles*4, 8) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
-__global__ __launch_bounds__(256, 2) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
+__global__ __launch_bounds__(256, CH_OCC) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
                                                                const uint16_t* __restrict__ wq,
                                                                const float* __restrict__ bias, float inv_scale,
                                                                int L, int P, int tiles, int nwork,
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_f16x3_kernel(const uint16_t* _
       if (wave < 2) ch_dma16(src + in_src[7], dst + 7 * 4096);
     }
     wdma(g, 0);
-    wdma(g, 1);
+    if (CH_DIST == 2) wdma(g, 1);
     ch_wait_vm<0>();
     __syncthreads();                                   // the tile of every wave has landed
 #pragma unroll 1
@@ -173,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5_f16x3_kernel(const uint16_t* _
       for (int dx = 0; dx < 5; ++dx) {
         const int tap = dy * 5 + dx;
         // weights two taps ahead; this tap's two pieces must have landed (2 instructions per tap)
-        if (tap + 2 < 25) { wdma(g, tap + 2); ch_wait_vm<4>(); }
-        else if (tap + 1 < 25) ch_wait_vm<2>();
+        if (tap + CH_DIST < 25) { wdma(g, tap + CH_DIST); ch_wait_vm<2 * CH_DIST>(); }
+        else if (CH_DIST == 2 && tap + 1 < 25) ch_wait_vm<2>();
         else ch_wait_vm<0>();
         const uint4* wl = w_l + (tap & (CH_RING - 1)) * CH_WSLOT + a_off;
         const uint4 a0 = wl[0], a1 = wl[64];
