@@ -99,18 +99,33 @@ static int pack_weights(dmp_ctx* c) {
   auto& pool = W.allocs;
   int rc;
   // vertical GRU
-  auto gate4 = [](const std::vector<float>& w, int K, int Kpad) {
-    // w is [3*512][K] (rows r | z | n); returns [Kpad][512][4] = {r, z, n, 0}
-    std::vector<float> p((size_t)Kpad * 512 * 4, 0.f);
-    for (int k = 0; k < K; ++k)
+  auto pieces = [&](const std::vector<float>& w, int K, int Kpad, float scale, uint16_t** out) -> int {
+    // w is [3*512][K] (rows r | z | n); packed [piece 2][gate 3][Kpad/8][512][8] f16 pieces of scale*w
+    const int KQ = Kpad / 8;
+    std::vector<uint16_t> q((size_t)2 * 3 * KQ * 512 * 8, 0);
+    for (int g = 0; g < 3; ++g)
       for (int j = 0; j < 512; ++j)
-        for (int g = 0; g < 3; ++g) p[((size_t)k * 512 + j) * 4 + g] = w[((size_t)g * 512 + j) * K + k];
-    return p;
+        for (int k = 0; k < K; ++k) {
+          uint16_t p2[2];
+          split2_f16(scale * w[((size_t)g * 512 + j) * K + k], p2);
+          for (int p = 0; p < 2; ++p)
+            q[((((size_t)p * 3 + g) * KQ + k / 8) * 512 + j) * 8 + k % 8] = p2[p];
+        }
+    int r = dev_alloc(pool, bytes, out, (int64_t)q.size());
+    if (r) return r;
+    DMP_HIP(hipMemcpy(*out, q.data(), sizeof(uint16_t) * q.size(), hipMemcpyHostToDevice));
+    return DMP_OK;
   };
-  if ((rc = upload(pool, bytes, &W.v_wx[0], gate4(H["vgru.weight_ih_l0"], 22, 24)))) return rc;
-  if ((rc = upload(pool, bytes, &W.v_wh[0], gate4(H["vgru.weight_hh_l0"], 512, 512)))) return rc;
-  if ((rc = upload(pool, bytes, &W.v_wx[1], gate4(H["vgru.weight_ih_l1"], 512, 512)))) return rc;
-  if ((rc = upload(pool, bytes, &W.v_wh[1], gate4(H["vgru.weight_hh_l1"], 512, 512)))) return rc;
+  for (int l = 0; l < 2; ++l) {
+    const auto& wi = H["vgru.weight_ih_l" + std::to_string(l)];
+    const auto& wh = H["vgru.weight_hh_l" + std::to_string(l)];
+    // one power-of-two scale per layer: the input and the recurrent products share accumulators
+    const float scale = std::fmin(conv_weight_scale_f16(wi.data(), wi.size()),
+                                  conv_weight_scale_f16(wh.data(), wh.size()));
+    W.v_inv_scale[l] = 1.0f / (scale * VGRU_STATE_SCALE);
+    if ((rc = pieces(wi, l == 0 ? 22 : 512, l == 0 ? 32 : 512, scale, &W.v_wx[l]))) return rc;
+    if ((rc = pieces(wh, 512, 512, scale, &W.v_wh[l]))) return rc;
+  }
   for (int l = 0; l < 2; ++l) {
     const auto& bi = H["vgru.bias_ih_l" + std::to_string(l)];
     const auto& bh = H["vgru.bias_hh_l" + std::to_string(l)];
@@ -302,7 +317,10 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(x3, LL);
   A_(apc_sums, 2 * L + 1);
   for (int l = 0; l < 2; ++l)
-    for (int p = 0; p < 2; ++p) A_(hT[l][p], (int64_t)WIDTH * Lb);
+    for (int p = 0; p < 2; ++p) {
+      A_(hT[l][p], (int64_t)WIDTH * Lb);
+      A_(hH[l][p], (int64_t)2 * WIDTH * Lb);
+    }
   A_(vout, L * WIDTH);
   A_(seq_g, L * 1536);
   A_(seq_a, L * WIDTH);

@@ -12,6 +12,7 @@ namespace dmp {
 
 constexpr int WIDTH = 512;     // GRU width
 constexpr int HID2 = 256;      // bidirectional GRU hidden per direction
+constexpr float VGRU_STATE_SCALE = 1024.f;   // vertical-GRU state is split into f16 pieces of 1024*h
 constexpr int CW = 128;        // pair trunk width
 constexpr int NBLOCK = 16;
 constexpr int STEM_OUT = 384;  // 128 * pool 3
@@ -72,9 +73,10 @@ struct Weights {
   bool ready = false;
   std::map<std::string, std::vector<float>> host;          // raw tensors by key
   std::map<std::string, std::vector<int64_t>> shapes;
-  // vertical GRU, gate-interleaved [k][512][4] = {W_r[j,k], W_z[j,k], W_n[j,k], 0}
-  float* v_wx[2] = {nullptr, nullptr};   // input weights (layer 0: K = 22 padded to 24)
-  float* v_wh[2] = {nullptr, nullptr};   // hidden weights
+  // vertical GRU: f16 pieces of scale*W, [piece 2][gate 3][k/8][512][8] (see vgru.hip)
+  uint16_t* v_wx[2] = {nullptr, nullptr};  // input weights (layer 0: K = 22 padded to 32)
+  uint16_t* v_wh[2] = {nullptr, nullptr};  // hidden weights
+  float v_inv_scale[2] = {1.f, 1.f};       // 1 / (weight scale * state scale) per layer
   float *v_b0 = nullptr, *v_b1 = nullptr;  // [4][512]: r(bi+bh), z(bi+bh), in(bi), hn(bh)
   GruDirW hgru[2][2];                      // [layer][dir]
   GruDirW cgru[3][2];
@@ -123,7 +125,8 @@ struct dmp_ctx {
   float* x3 = nullptr;
   double* apc_sums = nullptr;  // [2L+1]
   // sequence trunk
-  float* hT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [layer][parity][512][Lb]
+  float* hT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [layer][parity][128][Lb][4] float32 state
+  uint16_t* hH[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // same state as f16 pieces [2][64][Lb][8]
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions
   float* seq_a = nullptr;   // [L][512]

@@ -2,22 +2,25 @@
 // time axis = N sequences, batch = L columns, hidden 512).
 //
 // One launch per time step computes layer 0 at step t and layer 1 at step t-1 (both read the same
-// h0 state) as f32-MFMA GEMMs  gates^T[j, b] = sum_k W[j, k] * x[k, b]  with the hidden index j
-// on the MFMA M axis and the alignment column b on the N axis.
+// h0 state) as GEMMs  gates^T[j, b] = sum_k W[j, k] * x[k, b]  with the hidden index j on the MFMA M
+// axis and the alignment column b on the N axis.
 //
-// Layouts are chosen so one 16-byte load feeds several MFMAs (4-byte operand loads made the
-// first version VMEM-issue bound: 10 us of load issue next to 12 us of MFMA per step, measured
-// with tools/ubench_vgru.hip):
-//   weights  Wp[k][j][4]   = {W_r[j,k], W_z[j,k], W_n[j,k], 0}  - one load = the A operands of the
-//                             three gate MFMAs of a k;
-//   state    hP[k/4][b][4] = h[4(k/4) .. +3, b]                  - one load = the B operands of four
-//                             k steps, and the epilogue stores four consecutive j per lane.
-// An MFMA 32x32x2 consumes a k pair (lane half kk = 0/1); pairs are formed as (8o+e, 8o+4+e),
-// e = 0..3, inside a "k octet" o, which is what the two layouts deliver to the two lane halves.
+// Arithmetic: float32-grade products on the f16 matrix cores, the same scheme as conv_f16.h.  Every
+// operand is the sum of two f16 pieces (weights: S*w = w0 + w1 with a power-of-two S per layer;
+// state: 1024*h = h0 + h1, |h| < 1); v_mfma_f32_32x32x16_f16 accumulates w0 h1 + w1 h0 + w0 h0 in
+// float32 and the sums are scaled back by 1/(1024 S) (exact).  The dropped w1 h1 term is 2^-22 of a
+// product.  The one-hot layer-0 input is the exact f16 value 1024 (low piece 0: two products).
+// The previous version of this kernel ran the exact-f32 MFMA (32x32x2): 17.6 us of matrix-core time
+// per step against 3.3 us here.
+//
+// Layouts (one 16-byte load = one MFMA operand):
+//   weights  Wq[piece 2][gate 3][k/8][512 j][8]  f16     A operand of (gate, piece) for 8 k
+//   state    hH[piece 2][k/8 = 64][Lb][8]        f16     B operand;  written by the epilogue
+//            hP[j/4 = 128][Lb][4]                f32     the state itself, for h' = (h - n) z + n
 //
 // Workgroup = 8 waves on one (32 hidden x 32 column) tile: waves 0-3 split K of the recurrent
 // product W_hh h, waves 4-7 split K of the input product (layer 1: W_ih h0; layer 0: the one-hot
-// input generated in registers, K = 22 -> 24, wave 4 only).  The K slices are summed through LDS
+// input generated in registers, K = 22 -> 32, wave 4 only).  The K slices are summed through LDS
 // and waves 0-3 apply the gate maths (ATen gru_cell: h' = (h - n) z + n).
 // Block b runs on XCD b % 8; XCD x owns hidden tiles 2x, 2x+1 of both layers, so the weights it
 // streams every step (1.6 MB) stay in its 4 MB L2.
@@ -26,52 +29,69 @@
 namespace dmp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 vg_f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float vsigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+__device__ __forceinline__ f32x16 vg_mfma(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vg_f16x8, a), __builtin_bit_cast(vg_f16x8, b),
+                                                c, 0, 0, 0);
+}
+
 struct VStepArgs {
   const uint8_t* codes;     // row t of the alignment (L bytes) or nullptr
-  const float* wxP[2];      // [layer]: input weights  [Kx][512][4]
-  const float* whP[2];      // [layer]: hidden weights [512][512][4]
+  const uint4* wx[2];       // [layer]: input weight pieces   [2][3][KQ][512] x 16 bytes (KQ = 4 / 64)
+  const uint4* wh[2];       // [layer]: hidden weight pieces  [2][3][64][512] x 16 bytes
   const float* bias[2];     // [layer]: [4][512]: r (b_ir+b_hr), z (b_iz+b_hz), b_in, b_hn
-  const float* h0_prev;     // packed state [128][Lb][4]
+  float inv_scale[2];
+  const float* h0_prev;     // float32 state [128][Lb][4]
   float* h0_next;
   const float* h1_prev;
   float* h1_next;
+  const uint4* g0_prev;     // f16 pieces of 1024*state [2][64][Lb] x 16 bytes
+  uint16_t* g0_next;
+  const uint4* g1_prev;
+  uint16_t* g1_next;
   int L, Lb;
   int do_l0, do_l1;
 };
 
-// One wave's quarter of a K = 512 contraction: octets o = w, w+4, ..., w+60, three accumulators.
-// Hand-staged: the 10 loads of the next two octets are issued before the 24 MFMAs of the current.
-__device__ __forceinline__ void k512_octets(const float* __restrict__ wp, const float* __restrict__ xp,
-                                            int Lb, int w, int kk, f32x16& a0, f32x16& a1, f32x16& a2) {
-  float4 wv[2][2][4];
-  float4 xv[2][2];
+// One wave's quarter of a K = 512 contraction: MFMA steps s = w, w+4, ..., w+28 (16 k each), three
+// gate accumulators.  Hand-staged: the 16 loads of the next two steps are issued before the 18
+// MFMAs of the current two.
+__device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const uint4* __restrict__ xp, int Lb,
+                                           int w, int kk, f32x16& a0, f32x16& a1, f32x16& a2) {
+  uint4 wv[2][2][3][2];   // [buffer][step][gate][piece]
+  uint4 xv[2][2][2];      // [buffer][step][piece]
   auto load_chunk = [&](int buf, int c) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int o = w + 4 * (2 * c + u);
-      xv[buf][u] = *reinterpret_cast<const float4*>(xp + (int64_t)(2 * o + kk) * Lb * 4);
+      const int kq = 2 * (w + 4 * (2 * c + u)) + kk;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        wv[buf][u][e] = *reinterpret_cast<const float4*>(wp + (int64_t)(8 * o + 4 * kk + e) * 2048);
+      for (int p = 0; p < 2; ++p) {
+        xv[buf][u][p] = xp[(int64_t)(p * 64 + kq) * Lb];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) wv[buf][u][g][p] = wp[(int64_t)((p * 3 + g) * 64 + kq) * 512];
+      }
     }
   };
   load_chunk(0, 0);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    if (c + 1 < 8) load_chunk((c + 1) & 1, c + 1);
+  for (int c = 0; c < 4; ++c) {
+    if (c + 1 < 4) load_chunk((c + 1) & 1, c + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const float xs[4] = {xv[c & 1][u].x, xv[c & 1][u].y, xv[c & 1][u].z, xv[c & 1][u].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[c & 1][u][e].x, xs[e], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[c & 1][u][e].y, xs[e], a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[c & 1][u][e].z, xs[e], a2, 0, 0, 0);
-      }
+      const uint4 x0 = xv[c & 1][u][0], x1 = xv[c & 1][u][1];
+      a0 = vg_mfma(wv[c & 1][u][0][0], x1, a0);
+      a1 = vg_mfma(wv[c & 1][u][1][0], x1, a1);
+      a2 = vg_mfma(wv[c & 1][u][2][0], x1, a2);
+      a0 = vg_mfma(wv[c & 1][u][0][1], x0, a0);
+      a1 = vg_mfma(wv[c & 1][u][1][1], x0, a1);
+      a2 = vg_mfma(wv[c & 1][u][2][1], x0, a2);
+      a0 = vg_mfma(wv[c & 1][u][0][0], x0, a0);
+      a1 = vg_mfma(wv[c & 1][u][1][0], x0, a1);
+      a2 = vg_mfma(wv[c & 1][u][2][0], x0, a2);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -92,33 +112,39 @@ __global__ __launch_bounds__(512) void vgru_step_kernel(VStepArgs a) {
   const int b0 = (rest % nbt) * 32, j0 = (2 * xcd + (slot & 1)) * 32;
   const int Lb = a.Lb;
   const float* hprev = (layer == 0) ? a.h0_prev : a.h1_prev;
+  const uint4* gprev = (layer == 0) ? a.g0_prev : a.g1_prev;
 
   f32x16 acc_r, acc_z, acc_t;       // third = W_hn h (part 0) or W_in x (part 1)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_t[r] = 0.f; }
 
   if (part == 0) {
-    k512_octets(a.whP[layer] + (int64_t)(j0 + li) * 4, hprev + (int64_t)(b0 + li) * 4, Lb, w, kk,
-                acc_r, acc_z, acc_t);
+    k512_steps(a.wh[layer] + (j0 + li), gprev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
   } else if (layer == 1) {
-    k512_octets(a.wxP[1] + (int64_t)(j0 + li) * 4, a.h0_prev + (int64_t)(b0 + li) * 4, Lb, w, kk,
-                acc_r, acc_z, acc_t);
+    k512_steps(a.wx[1] + (j0 + li), a.g0_prev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
   } else if (w == 0) {
-    // layer 0 input: one-hot of the residue code, K = 24 (rows 22, 23 of the packed weights are 0)
+    // layer 0 input: one-hot of the residue code (value 1024 = the state scale), K = 32 (rows 22..31
+    // of the packed weights are 0)
     const int b = b0 + li;
     const int code = (b < a.L) ? (int)a.codes[b] : 0;
-    const float* wp = a.wxP[0] + (int64_t)(j0 + li) * 4;
+    const uint4* wp = a.wx[0] + (j0 + li);
 #pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = 8 * o + 4 * kk + e;
-        const float4 w4 = *reinterpret_cast<const float4*>(wp + (int64_t)k * 2048);
-        const float x = (code == k) ? 1.0f : 0.0f;
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, x, acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, x, acc_z, 0, 0, 0);
-        acc_t = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, x, acc_t, 0, 0, 0);
-      }
+    for (int s = 0; s < 2; ++s) {
+      const int kq = 2 * s + kk;
+      const int d = code - 8 * kq;                       // position of the hot element among this lane's 8 k
+      const unsigned hot = (d >= 0 && d < 8) ? (0x6400u << (16 * (d & 1))) : 0u;
+      uint4 x;
+      x.x = (d >> 1) == 0 ? hot : 0u;
+      x.y = (d >> 1) == 1 ? hot : 0u;
+      x.z = (d >> 1) == 2 ? hot : 0u;
+      x.w = (d >> 1) == 3 ? hot : 0u;
+      acc_r = vg_mfma(wp[(int64_t)((1 * 3 + 0) * 4 + kq) * 512], x, acc_r);
+      acc_z = vg_mfma(wp[(int64_t)((1 * 3 + 1) * 4 + kq) * 512], x, acc_z);
+      acc_t = vg_mfma(wp[(int64_t)((1 * 3 + 2) * 4 + kq) * 512], x, acc_t);
+      acc_r = vg_mfma(wp[(int64_t)((0 * 3 + 0) * 4 + kq) * 512], x, acc_r);
+      acc_z = vg_mfma(wp[(int64_t)((0 * 3 + 1) * 4 + kq) * 512], x, acc_z);
+      acc_t = vg_mfma(wp[(int64_t)((0 * 3 + 2) * 4 + kq) * 512], x, acc_t);
+    }
   }
 
   // ---- stage 1: the input-product waves hand their partial sums to the recurrent-product waves
@@ -154,7 +180,9 @@ __global__ __launch_bounds__(512) void vgru_step_kernel(VStepArgs a) {
   __syncthreads();
   if (part != 0) return;
   const float* bias = a.bias[layer];
+  const float inv = a.inv_scale[layer];
   float* hnext = (layer == 0) ? a.h0_next : a.h1_next;
+  uint16_t* gnext = (layer == 0) ? a.g0_next : a.g1_next;
   const int j4 = j0 + 8 * w + 4 * kk;              // rows (4w+q): j = j4 + q, q = 0..3
   const int b = b0 + li;
   const float4 bR = *reinterpret_cast<const float4*>(bias + j4);
@@ -167,19 +195,30 @@ __global__ __launch_bounds__(512) void vgru_step_kernel(VStepArgs a) {
   const float4 hp4 = *reinterpret_cast<const float4*>(hprev + hoff);
   const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
   float hn[4];
+  unsigned short q0[4], q1[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = w * 4 + q;
     float s[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      s[g] = (red[0][g][r][lane] + red[1][g][r][lane]) + (red[2][g][r][lane] + red[3][g][r][lane]);
+      s[g] = ((red[0][g][r][lane] + red[1][g][r][lane]) + (red[2][g][r][lane] + red[3][g][r][lane])) * inv;
     const float rg = vsigmoid(s[0] + br[q]);
     const float zg = vsigmoid(s[1] + bz[q]);
     const float ng = tanhf((s[2] + bi[q]) + rg * (s[3] + bh[q]));
     hn[q] = (hp[q] - ng) * zg + ng;
+    const float hs = hn[q] * VGRU_STATE_SCALE;
+    const _Float16 p0 = (_Float16)hs;
+    const _Float16 p1 = (_Float16)(hs - (float)p0);
+    q0[q] = __builtin_bit_cast(unsigned short, p0);
+    q1[q] = __builtin_bit_cast(unsigned short, p1);
   }
   *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
+  *reinterpret_cast<uint2*>(gnext + goff) =
+      make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
+  *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
+      make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
 }
 
 // out[l][j] = hP[j/4][l][j%4]
@@ -193,12 +232,18 @@ __global__ __launch_bounds__(128) void vgru_out_kernel(const float* __restrict__
 int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s) {
   const int Lb = round_up(L, 32);
   const size_t hbytes = sizeof(float) * WIDTH * Lb;
-  DMP_HIP(hipMemsetAsync(c->hT[0][0], 0, hbytes, s));
-  DMP_HIP(hipMemsetAsync(c->hT[1][0], 0, hbytes, s));
+  for (int l = 0; l < 2; ++l) {
+    DMP_HIP(hipMemsetAsync(c->hT[l][0], 0, hbytes, s));
+    DMP_HIP(hipMemsetAsync(c->hH[l][0], 0, hbytes, s));     // 2 pieces x 512 x Lb x 2 bytes
+  }
   const Weights& W = c->W;
   VStepArgs a{};
-  a.wxP[0] = W.v_wx[0]; a.whP[0] = W.v_wh[0]; a.bias[0] = W.v_b0;
-  a.wxP[1] = W.v_wx[1]; a.whP[1] = W.v_wh[1]; a.bias[1] = W.v_b1;
+  for (int l = 0; l < 2; ++l) {
+    a.wx[l] = reinterpret_cast<const uint4*>(W.v_wx[l]);
+    a.wh[l] = reinterpret_cast<const uint4*>(W.v_wh[l]);
+    a.inv_scale[l] = W.v_inv_scale[l];
+  }
+  a.bias[0] = W.v_b0; a.bias[1] = W.v_b1;
   a.L = L; a.Lb = Lb;
   dim3 grid(8 * 2 * (Lb / 32) * 2);
   for (int t = 0; t <= N; ++t) {
@@ -209,6 +254,10 @@ int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, h
     a.h0_next = c->hT[0][(t + 1) & 1];
     a.h1_prev = c->hT[1][(t + 1) & 1];   // layer 1 runs step t-1: parity (t-1)&1
     a.h1_next = c->hT[1][t & 1];
+    a.g0_prev = reinterpret_cast<const uint4*>(c->hH[0][t & 1]);
+    a.g0_next = c->hH[0][(t + 1) & 1];
+    a.g1_prev = reinterpret_cast<const uint4*>(c->hH[1][(t + 1) & 1]);
+    a.g1_next = c->hH[1][t & 1];
     hipLaunchKernelGGL(vgru_step_kernel, grid, dim3(512), 0, s, a);
   }
   DMP_LAUNCH_CHECK();
