@@ -101,9 +101,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=3,
-                    help="targets in flight per GPU (one context + HIP stream each); a step is one "
-                         "batch of this many targets")
+                    help="targets in flight per GPU (one context + HIP stream each)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="targets per step and GPU (default 2 x streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stagger", action="store_true", help="scheduler: space the engines' phases")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,10 +127,11 @@ def main():
     S = max(1, args.streams)
     sd = synth.synth_weights(0, coord_scale=5.0)
     pipe = Pipeline(device, L_NS, N_NS, {k: torch.from_numpy(np.array(v)) for k, v in sd.items()},
-                    streams=S)
+                    streams=S, stagger=args.stagger)
 
-    # S synthetic targets per step and rank, all resident in HBM before the clock starts
-    total = (args.warmup + args.steps) * S
+    # B synthetic targets per step and rank, all resident in HBM before the clock starts
+    B = args.batch if args.batch > 0 else 2 * S
+    total = (args.warmup + args.steps) * B
     targets = []
     for i in range(total):
         rows = synth.synth_msa(L_NS, N_NS, seed=100000 * rank + i)
@@ -140,14 +143,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    outs = pipe.run(targets[:args.warmup * S], ITERS, MINSTEPS)
+    outs = pipe.run(targets[:args.warmup * B], ITERS, MINSTEPS)
     sync_all()
     for e in pipe.engines:
-        _lib.check(lib.dmp_profile_enable(e.ctx, 1, 16 * (ITERS + 1) * (args.steps + 1)))
+        _lib.check(lib.dmp_profile_enable(e.ctx, 1, 16 * (ITERS + 1) * (args.steps * B // S + 2)))
     t0 = time.perf_counter()
-    outs += pipe.run(targets[args.warmup * S:], ITERS, MINSTEPS)
+    # the steps are pipelined: step k+1 is queued as soon as every target of step k has started on an
+    # engine; the clock stops when all K batches have completed (sync_all)
+    tickets = []
+    for k in range(args.steps):
+        lo = (args.warmup + k) * B
+        tickets += [pipe.submit(m, ITERS, MINSTEPS) for m in targets[lo:lo + B]]
+        pipe.pump()
+    pipe.drain()
     sync_all()
     elapsed = time.perf_counter() - t0
+    outs += [pipe.result(t) for t in tickets]
     conv_tot, conv_cnt = 0.0, 0
     for e in pipe.engines:
         ms, n = C.c_float(), C.c_int()
@@ -178,7 +189,7 @@ def main():
                 traffic = None
         line = {
             "metric": "structures/s at L=300, N_seq=2000, 10 iters+100 min",
-            "value": world * args.steps * S / elapsed,
+            "value": world * args.steps * B / elapsed,
             "unit": "structures/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -192,9 +203,9 @@ def main():
             "finite_outputs": ok,
             "config": {"workload": "synthetic targets L=300 N_seq=2000, iterations=10, minsteps=100 "
                                    "(BASELINE.json metric config); one step = one batch of "
-                                   f"{S} independent targets per GPU",
+                                   f"{B} independent targets per GPU",
                        "L": L_NS, "n_seq": N_NS, "iterations": ITERS, "minsteps": MINSTEPS,
-                       "targets_per_step_per_gpu": S,
+                       "targets_per_step_per_gpu": B, "streams_per_gpu": S,
                        "weights": "synthetic seed 0 (reference state_dict shapes)",
                        "parallelism": f"replicas x{world}, no collective on the data path; "
                                       f"{S} HIP streams per GPU"},

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmpfold_hip.so")
+LIB_PATH = os.environ.get("DMPFOLD_HIP_LIB") or os.path.join(_HERE, "libdmpfold_hip.so")
 
 _vp, _i, _i64, _fp = C.c_void_p, C.c_int, C.c_int64, C.c_void_p   # device pointers travel as void*
 
@@ -46,6 +46,10 @@ SIGNATURES = {
     "dmp_predict_begin": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i, _vp]),
     "dmp_predict_pass": (_i, [_vp, _vp]),
     "dmp_predict_end": (_i, [_vp, _fp, _fp, _vp]),
+    "dmp_predict_next_unit": (_i, [_vp]),
+    "dmp_predict_issue_unit": (_i, [_vp, _vp]),
+    "dmp_ctx_pending": (_i, [_vp]),
+    "dmp_predict_begin_units": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i]),
     "dmp_lane_create": (_i, [C.POINTER(_vp)]),
     "dmp_lane_destroy": (None, [_vp]),
     "dmp_ctx_set_lane": (_i, [_vp, _vp]),

@@ -37,8 +37,11 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"),
-               os.path.join(os.path.dirname(HERE), "include", "dmpfold_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_bf16.h", "conv_f16.h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "dmpfold_hip.h"))
+    extra = os.environ.get("DMP_EXTRA_HIPCC_FLAGS", "").split()      # tuning experiments (-DVG_CH=1 ...)
+    lib = os.environ.get("DMP_LIB_OUT", LIB)
+    force = force or bool(extra)
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:
@@ -49,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))
@@ -61,12 +64,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -235,40 +235,58 @@ static int need_weights(dmp_ctx* c) {
   return DMP_OK;
 }
 
-static int trunk_pass(dmp_ctx* c, const float* z0, const float* dmap, int L, float* d_conf,
-                      float* d_M, hipStream_t s) {
+// A trunk pass = open (stem update, first split), 16 residual blocks, close (head + Gram matrix).
+static int trunk_open(dmp_ctx* c, const float* z0, const float* dmap, int L, hipStream_t s) {
   int rc;
-  float* cur = c->xa;
-  float* oth = c->xb;
-  if ((rc = stem_update_padded(c, z0, dmap, L, cur, s))) return rc;
+  c->trunk_cur = c->xa;
+  c->trunk_oth = c->xb;
+  c->xsplit_current = false;
+  if ((rc = stem_update_padded(c, z0, dmap, L, c->trunk_cur, s))) return rc;
   if (c->conv_mode != 1) {
     // f16 / bf16 pieces of the stem output; every block's norm kernel then emits those of its output
-    if ((rc = act_split(c, cur, L, s))) return rc;
+    if ((rc = act_split(c, c->trunk_cur, L, s))) return rc;
     c->xsplit_current = true;
   }
-  struct Reset { dmp_ctx* c; ~Reset() { c->xsplit_current = false; } } reset{c};
-  for (int k = 1; k <= NBLOCK; ++k) {
-    if (c->lane && c->lane->last) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->lane->last, 0));
-    if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
-      DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n], s));
-    }
-    if ((rc = conv5x5_maxout_padded(c, k, cur, L, c->u, c->stats, s, false))) return rc;
-    if (c->lane) {
-      dmp_lane* ln = c->lane;
-      void* e = ln->ev[ln->next];
-      ln->next = (ln->next + 1) % dmp_lane::RING;
-      DMP_HIP(hipEventRecord((hipEvent_t)e, s));
-      ln->last = e;
-    }
-    if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
-      DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n + 1], s));
-      c->prof_n += 2;
-    }
-    if ((rc = conv5x5_reduce_stats(c, L, c->stats, s))) return rc;
-    if ((rc = norm_scse_residual_padded(c, k, c->u, c->stats, cur, L, oth, s))) return rc;
-    std::swap(cur, oth);
+  return DMP_OK;
+}
+
+static int trunk_block(dmp_ctx* c, int k, int L, hipStream_t s) {
+  int rc;
+  if (c->lane && c->lane->last) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->lane->last, 0));
+  if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
+    DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n], s));
   }
-  return head_gram_padded(c, cur, L, d_conf, d_M, s);
+  if ((rc = conv5x5_maxout_padded(c, k, c->trunk_cur, L, c->u, c->stats, s, false))) return rc;
+  if (c->lane) {
+    dmp_lane* ln = c->lane;
+    void* e = ln->ev[ln->next];
+    ln->next = (ln->next + 1) % dmp_lane::RING;
+    DMP_HIP(hipEventRecord((hipEvent_t)e, s));
+    ln->last = e;
+  }
+  if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
+    DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n + 1], s));
+    c->prof_n += 2;
+  }
+  if ((rc = conv5x5_reduce_stats(c, L, c->stats, s))) return rc;
+  if ((rc = norm_scse_residual_padded(c, k, c->u, c->stats, c->trunk_cur, L, c->trunk_oth, s))) return rc;
+  std::swap(c->trunk_cur, c->trunk_oth);
+  return DMP_OK;
+}
+
+static int trunk_close(dmp_ctx* c, int L, float* d_conf, float* d_M, hipStream_t s) {
+  c->xsplit_current = false;
+  return head_gram_padded(c, c->trunk_cur, L, d_conf, d_M, s);
+}
+
+static int trunk_pass(dmp_ctx* c, const float* z0, const float* dmap, int L, float* d_conf,
+                      float* d_M, hipStream_t s) {
+  struct Reset { dmp_ctx* c; ~Reset() { c->xsplit_current = false; } } reset{c};
+  int rc;
+  if ((rc = trunk_open(c, z0, dmap, L, s))) return rc;
+  for (int k = 1; k <= NBLOCK; ++k)
+    if ((rc = trunk_block(c, k, L, s))) return rc;
+  return trunk_close(c, L, d_conf, d_M, s);
 }
 
 static int coords_from_mds(dmp_ctx* c, const float* mat1d, const float* mds, int L, float* d_ca,
@@ -321,6 +339,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
       A_(hT[l][p], (int64_t)WIDTH * Lb);
       A_(hH[l][p], (int64_t)2 * WIDTH * Lb);
     }
+  A_(vgru_run, 64);
   A_(vout, L * WIDTH);
   A_(seq_g, L * 1536);
   A_(seq_a, L * WIDTH);
@@ -355,6 +374,11 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
 #undef A_
   if (rc) { dmp_ctx_destroy(c); return rc; }
   if (hipMemset(c->seq_abort, 0, sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+  for (int i = 0; i < 2; ++i) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+    c->unit_ev[i] = (void*)e;
+  }
   *out = c;
   return DMP_OK;
 }
@@ -398,6 +422,9 @@ void dmp_ctx_destroy(dmp_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   for (void* p : c->W.allocs) (void)hipFree(p);
   for (void* e : c->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
+  for (void* e : c->unit_ev)
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+  for (auto& kv : c->vgru_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
   delete c;
 }
 
@@ -428,6 +455,8 @@ int dmp_weights_finalize(dmp_ctx* c) {
   DMP_HIP(hipSetDevice(c->device));
   for (void* p : c->W.allocs) { (void)hipFree(p); }
   c->W.allocs.clear();
+  for (auto& kv : c->vgru_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);   // they hold weight pointers
+  c->vgru_graphs.clear();
   int rc = pack_weights(c);
   if (rc) return rc;
   c->W.host.clear();
@@ -593,69 +622,147 @@ int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d
   return dmp_predict_end(ctx, d_coords, d_conf, stream);
 }
 
-int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
-                      int Lt, int nloops, int refine_steps, void* stream) {
+// ---- unit-granular issue ---------------------------------------------------------------------
+// A prediction = front-end units (features, sequence trunk, static stem; chunked so that a scheduler
+// regains control every ~2 ms of GPU work) followed by 18 units per pass: 0 = recycled distances +
+// stem update, 1..16 = residual block k (its convolution takes the lane), 17 = head, Gram matrix,
+// MDS, coordinate GRU, best-of update.
+static constexpr int FE_INV_BLOCKS = 6;    // Gauss-Jordan block steps per front-end unit
+static constexpr int FE_VGRU_STEPS = VGRU_CHUNK;  // vertical-GRU time steps per front-end unit (one graph replay)
+
+static int record_unit(dmp_ctx* c, hipStream_t s) {
+  DMP_HIP(hipEventRecord((hipEvent_t)c->unit_ev[c->unit_seq & 1], s));
+  c->unit_seq++;
+  return DMP_OK;
+}
+
+static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
+  const int L = c->last_L, N = c->last_N, u = c->fe_next;
+  const uint8_t* d_msa = c->run_msa;
+  int rc = DMP_OK;
+  if (u == 0) {
+    rc = msa_weights(c, d_msa, N, L, c->w, s);
+    if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, s);
+  } else if (u <= c->fe_inv) {
+    rc = spd_inverse_steps(c, c->cov, NS * L, (u - 1) * FE_INV_BLOCKS, u * FE_INV_BLOCKS, s);
+    if (!rc && u == c->fe_inv) rc = dca_contacts(c, c->cov, L, c->contacts, s);
+  } else if (u <= c->fe_inv + c->fe_vgru) {
+    const int j = u - c->fe_inv - 1;
+    rc = gru_vertical_steps(c, d_msa, N, L, j * FE_VGRU_STEPS, std::min((j + 1) * FE_VGRU_STEPS, N + 1),
+                            c->vout, s);
+  } else {
+    const float* inv = N > 1 ? c->cov : nullptr;
+    const float* contacts = N > 1 ? c->contacts : nullptr;
+    rc = gru_bidir(c, 0, c->vout, L, c->seq_b, s);
+    if (!rc) rc = transpose_f32(c->seq_b, L, WIDTH, c->mat1d, s);
+    if (!rc) rc = stem_static(c, c->mat1d, inv, contacts, L, c->z0, s);
+    if (!rc) rc = c->run_template ? pair_distances(c->run_template, L, 0, c->dmap, s)
+                                  : fill_f32(c->dmap, (int64_t)L * L, -1.0f, s);
+    if (!rc) rc = act_clear(c->xa, L, s);
+    if (!rc) rc = act_clear(c->xb, L, s);
+  }
+  if (rc) return rc;
+  c->fe_next = u + 1;
+  return record_unit(c, s);
+}
+
+int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
+                            int Lt, int nloops, int refine_steps) {
   CHECK_CAP(L, N);
   CHECK_W();
   DMP_ARG(d_msa != nullptr, "null argument");
   DMP_ARG(N >= 1 && L >= 8, "need N >= 1 and L >= 8 (got N=%d L=%d)", N, L);
   DMP_ARG(d_template_ca == nullptr || Lt == L,
           "template has %d CA atoms but the alignment has %d columns", Lt, L);
-  if (nloops < 0) nloops = 0;
-  if (refine_steps < 0) refine_steps = 0;
   dmp_ctx* c = ctx;
-  hipStream_t s = STREAM;
-  int rc;
   c->last_L = L;
   c->last_N = N;
   c->passes_done = 0;
-  c->run_nloops = nloops;
-  c->run_refine = refine_steps;
-  // ---- features
-  if ((rc = msa_weights(c, d_msa, N, L, c->w, s))) return rc;
-  const float *inv = nullptr, *contacts = nullptr;
-  if (N > 1) {
-    if ((rc = cov_build(c, d_msa, c->w, N, L, c->cov, s))) return rc;
-    if ((rc = spd_inverse(c, c->cov, NS * L, s))) return rc;
-    if ((rc = dca_contacts(c, c->cov, L, c->contacts, s))) return rc;
-    inv = c->cov;
-    contacts = c->contacts;
-  }
-  // ---- sequence trunk
-  if ((rc = gru_vertical(c, d_msa, N, L, c->vout, s))) return rc;
-  if ((rc = gru_bidir(c, 0, c->vout, L, c->seq_b, s))) return rc;
-  if ((rc = transpose_f32(c->seq_b, L, WIDTH, c->mat1d, s))) return rc;
-  // ---- pair trunk, static part
-  if ((rc = stem_static(c, c->mat1d, inv, contacts, L, c->z0, s))) return rc;
-  if (d_template_ca) rc = pair_distances(d_template_ca, L, 0, c->dmap, s);
-  else rc = fill_f32(c->dmap, (int64_t)L * L, -1.0f, s);
-  if (rc) return rc;
-  if ((rc = act_clear(c->xa, L, s))) return rc;
-  return act_clear(c->xb, L, s);
+  c->unit_next = 0;
+  c->run_nloops = nloops < 0 ? 0 : nloops;
+  c->run_refine = refine_steps < 0 ? 0 : refine_steps;
+  c->run_msa = d_msa;
+  c->run_template = d_template_ca;
+  c->fe_next = 0;
+  c->fe_inv = N > 1 ? cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
+  c->fe_vgru = cdiv(N + 1, FE_VGRU_STEPS);
+  c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
+  return DMP_OK;
 }
 
-// one trunk pass (first pass or one recycling iteration) + MDS + coordinate GRU + best-of update
-int dmp_predict_pass(dmp_ctx* ctx, void* stream) {
+int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
+                      int Lt, int nloops, int refine_steps, void* stream) {
+  int rc = dmp_predict_begin_units(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps);
+  while (!rc && ctx->fe_next < ctx->fe_total) rc = issue_front_end_unit(ctx, STREAM);
+  return rc;
+}
+
+int dmp_predict_next_unit(const dmp_ctx* ctx) {
+  if (!ctx) return DMP_UNIT_NONE;
+  if (ctx->fe_next < ctx->fe_total) return DMP_UNIT_LIGHT;
+  if (ctx->passes_done > ctx->run_nloops) return DMP_UNIT_NONE;
+  return (ctx->unit_next >= 1 && ctx->unit_next <= NBLOCK) ? DMP_UNIT_CONV : DMP_UNIT_LIGHT;
+}
+
+int dmp_predict_issue_unit(dmp_ctx* ctx, void* stream) {
   DMP_ARG(ctx != nullptr, "null context");
   dmp_ctx* c = ctx;
-  DMP_ARG(c->passes_done <= c->run_nloops, "all passes of this prediction were already issued");
   hipStream_t s = STREAM;
-  const int L = c->last_L, pass = c->passes_done;
-  int rc;
-  if (pass > 0 && (rc = pair_distances(c->ca, L, 1, c->dmap, s))) return rc;
-  if ((rc = trunk_pass(c, c->z0, c->dmap, L, c->conf, c->gram, s))) return rc;
-  if ((rc = eigh_top8(c, c->gram, L, c->mds, s))) return rc;
-  if ((rc = coords_from_mds(c, c->mat1d, c->mds, L, c->ca, s))) return rc;
-  if (pass == 0 && c->run_refine > 0 && (rc = refine_coords(c->ca, L, c->run_refine, s))) return rc;
-  if ((rc = select_best(c, c->conf, c->ca, L, pass, c->max_passes, s))) return rc;
-  c->passes_done = pass + 1;
+  if (c->fe_next < c->fe_total) return issue_front_end_unit(c, s);
+  DMP_ARG(c->passes_done <= c->run_nloops, "all passes of this prediction were already issued");
+  const int L = c->last_L, pass = c->passes_done, u = c->unit_next;
+  int rc = DMP_OK;
+  if (u == 0) {
+    if (pass > 0) rc = pair_distances(c->ca, L, 1, c->dmap, s);
+    if (!rc) rc = trunk_open(c, c->z0, c->dmap, L, s);
+  } else if (u <= NBLOCK) {
+    rc = trunk_block(c, u, L, s);
+  } else {
+    rc = trunk_close(c, L, c->conf, c->gram, s);
+    if (!rc) rc = eigh_top8(c, c->gram, L, c->mds, s);
+    if (!rc) rc = coords_from_mds(c, c->mat1d, c->mds, L, c->ca, s);
+    if (!rc && pass == 0 && c->run_refine > 0) rc = refine_coords(c->ca, L, c->run_refine, s);
+    if (!rc) rc = select_best(c, c->conf, c->ca, L, pass, c->max_passes, s);
+  }
+  if (rc) { c->xsplit_current = false; return rc; }
+  if (u == NBLOCK + 1) { c->unit_next = 0; c->passes_done = pass + 1; }
+  else c->unit_next = u + 1;
+  return record_unit(c, s);
+}
+
+// Units issued through dmp_predict_begin / dmp_predict_issue_unit that have not completed yet:
+// 0, 1, or 2 (= two or more).
+int dmp_ctx_pending(dmp_ctx* ctx) {
+  DMP_ARG(ctx != nullptr, "null context");
+  if (ctx->unit_seq == 0) return 0;
+  hipError_t e = hipEventQuery((hipEvent_t)ctx->unit_ev[(ctx->unit_seq - 1) & 1]);
+  if (e == hipSuccess) return 0;
+  if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+  if (ctx->unit_seq < 2) return 1;
+  e = hipEventQuery((hipEvent_t)ctx->unit_ev[ctx->unit_seq & 1]);
+  if (e == hipSuccess) return 1;
+  if (e != hipErrorNotReady) return hip_fail(e, "hipEventQuery", __FILE__, __LINE__);
+  return 2;
+}
+
+// one whole pass = the remaining units of the current pass
+int dmp_predict_pass(dmp_ctx* ctx, void* stream) {
+  DMP_ARG(ctx != nullptr, "null context");
+  DMP_ARG(ctx->fe_next >= ctx->fe_total, "front-end units of this prediction are still outstanding");
+  DMP_ARG(ctx->passes_done <= ctx->run_nloops, "all passes of this prediction were already issued");
+  const int pass = ctx->passes_done;
+  while (ctx->passes_done == pass) {
+    const int rc = dmp_predict_issue_unit(ctx, stream);
+    if (rc) return rc;
+  }
   return DMP_OK;
 }
 
 int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) {
   DMP_ARG(ctx && d_coords && d_conf, "null argument");
   dmp_ctx* c = ctx;
-  DMP_ARG(c->passes_done == c->run_nloops + 1, "dmp_predict_end before all passes were issued");
+  DMP_ARG(c->fe_next >= c->fe_total && c->passes_done == c->run_nloops + 1,
+          "dmp_predict_end before all passes were issued");
   hipStream_t s = STREAM;
   const int L = c->last_L;
   int rc;

@@ -13,6 +13,8 @@ namespace dmp {
 constexpr int WIDTH = 512;     // GRU width
 constexpr int HID2 = 256;      // bidirectional GRU hidden per direction
 constexpr float VGRU_STATE_SCALE = 1024.f;   // vertical-GRU state is split into f16 pieces of 1024*h
+constexpr int VGRU_CHUNK = 128;        // vertical-GRU time steps per hipGraph replay ...
+constexpr int VGRU_CHUNK_SMALL = 16;   // ... and for the last <= 64 steps
 constexpr int CW = 128;        // pair trunk width
 constexpr int NBLOCK = 16;
 constexpr int STEM_OUT = 384;  // 128 * pool 3
@@ -127,6 +129,8 @@ struct dmp_ctx {
   // sequence trunk
   float* hT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [layer][parity][128][Lb][4] float32 state
   uint16_t* hH[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // same state as f16 pieces [2][64][Lb][8]
+  uint8_t* vgru_run = nullptr;             // device VRun record read by the graph's step kernels
+  std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions
   float* seq_a = nullptr;   // [L][512]
@@ -163,6 +167,14 @@ struct dmp_ctx {
   float* ca_pass = nullptr;    // [P][L][3]
   float* best_ca_snapshot = nullptr;
   int passes_done = 0;
+  int unit_next = 0;           // next unit of the current pass (0 open, 1..16 blocks, 17 close + MDS + coordinates)
+  float *trunk_cur = nullptr, *trunk_oth = nullptr;   // ping-pong activations of the pass in flight
+  void* unit_ev[2] = {nullptr, nullptr};   // hipEvent_t ring: recorded after each unit issued
+  long unit_seq = 0;           // units issued since the context was created
+  int fe_next = 0, fe_total = 0;           // front-end units (features, sequence trunk, static stem)
+  int fe_inv = 0, fe_vgru = 0;             // ... of which inverse chunks / vertical-GRU chunks
+  const uint8_t* run_msa = nullptr;        // arguments of the prediction in flight
+  const float* run_template = nullptr;
   int last_L = 0, last_N = 0;
   int max_passes = 0;
   // optional HIP-event timing of the conv kernel inside dmp_predict
@@ -190,9 +202,15 @@ int msa_weights(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_w, hipS
 int cov_build(dmp_ctx* c, const uint8_t* d_msa, const float* d_w, int N, int L, float* d_cov,
               hipStream_t s);
 int spd_inverse(dmp_ctx* c, float* d_A, int D, hipStream_t s);
+// block steps [blk_lo, blk_hi) of the in-place inverse (GJ_NB columns each); all of them = spd_inverse
+int spd_inverse_steps(dmp_ctx* c, float* d_A, int D, int blk_lo, int blk_hi, hipStream_t s);
 int dca_contacts(dmp_ctx* c, const float* d_inv, int L, float* d_contacts, hipStream_t s);
 // gru.hip
 int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s);
+// launches t in [t_lo, t_hi) of the N + 1 per-row launches (t_lo = 0 clears the state, t_hi = N + 1
+// writes d_out)
+int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
+                       hipStream_t s);
 int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hipStream_t s);
 // trunk.hip
 int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const float* d_contacts,

@@ -183,8 +183,12 @@ __global__ __launch_bounds__(256) void gj_writeback_kernel(float* __restrict__ A
 }
 
 int spd_inverse(dmp_ctx* c, float* A, int D, hipStream_t s) {
+  return spd_inverse_steps(c, A, D, 0, cdiv(D, GJ_NB), s);
+}
+
+int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipStream_t s) {
   float *P = c->gj_p, *R = c->gj_r, *Cp = c->gj_c;
-  for (int k0 = 0; k0 < D; k0 += GJ_NB) {
+  for (int k0 = blk_lo * GJ_NB; k0 < D && k0 < blk_hi * GJ_NB; k0 += GJ_NB) {
     const int bs = std::min(GJ_NB, D - k0);
     hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(256), 0, s, A, D, k0, bs, P);
     DMP_LAUNCH_CHECK();

@@ -28,6 +28,12 @@
 
 namespace dmp {
 
+#ifndef VG_CH
+#define VG_CH 2      // MFMA steps per load chunk (double-buffered)
+#endif
+#ifndef VG_OCC
+#define VG_OCC 2     // waves per SIMD the register budget is compiled for (2 = one workgroup per CU)
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 vg_f16x8 __attribute__((ext_vector_type(8)));
 
@@ -38,17 +44,29 @@ __device__ __forceinline__ f32x16 vg_mfma(uint4 a, uint4 b, f32x16 c) {
                                                 c, 0, 0, 0);
 }
 
-struct VStepArgs {
-  const uint8_t* codes;     // row t of the alignment (L bytes) or nullptr
+// Per-context constants of the step kernel (baked into the hipGraph nodes) ...
+struct VStatic {
   const uint4* wx[2];       // [layer]: input weight pieces   [2][3][KQ][512] x 16 bytes (KQ = 4 / 64)
   const uint4* wh[2];       // [layer]: hidden weight pieces  [2][3][64][512] x 16 bytes
   const float* bias[2];     // [layer]: [4][512]: r (b_ir+b_hr), z (b_iz+b_hz), b_in, b_hn
   float inv_scale[2];
-  const float* h0_prev;     // float32 state [128][Lb][4]
+  float* hT[2][2];          // [layer][parity] float32 state [128][Lb][4]
+  uint16_t* hH[2][2];       // [layer][parity] f16 pieces of 1024*state [2][64][Lb][8]
+};
+// ... and what changes from chunk to chunk, read from device memory (vgru_set_run_kernel)
+struct VRun {
+  const uint8_t* msa;       // N x L residue codes
+  int N, L, Lb;
+  int t0, t_end;            // node idx of the chunk runs time step t = t0 + idx if t < t_end
+};
+
+struct VStepArgs {          // the view of one time step the kernel body works with (scalars only:
+  const uint8_t* codes;     // row t of the alignment (L bytes) or nullptr;   arrays would go to scratch)
+  const float* h0_prev;
   float* h0_next;
   const float* h1_prev;
   float* h1_next;
-  const uint4* g0_prev;     // f16 pieces of 1024*state [2][64][Lb] x 16 bytes
+  const uint4* g0_prev;
   uint16_t* g0_next;
   const uint4* g1_prev;
   uint16_t* g1_next;
@@ -61,12 +79,12 @@ struct VStepArgs {
 // MFMAs of the current two.
 __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const uint4* __restrict__ xp, int Lb,
                                            int w, int kk, f32x16& a0, f32x16& a1, f32x16& a2) {
-  uint4 wv[2][2][3][2];   // [buffer][step][gate][piece]
-  uint4 xv[2][2][2];      // [buffer][step][piece]
+  uint4 wv[2][VG_CH][3][2];   // [buffer][step][gate][piece]
+  uint4 xv[2][VG_CH][2];      // [buffer][step][piece]
   auto load_chunk = [&](int buf, int c) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int kq = 2 * (w + 4 * (2 * c + u)) + kk;
+    for (int u = 0; u < VG_CH; ++u) {
+      const int kq = 2 * (w + 4 * (VG_CH * c + u)) + kk;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         xv[buf][u][p] = xp[(int64_t)(p * 64 + kq) * Lb];
@@ -77,11 +95,11 @@ __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const u
   };
   load_chunk(0, 0);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c + 1 < 4) load_chunk((c + 1) & 1, c + 1);
+  for (int c = 0; c < 8 / VG_CH; ++c) {
+    if (c + 1 < 8 / VG_CH) load_chunk((c + 1) & 1, c + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < VG_CH; ++u) {
       const uint4 x0 = xv[c & 1][u][0], x1 = xv[c & 1][u][1];
       a0 = vg_mfma(wv[c & 1][u][0][0], x1, a0);
       a1 = vg_mfma(wv[c & 1][u][1][0], x1, a1);
@@ -98,8 +116,24 @@ __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const u
 }
 
 // grid: 8 * 2 * (Lb/32) * 2 blocks, 1-D (heavier layer-1 tiles first)   block: 512
-__global__ __launch_bounds__(512) void vgru_step_kernel(VStepArgs a) {
+__global__ __launch_bounds__(512, VG_OCC) void vgru_step_kernel(VStatic st, const VRun* __restrict__ run,
+                                                                int idx) {
   __shared__ float red[4][4][16][64];
+  const int t = run->t0 + idx;
+  if (t >= run->t_end) return;
+  VStepArgs a;
+  {
+    const int N = run->N;
+    a.L = run->L; a.Lb = run->Lb;
+    a.codes = (t < N) ? run->msa + (int64_t)t * a.L : nullptr;
+    a.do_l0 = (t < N);
+    a.do_l1 = (t >= 1);
+    const int p = t & 1;      // layer 0 reads parity t, writes t+1; layer 1 (step t-1) reads t+1, writes t
+    a.h0_prev = st.hT[0][p];     a.h0_next = st.hT[0][p ^ 1];
+    a.h1_prev = st.hT[1][p ^ 1]; a.h1_next = st.hT[1][p];
+    a.g0_prev = reinterpret_cast<const uint4*>(st.hH[0][p]);     a.g0_next = st.hH[0][p ^ 1];
+    a.g1_prev = reinterpret_cast<const uint4*>(st.hH[1][p ^ 1]); a.g1_next = st.hH[1][p];
+  }
   const int nbt = a.Lb >> 5;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int rest = slot >> 1;
@@ -119,15 +153,15 @@ __global__ __launch_bounds__(512) void vgru_step_kernel(VStepArgs a) {
   for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_t[r] = 0.f; }
 
   if (part == 0) {
-    k512_steps(a.wh[layer] + (j0 + li), gprev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
+    k512_steps(st.wh[layer] + (j0 + li), gprev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
   } else if (layer == 1) {
-    k512_steps(a.wx[1] + (j0 + li), a.g0_prev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
+    k512_steps(st.wx[1] + (j0 + li), a.g0_prev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
   } else if (w == 0) {
     // layer 0 input: one-hot of the residue code (value 1024 = the state scale), K = 32 (rows 22..31
     // of the packed weights are 0)
     const int b = b0 + li;
     const int code = (b < a.L) ? (int)a.codes[b] : 0;
-    const uint4* wp = a.wx[0] + (j0 + li);
+    const uint4* wp = st.wx[0] + (j0 + li);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int kq = 2 * s + kk;
@@ -179,8 +213,8 @@ __global__ __launch_bounds__(512) void vgru_step_kernel(VStepArgs a) {
   }
   __syncthreads();
   if (part != 0) return;
-  const float* bias = a.bias[layer];
-  const float inv = a.inv_scale[layer];
+  const float* bias = st.bias[layer];
+  const float inv = st.inv_scale[layer];
   float* hnext = (layer == 0) ? a.h0_next : a.h1_next;
   uint16_t* gnext = (layer == 0) ? a.g0_next : a.g1_next;
   const int j4 = j0 + 8 * w + 4 * kk;              // rows (4w+q): j = j4 + q, q = 0..3
@@ -230,39 +264,85 @@ __global__ __launch_bounds__(128) void vgru_out_kernel(const float* __restrict__
 }
 
 int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s) {
+  return gru_vertical_steps(c, d_msa, N, L, 0, N + 1, d_out, s);
+}
+
+__global__ void vgru_set_run_kernel(VRun* run, const uint8_t* msa, int N, int L, int Lb, int t0, int t_end) {
+  run->msa = msa; run->N = N; run->L = L; run->Lb = Lb; run->t0 = t0; run->t_end = t_end;
+}
+
+// A chain of `len` step-kernel nodes (idx = 0..len-1) for a given grid; built once per context and
+// grid size.  Replaying it costs one host call instead of `len` launches, and the gap between
+// dependent kernels is 1.8 us instead of 2.8 us (tools/ubench_launch.hip).
+static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
+  const int64_t key = ((int64_t)grid << 16) | len;
+  auto it = c->vgru_graphs.find(key);
+  if (it != c->vgru_graphs.end()) { *out = (hipGraphExec_t)it->second; return DMP_OK; }
+  const Weights& W = c->W;
+  VStatic st{};
+  for (int l = 0; l < 2; ++l) {
+    st.wx[l] = reinterpret_cast<const uint4*>(W.v_wx[l]);
+    st.wh[l] = reinterpret_cast<const uint4*>(W.v_wh[l]);
+    st.inv_scale[l] = W.v_inv_scale[l];
+    for (int p = 0; p < 2; ++p) { st.hT[l][p] = c->hT[l][p]; st.hH[l][p] = c->hH[l][p]; }
+  }
+  st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
+  const VRun* run = reinterpret_cast<const VRun*>(c->vgru_run);
+  hipGraph_t g;
+  DMP_HIP(hipGraphCreate(&g, 0));
+  hipGraphNode_t prev = nullptr;
+  for (int idx = 0; idx < len; ++idx) {
+    int idx_arg = idx;
+    void* params[3] = {(void*)&st, (void*)&run, (void*)&idx_arg};
+    hipKernelNodeParams kp{};
+    kp.func = (void*)vgru_step_kernel;
+    kp.gridDim = dim3(grid);
+    kp.blockDim = dim3(512);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = params;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    hipError_t e = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); return hip_fail(e, "hipGraphAddKernelNode", __FILE__, __LINE__); }
+    prev = node;
+  }
+  hipGraphExec_t ge;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+  c->vgru_graphs[key] = (void*)ge;
+  *out = ge;
+  return DMP_OK;
+}
+
+int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
+                       hipStream_t s) {
   const int Lb = round_up(L, 32);
   const size_t hbytes = sizeof(float) * WIDTH * Lb;
-  for (int l = 0; l < 2; ++l) {
-    DMP_HIP(hipMemsetAsync(c->hT[l][0], 0, hbytes, s));
-    DMP_HIP(hipMemsetAsync(c->hH[l][0], 0, hbytes, s));     // 2 pieces x 512 x Lb x 2 bytes
+  if (t_lo <= 0) {
+    t_lo = 0;
+    for (int l = 0; l < 2; ++l) {
+      DMP_HIP(hipMemsetAsync(c->hT[l][0], 0, hbytes, s));
+      DMP_HIP(hipMemsetAsync(c->hH[l][0], 0, hbytes, s));     // 2 pieces x 512 x Lb x 2 bytes
+    }
   }
-  const Weights& W = c->W;
-  VStepArgs a{};
-  for (int l = 0; l < 2; ++l) {
-    a.wx[l] = reinterpret_cast<const uint4*>(W.v_wx[l]);
-    a.wh[l] = reinterpret_cast<const uint4*>(W.v_wh[l]);
-    a.inv_scale[l] = W.v_inv_scale[l];
-  }
-  a.bias[0] = W.v_b0; a.bias[1] = W.v_b1;
-  a.L = L; a.Lb = Lb;
-  dim3 grid(8 * 2 * (Lb / 32) * 2);
-  for (int t = 0; t <= N; ++t) {
-    a.codes = (t < N) ? d_msa + (int64_t)t * L : nullptr;
-    a.do_l0 = (t < N);
-    a.do_l1 = (t >= 1);
-    a.h0_prev = c->hT[0][t & 1];
-    a.h0_next = c->hT[0][(t + 1) & 1];
-    a.h1_prev = c->hT[1][(t + 1) & 1];   // layer 1 runs step t-1: parity (t-1)&1
-    a.h1_next = c->hT[1][t & 1];
-    a.g0_prev = reinterpret_cast<const uint4*>(c->hH[0][t & 1]);
-    a.g0_next = c->hH[0][(t + 1) & 1];
-    a.g1_prev = reinterpret_cast<const uint4*>(c->hH[1][(t + 1) & 1]);
-    a.g1_next = c->hH[1][t & 1];
-    hipLaunchKernelGGL(vgru_step_kernel, grid, dim3(512), 0, s, a);
+  if (t_hi > N + 1) t_hi = N + 1;
+  const int grid = 8 * 2 * (Lb / 32) * 2;
+  VRun* run = reinterpret_cast<VRun*>(c->vgru_run);
+  for (int t = t_lo; t < t_hi;) {
+    const int len = (t_hi - t > VGRU_CHUNK / 2) ? VGRU_CHUNK : VGRU_CHUNK_SMALL;
+    hipGraphExec_t ge;
+    int rc = vgru_graph(c, grid, len, &ge);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vgru_set_run_kernel, dim3(1), dim3(1), 0, s, run, d_msa, N, L, Lb, t, t_hi);
+    DMP_HIP(hipGraphLaunch(ge, s));
+    t += len;
   }
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vgru_out_kernel, dim3(L), dim3(128), 0, s, c->hT[1][N & 1], Lb, d_out);
-  DMP_LAUNCH_CHECK();
+  if (t_hi == N + 1) {
+    hipLaunchKernelGGL(vgru_out_kernel, dim3(L), dim3(128), 0, s, c->hT[1][N & 1], Lb, d_out);
+    DMP_LAUNCH_CHECK();
+  }
   return DMP_OK;
 }
 

@@ -169,6 +169,27 @@ int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const fl
 int dmp_predict_pass(dmp_ctx* ctx, void* stream);
 int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream);
 
+/* Finer issue granularity for a throughput scheduler.  dmp_predict_begin_units validates and
+ * records the arguments without enqueueing anything; the prediction is then a sequence of units
+ * handed out by dmp_predict_issue_unit: first the front end in chunks of about 2 ms of GPU work
+ * (sequence weights + covariance; the inverse, 6 block steps at a time, then contacts; the
+ * vertical GRU, 128 alignment rows at a time; sequence GRU + static stem), then 18 units per pass:
+ * unit 0 = recycled distance map + stem update, units 1..16 = residual block k (its conv5x5 takes
+ * the lane), unit 17 = head + Gram matrix + MDS + coordinate GRU + best-of update.
+ * dmp_predict_begin = begin_units + all front-end units; dmp_predict_pass = the remaining units of
+ * the current pass.  dmp_predict_next_unit tells what the next dmp_predict_issue_unit would
+ * enqueue; dmp_ctx_pending returns how many issued units have not completed on the GPU (0, 1, or 2
+ * for "two or more"; negative on error), so a scheduler can hand the lane only to contexts whose
+ * next convolution can start at once and keep its own issue loop from running far ahead. */
+#define DMP_UNIT_NONE 0   /* every pass of this prediction was issued: call dmp_predict_end */
+#define DMP_UNIT_LIGHT 1  /* no convolution in the unit */
+#define DMP_UNIT_CONV 2   /* residual block: one lane turn */
+int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L,
+                            const float* d_template_ca, int Lt, int nloops, int refine_steps);
+int dmp_predict_next_unit(const dmp_ctx* ctx);
+int dmp_predict_issue_unit(dmp_ctx* ctx, void* stream);
+int dmp_ctx_pending(dmp_ctx* ctx);
+
 /* Throughput mode: contexts of ONE process that run on different streams may share a lane.  The
  * machine-filling conv5x5 launches of all contexts on a lane then take turns (cross-stream events)
  * while every other kernel of one target overlaps the convolutions of another.  All contexts of

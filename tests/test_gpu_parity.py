@@ -358,6 +358,63 @@ def test_end_to_end_with_refinement_within_noise_floor(st):
     assert np.abs(confs.cpu().numpy() - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
 
 
+def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
+    """The unit-granular scheduler (3 engines, shared lane, more targets than engines, mixed sizes)
+    returns bit-identical results to one engine running the same targets one after the other, and
+    the goldens' tolerances hold."""
+    from dmpfold2_amd.predict import Pipeline
+    names = ["pf10963_n0_m0", "synth_L40_N64_n2_m0", "synth_L30_N1_n1_m3", "pf10963_n2_m5",
+             "synth_L40_N64_n2_m0", "pf10963_n0_m0", "synth_L30_N1_n1_m3"]
+    iters = {"pf10963_n0_m0": (0, 0), "synth_L40_N64_n2_m0": (2, 0), "synth_L30_N1_n1_m3": (1, 3),
+             "pf10963_n2_m5": (2, 5)}
+    gs = [load_golden(n) for n in names]
+    dev = torch.device("cuda:0")
+    pipe = Pipeline(dev, 128, 3000, synth_sd, streams=3)
+    tickets = [pipe.submit(torch.from_numpy(np.ascontiguousarray(g["alnmat"])).to(dev), *iters[n])
+               for n, g in zip(names, gs)]
+    pipe.drain()
+    pipe.sync_check()
+    for n, g, t in zip(names, gs, tickets):
+        coords, confs = pipe.result(t)
+        ref_c, ref_f = st_engine.eng.predict(g["alnmat"], None, *iters[n])
+        st_engine.eng.sync_check()
+        assert torch.equal(coords, ref_c) and torch.equal(confs, ref_f), n
+        if iters[n][1] == 0:
+            assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= 1e-3
+    pipe.close()
+
+
+def test_unit_api_contract(st_engine):
+    """dmp_predict_next_unit / issue_unit: 18 units per pass, blocks are the conv units, pass == units."""
+    eng = st_engine.eng
+    lib = eng.lib
+    g = load_golden("synth_L40_N64_n2_m0")
+    ref_c, ref_f = eng.predict(g["alnmat"], None, 2, 0)
+    eng.sync_check()
+    d_msa = torch.from_numpy(np.ascontiguousarray(g["alnmat"])).cuda()
+    n, L = d_msa.shape
+    coords = torch.empty((L, 5, 3), device="cuda")
+    confs = torch.empty((L,), device="cuda")
+    s = eng.stream()
+    assert lib.dmp_predict_begin_units(eng.ctx, d_msa.data_ptr(), n, L, None, 0, 2, 0) == 0
+    assert lib.dmp_predict_pass(eng.ctx, s) < 0                # front end still outstanding
+    kinds = []
+    while True:
+        k = lib.dmp_predict_next_unit(eng.ctx)
+        if k == 0:
+            break
+        kinds.append(k)
+        assert lib.dmp_predict_issue_unit(eng.ctx, s) == 0
+    # front end of a 64 x 40 alignment: weights + covariance, 7 inverse block steps in 2 chunks,
+    # 65 vertical-GRU launches in 1 chunk, sequence GRU + static stem
+    assert kinds == [1] * 5 + ([1] + [2] * 16 + [1]) * 3
+    assert lib.dmp_predict_issue_unit(eng.ctx, s) < 0          # nothing left to issue
+    assert lib.dmp_predict_end(eng.ctx, coords.data_ptr(), confs.data_ptr(), s) == 0
+    eng.sync_check()
+    assert lib.dmp_ctx_pending(eng.ctx) == 0
+    assert torch.equal(coords, ref_c) and torch.equal(confs, ref_f)
+
+
 def test_python_api_and_cli(weights_file, tmp_path):
     from dmpfold2_amd import aln_to_coords, run_dmpfold
     g = load_golden("pf10963_n0_m0")
