@@ -318,7 +318,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   c->max_N = max_N;
   c->max_passes = 128;
   const int64_t L = max_L, N = max_N, D = NS * L, LL = L * L;
-  const int64_t Lb = round_up(max_L, 32), P = act_pitch(max_L), T = act_tiles(max_L);
+  const int64_t Lb = round_up(max_L, 64), P = act_pitch(max_L), T = act_tiles(max_L);   // 64 = vertical-GRU column tile
   int rc = 0;
 #define A_(field, count) if (!rc) rc = dev_alloc(c->allocs, c->bytes, &c->field, (count))
   A_(msa_words, N * cdiv64(L, 4));

@@ -134,9 +134,17 @@ __global__ __launch_bounds__(256, CH_OCC) void conv5x5_f16x3_kernel(const uint16
     const int yy = r2 / CH_PITCH;
     int xx = r2 % CH_PITCH;
     xx = xx < CH_HALO ? xx : 0;                     // pad slots re-read a valid pixel
+#ifdef CH_EXP_SAMETILE      // traffic experiment only: every workgroup reads the first tile's halo
+    in_src[e] = (int)(((int64_t)(p * 16 + cg) * P + yy) * P + xx);
+#else
     in_src[e] = (int)(((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx);
+#endif
   }
+#ifdef CH_EXP_SAMEW         // traffic experiment only: every workgroup streams the first split's weights
+  const uint4* wq4 = reinterpret_cast<const uint4*>(wq) +
+#else
   const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 25 * 4 * CH_WSLOT +
+#endif
                      (int64_t)wave * CH_WSLOT + lane;
 
   int b_off[8];

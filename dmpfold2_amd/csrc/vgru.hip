@@ -18,12 +18,15 @@
 //   state    hH[piece 2][k/8 = 64][Lb][8]        f16     B operand;  written by the epilogue
 //            hP[j/4 = 128][Lb][4]                f32     the state itself, for h' = (h - n) z + n
 //
-// Workgroup = 8 waves on one (32 hidden x 32 column) tile: waves 0-3 split K of the recurrent
-// product W_hh h, waves 4-7 split K of the input product (layer 1: W_ih h0; layer 0: the one-hot
-// input generated in registers, K = 22 -> 32, wave 4 only).  The K slices are summed through LDS
-// and waves 0-3 apply the gate maths (ATen gru_cell: h' = (h - n) z + n).
+// Workgroup = 8 waves = two groups of four, each group one K = 512 product on a (32 hidden x 32
+// column) tile split four ways (layer 1: recurrent and input product of one tile; layer 0: the
+// recurrent products of two tiles, the K = 22 -> 32 one-hot input product generated in registers by
+// wave 0 of the group).  The K slices are summed through LDS behind one barrier and four waves per
+// tile apply the gate maths (ATen gru_cell: h' = (h - n) z + n).
 // Block b runs on XCD b % 8; XCD x owns hidden tiles 2x, 2x+1 of both layers, so the weights it
 // streams every step (1.6 MB) stay in its 4 MB L2.
+// The N + 1 dependent launches are replayed from hipGraph chains of 128 (or 16) step nodes; what
+// changes between chunks lives in a small device record (VRun) written by a 1-thread kernel.
 #include "common.h"
 
 namespace dmp {
@@ -60,34 +63,36 @@ struct VRun {
   int t0, t_end;            // node idx of the chunk runs time step t = t0 + idx if t < t_end
 };
 
-struct VStepArgs {          // the view of one time step the kernel body works with (scalars only:
-  const uint8_t* codes;     // row t of the alignment (L bytes) or nullptr;   arrays would go to scratch)
-  const float* h0_prev;
-  float* h0_next;
-  const float* h1_prev;
-  float* h1_next;
-  const uint4* g0_prev;
-  uint16_t* g0_next;
-  const uint4* g1_prev;
-  uint16_t* g1_next;
-  int L, Lb;
-  int do_l0, do_l1;
-};
+
+#ifndef VG_NSUB_N
+#define VG_NSUB_N 1
+#endif
+constexpr int VG_NSUB = VG_NSUB_N;     // 32-column subtiles per wave: the weight operands are reused VG_NSUB times
+constexpr int VG_TB = 32 * VG_NSUB;    // columns per tile
+
+struct VAcc { f32x16 r[VG_NSUB], z[VG_NSUB], t[VG_NSUB]; };
 
 // One wave's quarter of a K = 512 contraction: MFMA steps s = w, w+4, ..., w+28 (16 k each), three
-// gate accumulators.  Hand-staged: the 16 loads of the next two steps are issued before the 18
-// MFMAs of the current two.
+// gate accumulators per column subtile.  Hand-staged: the loads of the next chunk are issued before
+// the MFMAs of the current one.
+// Measured at L = 300 (240 workgroups, 12.3 us per step): the same kernel without MFMAs takes as
+// long; with all loads redirected to one cache line 7.6 us.  A CU sustains about 50 GB/s of L1
+// misses here whatever the request pattern (rotating the k order per workgroup changes nothing), so
+// the step time follows the bytes one CU has to pull: 64-column tiles (VG_NSUB_N = 2: weights
+// reused from registers, 0.6x the total L2 traffic, but half as many workgroups pulling 1.25x the
+// bytes each) run 18 us per step.
 __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const uint4* __restrict__ xp, int Lb,
-                                           int w, int kk, f32x16& a0, f32x16& a1, f32x16& a2) {
-  uint4 wv[2][VG_CH][3][2];   // [buffer][step][gate][piece]
-  uint4 xv[2][VG_CH][2];      // [buffer][step][piece]
+                                           int w, int kk, VAcc& A) {
+  uint4 wv[2][VG_CH][3][2];          // [buffer][step][gate][piece]
+  uint4 xv[2][VG_CH][VG_NSUB][2];    // [buffer][step][subtile][piece]
   auto load_chunk = [&](int buf, int c) {
 #pragma unroll
     for (int u = 0; u < VG_CH; ++u) {
       const int kq = 2 * (w + 4 * (VG_CH * c + u)) + kk;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        xv[buf][u][p] = xp[(int64_t)(p * 64 + kq) * Lb];
+#pragma unroll
+        for (int n = 0; n < VG_NSUB; ++n) xv[buf][u][n][p] = xp[(int64_t)(p * 64 + kq) * Lb + 32 * n];
 #pragma unroll
         for (int g = 0; g < 3; ++g) wv[buf][u][g][p] = wp[(int64_t)((p * 3 + g) * 64 + kq) * 512];
       }
@@ -100,159 +105,188 @@ __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const u
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < VG_CH; ++u) {
-      const uint4 x0 = xv[c & 1][u][0], x1 = xv[c & 1][u][1];
-      a0 = vg_mfma(wv[c & 1][u][0][0], x1, a0);
-      a1 = vg_mfma(wv[c & 1][u][1][0], x1, a1);
-      a2 = vg_mfma(wv[c & 1][u][2][0], x1, a2);
-      a0 = vg_mfma(wv[c & 1][u][0][1], x0, a0);
-      a1 = vg_mfma(wv[c & 1][u][1][1], x0, a1);
-      a2 = vg_mfma(wv[c & 1][u][2][1], x0, a2);
-      a0 = vg_mfma(wv[c & 1][u][0][0], x0, a0);
-      a1 = vg_mfma(wv[c & 1][u][1][0], x0, a1);
-      a2 = vg_mfma(wv[c & 1][u][2][0], x0, a2);
+#pragma unroll
+      for (int n = 0; n < VG_NSUB; ++n) {
+        const uint4 x0 = xv[c & 1][u][n][0], x1 = xv[c & 1][u][n][1];
+        A.r[n] = vg_mfma(wv[c & 1][u][0][0], x1, A.r[n]);
+        A.z[n] = vg_mfma(wv[c & 1][u][1][0], x1, A.z[n]);
+        A.t[n] = vg_mfma(wv[c & 1][u][2][0], x1, A.t[n]);
+        A.r[n] = vg_mfma(wv[c & 1][u][0][1], x0, A.r[n]);
+        A.z[n] = vg_mfma(wv[c & 1][u][1][1], x0, A.z[n]);
+        A.t[n] = vg_mfma(wv[c & 1][u][2][1], x0, A.t[n]);
+        A.r[n] = vg_mfma(wv[c & 1][u][0][0], x0, A.r[n]);
+        A.z[n] = vg_mfma(wv[c & 1][u][1][0], x0, A.z[n]);
+        A.t[n] = vg_mfma(wv[c & 1][u][2][0], x0, A.t[n]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// grid: 8 * 2 * (Lb/32) * 2 blocks, 1-D (heavier layer-1 tiles first)   block: 512
+constexpr int VG_LDS_BYTES = (8 * 3 + 2) * 16 * 64 * 4;   // 106496: per-wave partial sums + layer-0 input part
+
+// column pitch of the state buffers / number of workgroups of a step: per XCD 2 hidden tiles x
+// (nbt layer-1 tiles + ceil(nbt/2) layer-0 pairs)
+__host__ __device__ inline int vgru_pitch(int L) { return (L + VG_TB - 1) / VG_TB * VG_TB; }
+__host__ __device__ inline int vgru_grid(int Lb) {
+  const int nbt = Lb / VG_TB;
+  return 8 * 2 * (nbt + ((nbt + 1) >> 1));
+}
+
+// Every workgroup is two groups of four waves, each group one K = 512 product split four ways on a
+// (32 hidden x 64 column) tile:
+//   layer 1:  group 0 = W_hh h1, group 1 = W_ih h0 of the SAME tile;
+//   layer 0:  group g = W_hh h0 of column tile 2p+g (two tiles per workgroup); the K = 32 one-hot
+//             input product of a tile is done by wave 0 of its group.
+// All workgroups therefore carry the same load (8 waves x 8 MFMA steps x 2 subtiles); at L = 300
+// the 128 of them run as a single round.  Per column subtile: every wave stores its partial sums,
+// barrier, four waves per tile add them up and apply the gate maths.
+// grid: vgru_grid(Lb)   block: 512   dynamic LDS: VG_LDS_BYTES
 __global__ __launch_bounds__(512, VG_OCC) void vgru_step_kernel(VStatic st, const VRun* __restrict__ run,
                                                                 int idx) {
-  __shared__ float red[4][4][16][64];
+  extern __shared__ __attribute__((aligned(16))) float vg_red[];   // [8 waves][3][16][64] | [2 groups][16][64]
   const int t = run->t0 + idx;
   if (t >= run->t_end) return;
-  VStepArgs a;
-  {
-    const int N = run->N;
-    a.L = run->L; a.Lb = run->Lb;
-    a.codes = (t < N) ? run->msa + (int64_t)t * a.L : nullptr;
-    a.do_l0 = (t < N);
-    a.do_l1 = (t >= 1);
-    const int p = t & 1;      // layer 0 reads parity t, writes t+1; layer 1 (step t-1) reads t+1, writes t
-    a.h0_prev = st.hT[0][p];     a.h0_next = st.hT[0][p ^ 1];
-    a.h1_prev = st.hT[1][p ^ 1]; a.h1_next = st.hT[1][p];
-    a.g0_prev = reinterpret_cast<const uint4*>(st.hH[0][p]);     a.g0_next = st.hH[0][p ^ 1];
-    a.g1_prev = reinterpret_cast<const uint4*>(st.hH[1][p ^ 1]); a.g1_next = st.hH[1][p];
-  }
-  const int nbt = a.Lb >> 5;
+  const int N = run->N, L = run->L, Lb = run->Lb;
+  const int nbt = Lb / VG_TB, nbp = (nbt + 1) >> 1;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int rest = slot >> 1;
-  const int layer = 1 - rest / nbt;
-  if (layer == 0 && !a.do_l0) return;
-  if (layer == 1 && !a.do_l1) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int part = wave >> 2, w = wave & 3;
+  const int rest = slot >> 1;                       // [0, nbt): layer 1 tiles, [nbt, nbt + nbp): layer 0 pairs
+  const int layer = rest < nbt ? 1 : 0;
+  if (layer == 0 && !(t < N)) return;
+  if (layer == 1 && !(t >= 1)) return;
+  const int par = t & 1;      // layer 0 reads parity t, writes t+1; layer 1 (step t-1) reads t+1, writes t
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, w = wave & 3;
   const int kk = lane >> 5, li = lane & 31;
-  const int b0 = (rest % nbt) * 32, j0 = (2 * xcd + (slot & 1)) * 32;
-  const int Lb = a.Lb;
-  const float* hprev = (layer == 0) ? a.h0_prev : a.h1_prev;
-  const uint4* gprev = (layer == 0) ? a.g0_prev : a.g1_prev;
+  const int j0 = (2 * xcd + (slot & 1)) * 32;
+  const int bt = layer ? rest : 2 * (rest - nbt) + grp;      // this group's column tile
+  const bool valid = bt < nbt;                               // odd tile count: the last pair is half empty
+  const int b0 = bt * VG_TB;
 
-  f32x16 acc_r, acc_z, acc_t;       // third = W_hn h (part 0) or W_in x (part 1)
+  VAcc A;                                 // A.t = W_hn h (recurrent groups) or W_in x (layer-1 input group)
+  f32x16 acc_in[VG_NSUB];                 // layer 0, wave 0 of a group: W_in x of the one-hot input
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_t[r] = 0.f; }
+  for (int n = 0; n < VG_NSUB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { A.r[n][r] = 0.f; A.z[n][r] = 0.f; A.t[n][r] = 0.f; acc_in[n][r] = 0.f; }
 
-  if (part == 0) {
-    k512_steps(st.wh[layer] + (j0 + li), gprev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
-  } else if (layer == 1) {
-    k512_steps(st.wx[1] + (j0 + li), a.g0_prev + (b0 + li), Lb, w, kk, acc_r, acc_z, acc_t);
-  } else if (w == 0) {
-    // layer 0 input: one-hot of the residue code (value 1024 = the state scale), K = 32 (rows 22..31
-    // of the packed weights are 0)
-    const int b = b0 + li;
-    const int code = (b < a.L) ? (int)a.codes[b] : 0;
-    const uint4* wp = st.wx[0] + (j0 + li);
+  if (layer == 1) {
+    const uint4* wp = (grp == 0 ? st.wh[1] : st.wx[1]) + (j0 + li);
+    const uint4* xp = reinterpret_cast<const uint4*>(grp == 0 ? st.hH[1][par ^ 1] : st.hH[0][par]) + (b0 + li);
+    k512_steps(wp, xp, Lb, w, kk, A);
+  } else if (valid) {
+    k512_steps(st.wh[0] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[0][par]) + (b0 + li), Lb, w, kk, A);
+    if (w == 0) {
+      // layer 0 input: one-hot of the residue code (value 1024 = the state scale), K = 32 (rows
+      // 22..31 of the packed weights are 0)
+      const uint4* wp = st.wx[0] + (j0 + li);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int kq = 2 * s + kk;
-      const int d = code - 8 * kq;                       // position of the hot element among this lane's 8 k
-      const unsigned hot = (d >= 0 && d < 8) ? (0x6400u << (16 * (d & 1))) : 0u;
-      uint4 x;
-      x.x = (d >> 1) == 0 ? hot : 0u;
-      x.y = (d >> 1) == 1 ? hot : 0u;
-      x.z = (d >> 1) == 2 ? hot : 0u;
-      x.w = (d >> 1) == 3 ? hot : 0u;
-      acc_r = vg_mfma(wp[(int64_t)((1 * 3 + 0) * 4 + kq) * 512], x, acc_r);
-      acc_z = vg_mfma(wp[(int64_t)((1 * 3 + 1) * 4 + kq) * 512], x, acc_z);
-      acc_t = vg_mfma(wp[(int64_t)((1 * 3 + 2) * 4 + kq) * 512], x, acc_t);
-      acc_r = vg_mfma(wp[(int64_t)((0 * 3 + 0) * 4 + kq) * 512], x, acc_r);
-      acc_z = vg_mfma(wp[(int64_t)((0 * 3 + 1) * 4 + kq) * 512], x, acc_z);
-      acc_t = vg_mfma(wp[(int64_t)((0 * 3 + 2) * 4 + kq) * 512], x, acc_t);
+      for (int s = 0; s < 2; ++s) {
+        const int kq = 2 * s + kk;
+        uint4 wq[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) wq[g][p] = wp[(int64_t)((p * 3 + g) * 4 + kq) * 512];
+#pragma unroll
+        for (int n = 0; n < VG_NSUB; ++n) {
+          const int b = b0 + 32 * n + li;
+          const int code = (b < L) ? (int)run->msa[(int64_t)t * L + b] : 0;
+          const int d = code - 8 * kq;                   // position of the hot element among this lane's 8 k
+          const unsigned hot = (d >= 0 && d < 8) ? (0x6400u << (16 * (d & 1))) : 0u;
+          uint4 x;
+          x.x = (d >> 1) == 0 ? hot : 0u;
+          x.y = (d >> 1) == 1 ? hot : 0u;
+          x.z = (d >> 1) == 2 ? hot : 0u;
+          x.w = (d >> 1) == 3 ? hot : 0u;
+          A.r[n] = vg_mfma(wq[0][1], x, A.r[n]);
+          A.z[n] = vg_mfma(wq[1][1], x, A.z[n]);
+          acc_in[n] = vg_mfma(wq[2][1], x, acc_in[n]);
+          A.r[n] = vg_mfma(wq[0][0], x, A.r[n]);
+          A.z[n] = vg_mfma(wq[1][0], x, A.z[n]);
+          acc_in[n] = vg_mfma(wq[2][0], x, acc_in[n]);
+        }
+      }
     }
   }
 
-  // ---- stage 1: the input-product waves hand their partial sums to the recurrent-product waves
-  if (part == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      red[w][0][r][lane] = acc_r[r];
-      red[w][1][r][lane] = acc_z[r];
-      red[w][2][r][lane] = acc_t[r];
-    }
-  }
-  __syncthreads();
-  f32x16 acc_in;
-  if (part == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc_r[r] += red[w][0][r][lane];
-      acc_z[r] += red[w][1][r][lane];
-      acc_in[r] = red[w][2][r][lane];
-    }
-  }
-  __syncthreads();
-  // ---- stage 2: sum the four K slices, each wave finishing a quarter of the tile
-  if (part == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      red[w][0][r][lane] = acc_r[r];
-      red[w][1][r][lane] = acc_z[r];
-      red[w][2][r][lane] = acc_in[r];
-      red[w][3][r][lane] = acc_t[r];
-    }
-  }
-  __syncthreads();
-  if (part != 0) return;
+  const bool finisher = layer == 1 ? grp == 0 : valid;      // layer 1: waves 0-3; layer 0: every valid group
   const float* bias = st.bias[layer];
   const float inv = st.inv_scale[layer];
-  float* hnext = (layer == 0) ? a.h0_next : a.h1_next;
-  uint16_t* gnext = (layer == 0) ? a.g0_next : a.g1_next;
+  const float* hprev = layer ? st.hT[1][par ^ 1] : st.hT[0][par];
+  float* hnext = layer ? st.hT[1][par] : st.hT[0][par ^ 1];
+  uint16_t* gnext = layer ? st.hH[1][par] : st.hH[0][par ^ 1];
   const int j4 = j0 + 8 * w + 4 * kk;              // rows (4w+q): j = j4 + q, q = 0..3
-  const int b = b0 + li;
   const float4 bR = *reinterpret_cast<const float4*>(bias + j4);
   const float4 bZ = *reinterpret_cast<const float4*>(bias + 512 + j4);
   const float4 bI = *reinterpret_cast<const float4*>(bias + 1024 + j4);
   const float4 bH = *reinterpret_cast<const float4*>(bias + 1536 + j4);
   const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
   const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
-  const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
-  const float4 hp4 = *reinterpret_cast<const float4*>(hprev + hoff);
-  const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
-  float hn[4];
-  unsigned short q0[4], q1[4];
+  float* mine = vg_red + (int64_t)wave * (3 * 16 * 64);
+  float* red_in = vg_red + 8 * 3 * 16 * 64 + grp * (16 * 64);
+  const float* g0 = vg_red + (int64_t)(layer ? 0 : 4 * grp) * (3 * 16 * 64);   // the recurrent group's 4 waves
+  const float* g1 = vg_red + (int64_t)4 * (3 * 16 * 64);                        // layer 1: the input group's
+
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = w * 4 + q;
-    float s[4];
+  for (int n = 0; n < VG_NSUB; ++n) {
+    // ---- every wave stores its partial sums of subtile n; barrier; four waves per tile finish it
+    if (n > 0) __syncthreads();
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      s[g] = ((red[0][g][r][lane] + red[1][g][r][lane]) + (red[2][g][r][lane] + red[3][g][r][lane])) * inv;
-    const float rg = vsigmoid(s[0] + br[q]);
-    const float zg = vsigmoid(s[1] + bz[q]);
-    const float ng = tanhf((s[2] + bi[q]) + rg * (s[3] + bh[q]));
-    hn[q] = (hp[q] - ng) * zg + ng;
-    const float hs = hn[q] * VGRU_STATE_SCALE;
-    const _Float16 p0 = (_Float16)hs;
-    const _Float16 p1 = (_Float16)(hs - (float)p0);
-    q0[q] = __builtin_bit_cast(unsigned short, p0);
-    q1[q] = __builtin_bit_cast(unsigned short, p1);
+    for (int r = 0; r < 16; ++r) {
+      mine[(0 * 16 + r) * 64 + lane] = A.r[n][r];
+      mine[(1 * 16 + r) * 64 + lane] = A.z[n][r];
+      mine[(2 * 16 + r) * 64 + lane] = A.t[n][r];
+    }
+    if (layer == 0 && w == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red_in[r * 64 + lane] = acc_in[n][r];
+    }
+    __syncthreads();
+    if (!finisher) continue;
+    const int b = b0 + 32 * n + li;
+    const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
+    const float4 hp4 = *reinterpret_cast<const float4*>(hprev + hoff);
+    const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+    float hn[4];
+    unsigned short q0[4], q1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = w * 4 + q;
+      float s[4];      // r, z, in, hn
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float* p = g0 + (g * 16 + r) * 64 + lane;
+        s[g == 2 ? 3 : g] = (p[0] + p[3 * 16 * 64]) + (p[2 * 3 * 16 * 64] + p[3 * 3 * 16 * 64]);
+      }
+      if (layer) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const float* p = g1 + (g * 16 + r) * 64 + lane;
+          const float v = (p[0] + p[3 * 16 * 64]) + (p[2 * 3 * 16 * 64] + p[3 * 3 * 16 * 64]);
+          if (g == 2) s[2] = v; else s[g] += v;
+        }
+      } else {
+        s[2] = red_in[r * 64 + lane];
+      }
+      const float rg = vsigmoid(s[0] * inv + br[q]);
+      const float zg = vsigmoid(s[1] * inv + bz[q]);
+      const float ng = tanhf((s[2] * inv + bi[q]) + rg * (s[3] * inv + bh[q]));
+      hn[q] = (hp[q] - ng) * zg + ng;
+      const float hs = hn[q] * VGRU_STATE_SCALE;
+      const _Float16 p0 = (_Float16)hs;
+      const _Float16 p1 = (_Float16)(hs - (float)p0);
+      q0[q] = __builtin_bit_cast(unsigned short, p0);
+      q1[q] = __builtin_bit_cast(unsigned short, p1);
+    }
+    *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
+    *reinterpret_cast<uint2*>(gnext + goff) =
+        make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
+    *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
+        make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
   }
-  *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-  const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
-  *reinterpret_cast<uint2*>(gnext + goff) =
-      make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
-  *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
-      make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
 }
 
 // out[l][j] = hP[j/4][l][j%4]
@@ -288,6 +322,8 @@ static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
   }
   st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
   const VRun* run = reinterpret_cast<const VRun*>(c->vgru_run);
+  DMP_HIP(hipFuncSetAttribute((const void*)vgru_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              VG_LDS_BYTES));
   hipGraph_t g;
   DMP_HIP(hipGraphCreate(&g, 0));
   hipGraphNode_t prev = nullptr;
@@ -298,7 +334,7 @@ static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
     kp.func = (void*)vgru_step_kernel;
     kp.gridDim = dim3(grid);
     kp.blockDim = dim3(512);
-    kp.sharedMemBytes = 0;
+    kp.sharedMemBytes = VG_LDS_BYTES;
     kp.kernelParams = params;
     kp.extra = nullptr;
     hipGraphNode_t node;
@@ -317,7 +353,7 @@ static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
 
 int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
                        hipStream_t s) {
-  const int Lb = round_up(L, 32);
+  const int Lb = vgru_pitch(L);
   const size_t hbytes = sizeof(float) * WIDTH * Lb;
   if (t_lo <= 0) {
     t_lo = 0;
@@ -327,7 +363,7 @@ int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo,
     }
   }
   if (t_hi > N + 1) t_hi = N + 1;
-  const int grid = 8 * 2 * (Lb / 32) * 2;
+  const int grid = vgru_grid(Lb);
   VRun* run = reinterpret_cast<VRun*>(c->vgru_run);
   for (int t = t_lo; t < t_hi;) {
     const int len = (t_hi - t > VGRU_CHUNK / 2) ? VGRU_CHUNK : VGRU_CHUNK_SMALL;
