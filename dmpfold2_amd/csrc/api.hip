@@ -330,7 +330,8 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(cov, D * D);
   A_(gj_p, GJ_NB * GJ_NB);
   A_(gj_r, GJ_NB * D);
-  A_(gj_c, D * GJ_NB);
+  A_(gj_c, (int64_t)round_up((int)D, GJ_NB) * GJ_NB);
+  A_(gj_rt, (int64_t)round_up((int)D, GJ_NB) * GJ_NB);
   A_(contacts, LL);
   A_(x3, LL);
   A_(apc_sums, 2 * L + 1);

@@ -122,7 +122,8 @@ struct dmp_ctx {
   float* colmean = nullptr; // [21L]
   float* xc = nullptr;      // [N][21L]
   float* cov = nullptr;     // [D][D]
-  float *gj_p = nullptr, *gj_r = nullptr, *gj_c = nullptr;
+  float *gj_p = nullptr, *gj_r = nullptr;   // inverse of the diagonal block, row panel P A_k,:
+  float *gj_c = nullptr, *gj_rt = nullptr;  // column / row panels as k quads [32][Dp][4] (dca.hip)
   float* contacts = nullptr;  // [L][L]
   float* x3 = nullptr;
   double* apc_sums = nullptr;  // [2L+1]

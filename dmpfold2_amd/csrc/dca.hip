@@ -158,17 +158,142 @@ __global__ __launch_bounds__(256) void gj_diag_kernel(const float* __restrict__ 
   }
 }
 
-// C[i][kk] = A[i][k0+kk] (zero for rows inside the block); also zero R's block columns
-__global__ __launch_bounds__(256) void gj_panels_kernel(const float* __restrict__ A, int D, int k0,
-                                                        int bs, float* __restrict__ Cp,
-                                                        float* __restrict__ R) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)D * GJ_NB) return;
-  const int i = idx >> 7, kk = idx & 127;
-  const bool inblk = (i >= k0 && i < k0 + bs);
-  Cp[idx] = (kk < bs && !inblk) ? A[(int64_t)i * D + k0 + kk] : 0.f;
-  // R is [bs][D]; reuse the same index space: row kk, column i
-  if (kk < bs && inblk) R[(int64_t)kk * D + i] = 0.f;
+// Panels of a block step in the layout the trailing-update kernel loads with 16 bytes per lane:
+//   CT[k/4][i][4] = A[i][k0+k]  (column panel; zero for rows i inside the block and for k >= bs)
+//   RT[k/4][j][4] = R[k][j]     (row panel P A_k,: ; inside the block columns: P[k][j-k0], which makes
+//                                the trailing update of a zeroed block column produce -C P)
+// grid: Dp/64 blocks (64 rows / columns each)   block: 256
+__global__ __launch_bounds__(256) void gj_panels_kernel(const float* __restrict__ A, int D, int Dp, int k0,
+                                                        int bs, const float* __restrict__ P,
+                                                        const float* __restrict__ R,
+                                                        float4* __restrict__ CT, float4* __restrict__ RT) {
+  __shared__ float tile[64][GJ_NB + 1];
+  const int i0 = blockIdx.x * 64, tid = threadIdx.x;
+  for (int r = 0; r < 32; ++r) {                      // coalesced rows of the column panel
+    const int row = 2 * r + (tid >> 7), col = tid & 127, i = i0 + row;
+    const bool inblk = (i >= k0 && i < k0 + bs);
+    tile[row][col] = (i < D && col < bs && !inblk) ? A[(int64_t)i * D + k0 + col] : 0.f;
+  }
+  __syncthreads();
+  const int i = tid & 63;
+  const int gi = i0 + i;
+  const bool inblk = (gi >= k0 && gi < k0 + bs);
+  for (int it = 0; it < 8; ++it) {
+    const int q = (tid >> 6) + 4 * it;
+    CT[(int64_t)q * Dp + gi] = make_float4(tile[i][4 * q], tile[i][4 * q + 1], tile[i][4 * q + 2], tile[i][4 * q + 3]);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * q + e;
+      v[e] = (gi < D && k < bs) ? (inblk ? P[k * GJ_NB + (gi - k0)] : R[(int64_t)k * D + gi]) : 0.f;
+    }
+    RT[(int64_t)q * Dp + gi] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
+
+// Trailing update of a block step on the f32 matrix cores (exact: an MFMA chain is an fmaf chain):
+//   A[i][j] <- A[i][j] - sum_k C[i][k] R[k][j]     outside the block column,
+//   A[i][j] <-         - sum_k C[i][k] P[k][j-k0]  inside it (the old values are the panel C itself),
+// rows inside the block are left to gj_writeback_kernel.  K = 128; a workgroup owns a 128 x 128 tile
+// (wave = 64 x 64 = 2 x 2 MFMA blocks), operands come straight from the L2-resident panels with one
+// 16-byte load per lane and k quad (MFMA e of an octet pairs k = 8o+e with 8o+4+e: the two lane
+// halves load consecutive quads).
+// Measured at D = 6300 (2450 tiles): 142 us per update = 72 TFLOP/s (the generic gemm_kernel needed
+// 224 us for the two updates this replaces).  Knobs that measured the same or worse: deeper source-level
+// prefetch (the compiler schedules the loads itself; pinning them with scheduling barriers: 150-240
+// us), register budgets for 3-5 waves per SIMD (165 us), reading the tile before the MFMA chain
+// (GJT_PRELOAD: 168 us).  A CU pulls 64 KB of panel per wave and tile from L2; sharing the panels
+// through LDS is the next step.
+#ifndef GJT_PF
+#define GJT_PF 1        // k octets of operand loads in flight ahead of the MFMAs
+#endif
+#ifndef GJT_OCC
+#define GJT_OCC 2       // waves per SIMD the register budget is compiled for
+#endif
+#ifndef GJT_SCHED
+#define GJT_SCHED 0     // 1: pin the load / MFMA order with scheduling barriers
+#endif
+#ifndef GJT_PRELOAD
+#define GJT_PRELOAD 0   // 1: accumulators start at -A (tile read before the MFMA chain), 0: read-modify-write after it
+#endif
+// grid: (Dp/128)^2 blocks, row-block major   block: 256
+__global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __restrict__ A, int D, int Dp, int k0,
+                                                                   const float4* __restrict__ CT,
+                                                                   const float4* __restrict__ RT) {
+  const int nt = Dp >> 7;
+  const int tm = blockIdx.x / nt, tn = blockIdx.x % nt, kb = k0 >> 7;
+  if (tm == kb) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 5, li = lane & 31;
+  const int m0 = tm * 128 + (wave >> 1) * 64, n0 = tn * 128 + (wave & 1) * 64;
+  const bool blockcol = (tn == kb);
+  const float4* cp = CT + (int64_t)kk * Dp + m0 + li;
+  const float4* rp = RT + (int64_t)kk * Dp + n0 + li;
+  constexpr int PF = GJT_PF;
+  float4 av[2][PF][2], bv[2][PF][2];
+  auto load = [&](int buf, int c) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        av[buf][u][x] = cp[(int64_t)2 * (PF * c + u) * Dp + 32 * x];
+        bv[buf][u][x] = rp[(int64_t)2 * (PF * c + u) * Dp + 32 * x];
+      }
+  };
+  load(0, 0);
+  gj_f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + 32 * ni + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
+        acc[mi][ni][r] = (GJT_PRELOAD && !blockcol && row < D && col < D) ? -A[(int64_t)row * D + col] : 0.f;
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < 16 / PF; ++c) {
+    if (c + 1 < 16 / PF) load((c + 1) & 1, c + 1);
+#if GJT_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float4 a = av[c & 1][u][mi];
+        const float a4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float4 b = bv[c & 1][u][ni];
+          const float b4[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[mi][ni], 0, 0, 0);
+        }
+      }
+#if GJT_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + 32 * ni + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
+        if (row < D && col < D) {
+          float* p = A + (int64_t)row * D + col;
+          *p = GJT_PRELOAD ? -acc[mi][ni][r] : (blockcol ? 0.f : *p) - acc[mi][ni][r];
+        }
+      }
+    }
 }
 
 // A_k,: = R (outside the block), A_kk = P
@@ -187,7 +312,10 @@ int spd_inverse(dmp_ctx* c, float* A, int D, hipStream_t s) {
 }
 
 int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipStream_t s) {
-  float *P = c->gj_p, *R = c->gj_r, *Cp = c->gj_c;
+  float *P = c->gj_p, *R = c->gj_r;
+  const int Dp = round_up(D, GJ_NB);
+  float4* CT = reinterpret_cast<float4*>(c->gj_c);
+  float4* RT = reinterpret_cast<float4*>(c->gj_rt);
   for (int k0 = blk_lo * GJ_NB; k0 < D && k0 < blk_hi * GJ_NB; k0 += GJ_NB) {
     const int bs = std::min(GJ_NB, D - k0);
     hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(256), 0, s, A, D, k0, bs, P);
@@ -199,21 +327,11 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
     g.C = R; g.ldc = D; g.M = bs; g.N = D; g.K = bs; g.alpha = 1.f; g.beta = 0.f;
     int rc = gemm_f32(g, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)cdiv64((int64_t)D * GJ_NB, 256)),
-                       dim3(256), 0, s, A, D, k0, bs, Cp, R);
+    hipLaunchKernelGGL(gj_panels_kernel, dim3(Dp / 64), dim3(256), 0, s, A, D, Dp, k0, bs, P, R, CT, RT);
     DMP_LAUNCH_CHECK();
-    // A -= C * R
-    g.A = Cp; g.sam = GJ_NB; g.sak = 1;
-    g.B = R; g.sbk = D; g.sbn = 1;
-    g.C = A; g.ldc = D; g.M = D; g.N = D; g.K = bs; g.alpha = -1.f; g.beta = 1.f;
-    rc = gemm_f32(g, s);
-    if (rc) return rc;
-    // A[:, block] = -C * P
-    g.A = Cp; g.sam = GJ_NB; g.sak = 1;
-    g.B = P; g.sbk = GJ_NB; g.sbn = 1;
-    g.C = A + k0; g.ldc = D; g.M = D; g.N = bs; g.K = bs; g.alpha = -1.f; g.beta = 0.f;
-    rc = gemm_f32(g, s);
-    if (rc) return rc;
+    // A -= C R outside the block column, A[:, block] = -C P inside it
+    hipLaunchKernelGGL(gj_trailing_kernel, dim3((Dp / 128) * (Dp / 128)), dim3(256), 0, s, A, D, Dp, k0, CT, RT);
+    DMP_LAUNCH_CHECK();
     hipLaunchKernelGGL(gj_writeback_kernel, dim3(cdiv(D, 256), bs), dim3(256), 0, s, A, D, k0, bs,
                        R, P);
     DMP_LAUNCH_CHECK();

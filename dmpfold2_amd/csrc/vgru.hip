@@ -148,9 +148,9 @@ __global__ __launch_bounds__(512, VG_OCC) void vgru_step_kernel(VStatic st, cons
   const int t = run->t0 + idx;
   if (t >= run->t_end) return;
   const int N = run->N, L = run->L, Lb = run->Lb;
-  const int nbt = Lb / VG_TB, nbp = (nbt + 1) >> 1;
+  const int nbt = Lb / VG_TB;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int rest = slot >> 1;                       // [0, nbt): layer 1 tiles, [nbt, nbt + nbp): layer 0 pairs
+  const int rest = slot >> 1;                       // [0, nbt): layer 1 tiles, [nbt, nbt + ceil(nbt/2)): layer 0 pairs
   const int layer = rest < nbt ? 1 : 0;
   if (layer == 0 && !(t < N)) return;
   if (layer == 1 && !(t >= 1)) return;

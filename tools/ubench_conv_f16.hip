@@ -50,6 +50,7 @@ static void cpu_ref(const std::vector<float>& x, const std::vector<float>& w, co
 int main(int argc, char** argv) {
   const int Lt = argc > 1 ? atoi(argv[1]) : 24;
   const int Lb = argc > 2 ? atoi(argv[2]) : 300;
+  const int lds_bytes = argc > 3 ? atoi(argv[3]) : CONVH_LDS_BYTES;   // > 80 KB forces 1 workgroup per CU
   std::vector<float> w((size_t)512 * 128 * 25), b(512);
   unsigned s = 777u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffffff) / 16777216.f - 0.5f; };
@@ -62,8 +63,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(d_wq, wq.data(), wq.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(d_b, b.data(), 512 * 4, hipMemcpyHostToDevice));
   CK(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                         CONVH_LDS_BYTES));
-  printf("weight scale 2^%d, LDS %d B per workgroup\n", (int)std::log2(scale), CONVH_LDS_BYTES);
+                         lds_bytes));
+  printf("weight scale 2^%d, LDS %d B per workgroup\n", (int)std::log2(scale), lds_bytes);
   for (int L : {Lt, Lb}) {
     const int P = act_pitch(L), tiles = act_tiles(L);
     std::vector<float> x((size_t)128 * L * L);
@@ -83,7 +84,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_xs, xs.data(), xs.size() * 2, hipMemcpyHostToDevice));
     const int nwork = tiles * tiles * 4, grid = (nwork + 7) / 8 * 8;
     auto launch = [&]() {
-      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(grid), dim3(256), CONVH_LDS_BYTES, 0, d_xs, d_wq, d_b,
+      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(grid), dim3(256), lds_bytes, 0, d_xs, d_wq, d_b,
                          1.0f / scale, L, P, tiles, nwork, d_u, d_part);
     };
     launch();
