@@ -116,8 +116,23 @@ static int pack_weights(dmp_ctx* c) {
     DMP_HIP(hipMemcpy(*out, q.data(), sizeof(uint16_t) * q.size(), hipMemcpyHostToDevice));
     return DMP_OK;
   };
+  // The kernel feeds layer 0 the one-hot residue code, so the embedding (network.py:188, 223: a
+  // frozen identity in the reference, but part of the state_dict) is folded into the input weights:
+  // W_ih x = W_ih embed[code] = (W_ih embed^T)[:, code].  Exact for the identity.
+  std::vector<float> wi0_folded;
+  {
+    const auto& wi = H["vgru.weight_ih_l0"];     // [1536][22]
+    const auto& emb = H["embed.weight"];         // [22 codes][22]
+    wi0_folded.resize(wi.size());
+    for (int j = 0; j < 3 * 512; ++j)
+      for (int code = 0; code < 22; ++code) {
+        double acc = 0.0;
+        for (int k = 0; k < 22; ++k) acc += (double)wi[(size_t)j * 22 + k] * (double)emb[(size_t)code * 22 + k];
+        wi0_folded[(size_t)j * 22 + code] = (float)acc;
+      }
+  }
   for (int l = 0; l < 2; ++l) {
-    const auto& wi = H["vgru.weight_ih_l" + std::to_string(l)];
+    const auto& wi = l == 0 ? wi0_folded : H["vgru.weight_ih_l" + std::to_string(l)];
     const auto& wh = H["vgru.weight_hh_l" + std::to_string(l)];
     // one power-of-two scale per layer: the input and the recurrent products share accumulators
     const float scale = std::fmin(conv_weight_scale_f16(wi.data(), wi.size()),

@@ -1,0 +1,206 @@
+"""HIP path at BASELINE.json's full sizes.
+
+The oracle does not finish in seconds at these sizes, so the checks are (a) the oracle on the
+stages it can still do, (b) independent implementations of single stages (PyTorch-ROCm operators
+on the same GPU: integer counting, F.conv2d, nn.GRU - checkers only, never the product path),
+(c) size-independent properties: A A^-1 = I, truncation at 3000 rows, run-to-run determinism,
+scheduler == single engine.
+
+  configs[1]  L=200, N=1000, 10 + 100        oracle-checked prefix (2 recycling iterations, m = 0)
+  metric      L=300, N=2000, 10 + 100        stage checks + determinism + scheduler equality
+  configs[2]  L=500, N=5000 (-> 3000), 30+200   truncation property, finite outputs
+  configs[4]  L=1000, N=2000, 100 + 1000     runs within the context capacity, finite outputs
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ca_rmsd
+
+pytestmark = pytest.mark.gpu
+
+import dmpfold_oracle as O          # noqa: E402  (test infrastructure)
+
+
+def _msa(L, N, seed):
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import encode_aln
+    return encode_aln(synth.synth_msa(L, N, seed=seed))
+
+
+@pytest.fixture(scope="module")
+def ns(synth_sd):
+    """One context of the north-star capacity, shared by the stage checks."""
+    from abi import Stages
+    st = Stages(synth_sd, max_L=300, max_N=2000)
+    yield st
+    st.eng.sync_check()
+    st.eng.close()
+
+
+@pytest.fixture(scope="module")
+def ns_msa():
+    return _msa(300, 2000, 4242)
+
+
+def test_ns_msa_weights_bit_exact(ns, ns_msa):
+    """reweight at N=2000, L=300 against an integer count done with torch on the GPU."""
+    w = ns.msa_weights(ns_msa).cpu().numpy()
+    m = torch.from_numpy(np.minimum(ns_msa, 20)).cuda()
+    counts = torch.zeros(m.shape[0], dtype=torch.int64, device="cuda")
+    thr = np.float32(m.shape[1] * 0.8)
+    for lo in range(0, m.shape[0], 250):
+        same = (m[lo:lo + 250, None, :] == m[None, :, :]).sum(-1).to(torch.float32)
+        counts[lo:lo + 250] = (same > float(thr)).sum(-1)
+    ref = (1.0 / counts.to(torch.float32)).cpu().numpy()
+    assert np.array_equal(w, ref)
+
+
+def test_ns_covariance_inverse_identity(ns, ns_msa):
+    """fast_dca at D = 6300: covariance against the oracle's formula evaluated with torch on the
+    GPU, and cov @ inverse = I."""
+    w = ns.msa_weights(ns_msa)
+    cov = ns.cov_build(ns_msa, w)
+    N, L = ns_msa.shape
+    x = F.one_hot(torch.from_numpy(np.minimum(ns_msa, 20).astype(np.int64)).cuda(), 21).float().reshape(N, 21 * L)
+    S = w.sum()
+    num = S - torch.sqrt(w.mean())
+    mean = (x * w[:, None]).sum(0, keepdim=True) / num
+    xc = (x - mean) * torch.sqrt(w)[:, None]
+    ref = (xc.double().t() @ xc.double() / num.double()).float()
+    ref += torch.eye(21 * L, device="cuda") * (4.5 / torch.sqrt(S))
+    assert float((cov - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    inv = ns.spd_inverse(cov)
+    resid = (cov.double() @ inv.double() - torch.eye(21 * L, device="cuda", dtype=torch.float64)).abs().max()
+    assert float(resid) < 5e-4
+    assert float((inv - inv.t()).abs().max()) <= 1e-4 * float(inv.abs().max())
+
+
+def test_ns_gru_vertical_vs_torch_gru(ns, ns_msa, synth_sd):
+    """2000 recurrent steps x 300 columns against the GRU recurrence (network.py:189; ATen
+    gru_cell: h' = (h - n) z + n) written out with float64 matmuls on the GPU."""
+    out = ns.gru_vertical(ns_msa)
+    W = {k: torch.from_numpy(np.array(v)).cuda().double() for k, v in synth_sd.items() if k.startswith(("vgru.", "embed."))}
+    codes = torch.from_numpy(ns_msa.astype(np.int64)).cuda()
+    h = [torch.zeros(300, 512, dtype=torch.float64, device="cuda") for _ in range(2)]
+    for t in range(ns_msa.shape[0]):
+        x = W["embed.weight"][codes[t]]
+        for l in range(2):
+            gi = x @ W[f"vgru.weight_ih_l{l}"].t() + W[f"vgru.bias_ih_l{l}"]
+            gh = h[l] @ W[f"vgru.weight_hh_l{l}"].t() + W[f"vgru.bias_hh_l{l}"]
+            r = torch.sigmoid(gi[:, :512] + gh[:, :512])
+            z = torch.sigmoid(gi[:, 512:1024] + gh[:, 512:1024])
+            n = torch.tanh(gi[:, 1024:] + r * gh[:, 1024:])
+            h[l] = (h[l] - n) * z + n
+            x = h[l]
+    assert float((out.double() - h[1]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_ns_conv_block_vs_conv2d(ns, synth_sd, mode):
+    """One residual-block convolution at L = 300 against F.conv2d + maxout (float64 on the GPU)."""
+    ns.eng.set_option("conv_mode", mode)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(7)
+        x = torch.randn(128, 300, 300, device="cuda", generator=g) * 3.0
+        u, st = ns.conv(5, x)
+        w = torch.from_numpy(np.array(synth_sd["resnet.5.layer1.lin.weight"])).cuda().double()
+        b = torch.from_numpy(np.array(synth_sd["resnet.5.layer1.lin.bias"])).cuda().double()
+        ref = torch.empty(128, 300, 300, dtype=torch.float64, device="cuda")
+        for lo in range(0, 300, 50):             # rows lo..lo+49: im2col slab (3200 x 15000) in float64
+            xp = F.pad(x.double(), (2, 2, 2, 2))[:, lo:lo + 54]
+            cols = F.unfold(xp[None], 5)[0]                                   # (128*25, 50*300)
+            y = (w.reshape(512, 3200) @ cols + b[:, None]).reshape(128, 4, 50, 300)
+            ref[:, lo:lo + 50] = y.max(1)[0]
+        scale = float(ref.abs().max())
+        assert float((u.double() - ref).abs().max()) <= 1e-5 * scale
+        assert float((st[:, 0] - ref.sum((1, 2))).abs().max()) <= 1e-5 * float(ref.abs().sum((1, 2)).max())
+    finally:
+        ns.eng.set_option("conv_mode", 0)
+
+
+def test_ns_end_to_end_deterministic_and_scheduler_equal(ns, ns_msa, synth_sd):
+    """The north-star prediction twice on one engine, and through the 3-engine scheduler: same bits."""
+    from dmpfold2_amd.predict import Pipeline
+    c1, f1 = ns.eng.predict(ns_msa, None, 10, 100)
+    c2, f2 = ns.eng.predict(ns_msa, None, 10, 100)
+    ns.eng.sync_check()
+    assert torch.equal(c1, c2) and torch.equal(f1, f2)
+    assert bool(torch.isfinite(c1).all()) and bool(torch.isfinite(f1).all())
+    assert float(f1.min()) >= 0.0 and float(f1.max()) <= 1.0
+    dev = torch.device("cuda:0")
+    pipe = Pipeline(dev, 300, 2000, synth_sd, streams=3)
+    other = _msa(300, 2000, 99)
+    d_a, d_b = torch.from_numpy(ns_msa).to(dev), torch.from_numpy(other).to(dev)
+    res = pipe.run([d_a, d_b, d_a, d_b, d_a], 10, 100)
+    pipe.sync_check()
+    for i in (0, 2, 4):
+        assert torch.equal(res[i][0], c1) and torch.equal(res[i][1], f1)
+    assert torch.equal(res[1][0], res[3][0])
+    pipe.close()
+
+
+def test_config1_L200_N1000_prefix_vs_oracle(synth_sd, oracle_weights):
+    """configs[1] (L=200, N=1000): the oracle is affordable for 2 recycling iterations without the
+    minimiser; the full 10 + 100 run must then be finite and deterministic."""
+    from abi import Stages
+    msa = _msa(200, 1000, 11)
+    st = Stages(synth_sd, max_L=200, max_N=1000)
+    coords, confs = st.eng.predict(msa, None, 2, 0)
+    st.eng.sync_check()
+    rc, rf = O.predict(msa, oracle_weights, None, 2, 0, "canonical")
+    assert ca_rmsd(coords.cpu().numpy()[:, 1], np.asarray(rc)[:, 1]) <= 1e-3
+    assert np.abs(confs.cpu().numpy() - np.asarray(rf)).max() < 1e-4
+    a = st.eng.predict(msa, None, 10, 100)
+    b = st.eng.predict(msa, None, 10, 100)
+    st.eng.sync_check()
+    assert torch.equal(a[0], b[0]) and bool(torch.isfinite(a[0]).all())
+    st.eng.close()
+
+
+def test_config2_deep_msa_truncated_at_3000_rows(synth_sd, tmp_path, weights_file):
+    """configs[2] (L=500, N=5000, 30 + 200): the alignment is cut to its first 3000 rows
+    (predict.py:130-132), so the result equals that of the 3000-row alignment."""
+    from dmpfold2_amd import aln_to_coords, synth
+    rows = synth.synth_msa(500, 5000, seed=5)
+    full, cut = tmp_path / "deep.aln", tmp_path / "cut.aln"
+    synth.write_aln(str(full), rows)
+    synth.write_aln(str(cut), rows[:3000])
+    c1, f1 = aln_to_coords(str(full), device="cuda:0", iterations=30, minsteps=200, weights_file=weights_file)
+    c2, f2 = aln_to_coords(str(cut), device="cuda:0", iterations=30, minsteps=200, weights_file=weights_file)
+    assert c1.shape == (500, 5, 3) and f1.shape == (500,)
+    assert torch.equal(c1, c2) and torch.equal(f1, f2)
+    assert bool(torch.isfinite(c1).all()) and bool(torch.isfinite(f1).all())
+
+
+def test_config4_L1000_long_recycling(synth_sd):
+    """configs[4] (L=1000, N=2000, 100 iterations + 1000 minimiser steps) on one context."""
+    from dmpfold2_amd.predict import Engine
+    eng = Engine("cuda:0", 1000, 2000)
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+    assert eng.device_bytes < 16e9
+    msa = _msa(1000, 2000, 3)
+    coords, confs = eng.predict(msa, None, 100, 1000)
+    eng.sync_check()
+    assert coords.shape == (1000, 5, 3)
+    assert bool(torch.isfinite(coords).all()) and bool(torch.isfinite(confs).all())
+    eng.close()
+
+
+def test_embedding_is_folded_into_the_input_weights(synth_sd, oracle_weights):
+    """embed.weight is part of the state_dict (network.py:188 freezes it to the identity): a
+    different matrix must still give the reference's x = embed[code] semantics."""
+    from abi import Stages
+    rng = np.random.default_rng(3)
+    sd = dict(synth_sd)
+    sd["embed.weight"] = (np.eye(22) + 0.3 * rng.standard_normal((22, 22))).astype(np.float32)
+    ow = dict(oracle_weights)
+    ow["embed.weight"] = torch.from_numpy(sd["embed.weight"])
+    msa = _msa(40, 60, 8)
+    st = Stages(sd, max_L=64, max_N=64)
+    out = st.gru_vertical(msa).cpu().numpy()
+    idx = torch.from_numpy(msa.astype(np.int64))
+    v = O._gru(ow, "vgru", ow["embed.weight"][idx], 22, 512, 2, False, False)[-1].numpy()
+    assert np.abs(out - v).max() < 1e-5
+    st.eng.close()
