@@ -111,7 +111,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # DMP_FORCE_DIST=1 exercises the RCCL barrier / reduction path with a single rank (1-GPU boxes)
+    distributed = world > 1 or (os.environ.get("DMP_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -39,6 +39,14 @@ constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slo
 #ifndef CH_OCC
 #define CH_OCC 2             // workgroups per CU the register budget is compiled for
 #endif
+#ifndef CH_MAP_PAIR
+#define CH_MAP_PAIR 1        // 1: each XCD handles two of the four channel splits (see the kernel);
+#endif                       //    same time, fabric reads per launch 361 -> 257 MB (tools/pmc_fetch.sh)
+// number of workgroups to launch for tiles x tiles pixel tiles
+inline int conv_f16_grid(int tiles) {
+  const int ntiles = tiles * tiles;
+  return CH_MAP_PAIR ? 8 * 2 * ((ntiles + 3) / 4) : (ntiles * 4 + 7) / 8 * 8;
+}
 constexpr int CH_RING = CH_RING_SLOTS;
 constexpr int CH_DIST = CH_RING >= 4 ? 2 : 1;
 constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_RING * CH_WSLOT * 16;   // 63488 (ring 4) / 47104 (ring 2)
@@ -99,7 +107,7 @@ __device__ __forceinline__ ch_f32x16 ch_mfma(uint4 a, uint4 b, ch_f32x16 c) {
                                                 __builtin_bit_cast(ch_f16x8, b), c, 0, 0, 0);
 }
 
-// grid: round_up(tiles*tiles*4, 8) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
+// grid: conv_f16_grid(tiles) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
 __global__ __launch_bounds__(256, CH_OCC) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
                                                                const uint16_t* __restrict__ wq,
                                                                const float* __restrict__ bias, float inv_scale,
@@ -107,10 +115,20 @@ __global__ __launch_bounds__(256, CH_OCC) void conv5x5_f16x3_kernel(const uint16
                                                                float* __restrict__ u, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
   const int id = blockIdx.x;
+#if CH_MAP_PAIR
+  // XCD x works on the channel splits {0,1} (x even) or {2,3} (x odd) only: its share of the weight
+  // pieces is 3.3 MB, which fits the 4 MB L2; a tile's input is then read by two XCDs
+  const int xcd = id & 7, slot = id >> 3;
+  const int ntiles = tiles * tiles, tper = (ntiles + 3) >> 2;
+  const int tile = (xcd >> 1) * tper + (slot >> 1);
+  const int split = 2 * (xcd & 1) + (slot & 1);
+  if ((slot >> 1) >= tper || tile >= ntiles) return;
+#else
   const int per = gridDim.x >> 3;
   const int work = (id & 7) * per + (id >> 3);
   if (work >= nwork) return;
   const int tile = work >> 2, split = work & 3;
+#endif
   const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -623,7 +623,7 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
       hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(grid), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
                          B.bias, L, P, tiles, nwork, d_u, c->part);
     else
-      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(grid), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,
+      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,
                          B.bias, B.wh_inv_scale, L, P, tiles, nwork, d_u, c->part);
     DMP_LAUNCH_CHECK();
     return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;

@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_xs, xs.size() * 2)); CK(hipMalloc(&d_u, (size_t)128 * L * L * 4));
     CK(hipMalloc(&d_part, (size_t)tiles * tiles * 128 * 2 * 8));
     CK(hipMemcpy(d_xs, xs.data(), xs.size() * 2, hipMemcpyHostToDevice));
-    const int nwork = tiles * tiles * 4, grid = (nwork + 7) / 8 * 8;
+    const int nwork = tiles * tiles * 4, grid = conv_f16_grid(tiles);
     auto launch = [&]() {
       hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(grid), dim3(256), lds_bytes, 0, d_xs, d_wq, d_b,
                          1.0f / scale, L, P, tiles, nwork, d_u, d_part);
