@@ -1,0 +1,119 @@
+"""Batch front end: many independent alignments -> one PDB file each, sharded over the GPUs of a node.
+
+    python -m dmpfold2_amd.batch -l targets.txt -o out_dir [-n 10] [-m 100] [-w weights.pt] [--streams 3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m dmpfold2_amd.batch -l targets.txt -o out_dir
+
+`targets.txt` holds one alignment path per line, optionally followed by a template PDB path.  The
+reference has no batch mode (its CLI takes one alignment, predict.py:160-208); this is the
+"independent alignments shard embarrassingly" axis of SURVEY.md section 8e: every rank (one process
+per GPU) takes the targets `shard.partition_targets` assigns to it (longest first), runs them through
+a `Pipeline` (several targets in flight per GPU) and writes `<out_dir>/<alignment basename>.pdb` with
+the text of the single-target CLI.  No collective on the data path; `torch.distributed` only sums the
+target count and takes the maximum elapsed time for the summary line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import shard
+from .predict import (Pipeline, default_iterations, default_minsteps, encode_aln, load_state_dict,
+                      pdb_text, read_aln, read_template_ca)
+
+
+def read_target_list(path):
+    """[(alignment path, template path or None)] from a text file (blank lines and # comments skipped)."""
+    out = []
+    with open(path) as fh:
+        for line in fh:
+            line = line.split("#", 1)[0].strip()
+            if not line:
+                continue
+            parts = line.split()
+            out.append((parts[0], parts[1] if len(parts) > 1 else None))
+    return out
+
+
+def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_minsteps,
+              weights_file=None, state_dict=None, streams=3, device=None, rank=0, world=1):
+    """Predict the targets of this rank's shard; returns (number done, seconds, [output paths])."""
+    os.makedirs(out_dir, exist_ok=True)
+    parsed = []
+    for aln_path, tpl_path in targets:
+        rows = read_aln(aln_path)
+        parsed.append((aln_path, tpl_path, encode_aln(rows)))
+    costs = [shard.estimate_cost(m.shape[1], m.shape[0], iterations) for _, _, m in parsed]
+    mine = shard.partition_targets(costs, world)[rank]
+    if not mine:
+        return 0, 0.0, []
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    max_L = max(parsed[i][2].shape[1] for i in mine)
+    max_N = max(parsed[i][2].shape[0] for i in mine)
+    sd = state_dict if state_dict is not None else load_state_dict(weights_file)
+    pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
+    t0 = time.perf_counter()
+    tickets = []
+    for i in mine:                                   # longest first: the order partition_targets returns
+        aln_path, tpl_path, alnmat = parsed[i]
+        tpl = read_template_ca(tpl_path) if tpl_path else None
+        d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
+        tickets.append((i, pipe.submit(d_msa, iterations, minsteps, template_ca=tpl)))
+        pipe.pump()
+    pipe.drain()
+    pipe.sync_check()
+    outputs = []
+    for i, t in tickets:
+        coords, confs = pipe.result(t)
+        aln_path, _, alnmat = parsed[i]
+        out_path = os.path.join(out_dir, os.path.splitext(os.path.basename(aln_path))[0] + ".pdb")
+        with open(out_path, "w") as fh:
+            fh.write(pdb_text(coords, confs, alnmat))
+        outputs.append(out_path)
+    elapsed = time.perf_counter() - t0
+    pipe.close()
+    return len(mine), elapsed, outputs
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="DMPfold2 batch prediction on AMD MI355X (one process per GPU)")
+    ap.add_argument("-l", "--list", required=True, help="text file: one alignment path (+ optional template) per line")
+    ap.add_argument("-o", "--out_dir", required=True)
+    ap.add_argument("-n", "--iterations", type=int, default=default_iterations)
+    ap.add_argument("-m", "--minsteps", type=int, default=default_minsteps)
+    ap.add_argument("-w", "--model_weights", type=str, default=None)
+    ap.add_argument("--streams", type=int, default=3, help="targets in flight per GPU")
+    args = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    targets = read_target_list(args.list)
+    n, elapsed, _ = run_batch(targets, args.out_dir, args.iterations, args.minsteps,
+                              weights_file=args.model_weights, streams=args.streams,
+                              device=f"cuda:{local_rank}", rank=rank, world=world)
+    total, tmax = shard.job_summary(n, elapsed)
+    if rank == 0:
+        print(json.dumps({"targets": total, "seconds": tmax, "structures_per_s": total / tmax if tmax > 0 else 0.0,
+                          "n_gpus": world}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -284,25 +284,39 @@ class Pipeline:
             pass
 
     # ---- scheduler ---------------------------------------------------------------------------
-    def submit(self, d_msa, iterations=default_iterations, minsteps=default_minsteps):
-        """Queue one target (uint8 (N, L) tensor on the GPU); returns a ticket for `result`."""
+    def submit(self, d_msa, iterations=default_iterations, minsteps=default_minsteps, template_ca=None):
+        """Queue one target (uint8 (N, L) tensor on the GPU, optional template CA trace (L, 3));
+        returns a ticket for `result`."""
         assert d_msa.dtype == torch.uint8 and d_msa.is_contiguous() and d_msa.device == self.device
+        n, L = d_msa.shape
+        if L < 8:
+            raise RuntimeError(f"alignment has {L} columns; the network needs at least 8")
+        if L > self.engines[0].max_L or n > self.engines[0].max_N:
+            raise RuntimeError(f"alignment {n} x {L} exceeds the pipeline capacity "
+                               f"{self.engines[0].max_N} x {self.engines[0].max_L}")
+        d_tpl = None
+        if template_ca is not None:
+            d_tpl = torch.as_tensor(template_ca, dtype=torch.float32).reshape(-1, 3).to(self.device).contiguous()
+            if d_tpl.shape[0] != L:
+                raise RuntimeError(f"Sizes of tensors must match: template has {d_tpl.shape[0]} CA atoms, "
+                                   f"alignment has {L} columns")
         t = self._tickets
         self._tickets += 1
-        self._pending.append((t, d_msa, int(max(iterations, 0)), int(max(minsteps, 0))))
+        self._pending.append((t, d_msa, int(max(iterations, 0)), int(max(minsteps, 0)), d_tpl))
         return t
 
     def _begin(self, s, job):
-        t, d_msa, nloops, minsteps = job
+        t, d_msa, nloops, minsteps, d_tpl = job
         e = self.engines[s]
         e._stream.wait_stream(torch.cuda.current_stream(self.device))
         n, L = d_msa.shape
         with torch.cuda.stream(e._stream):
             coords = torch.empty((L, 5, 3), dtype=torch.float32, device=self.device)
             confs = torch.empty((L,), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.dmp_predict_begin_units(e.ctx, d_msa.data_ptr(), n, L, None, 0, nloops,
-                                                    minsteps))
-        self._slot[s] = (t, coords, confs, d_msa)
+        _lib.check(self.lib.dmp_predict_begin_units(
+            e.ctx, d_msa.data_ptr(), n, L, d_tpl.data_ptr() if d_tpl is not None else None,
+            L if d_tpl is not None else 0, nloops, minsteps))
+        self._slot[s] = (t, coords, confs, (d_msa, d_tpl))
 
     def _pump(self):
         """One scheduling round over the engines; True if anything was enqueued."""

@@ -384,6 +384,44 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
     pipe.close()
 
 
+def test_batch_front_end_matches_cli(weights_file, tmp_path):
+    """dmpfold2_amd.batch (targets file -> one PDB per target through the scheduler, template in
+    the second column) writes exactly the text the single-target CLI prints."""
+    from dmpfold2_amd import run_dmpfold, synth
+    from dmpfold2_amd.batch import read_target_list, run_batch
+    paths = []
+    g = load_golden("pf10963_n0_m0")
+    p = tmp_path / "pf10963.aln"
+    p.write_text("\n".join(golden_rows(g)) + "\n")
+    paths.append(str(p))
+    for k, (L, N) in enumerate([(24, 40), (57, 3), (33, 1), (64, 200), (40, 64)]):
+        q = tmp_path / f"t{k}.aln"
+        synth.write_aln(str(q), synth.synth_msa(L, N, seed=50 + k))
+        paths.append(str(q))
+
+    def cli(aln, tpl=None):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            run_dmpfold(["-i", aln, "-d", "cuda:0", "-n", "1", "-m", "2", "-w", weights_file] +
+                        (["-t", tpl] if tpl else []))
+        return buf.getvalue()
+
+    ref = {a: cli(a) for a in paths}
+    tpl = tmp_path / "tpl.pdb"                       # a previous model as the template of the same target
+    tpl.write_text(ref[paths[0]])
+    lst = tmp_path / "targets.txt"
+    lst.write_text("# alignment [template]\n" + "\n".join(paths[1:]) + f"\n{paths[0]} {tpl}\n")
+    targets = read_target_list(str(lst))
+    assert targets[-1] == (paths[0], str(tpl)) and len(targets) == 6
+    n, secs, outs = run_batch(targets, str(tmp_path / "out"), 1, 2, weights_file=weights_file, streams=3,
+                              device="cuda:0")
+    assert n == 6 and len(outs) == 6
+    for a in paths[1:]:
+        name = a.rsplit("/", 1)[1].replace(".aln", ".pdb")
+        assert (tmp_path / "out" / name).read_text() == ref[a], a
+    assert (tmp_path / "out" / "pf10963.pdb").read_text() == cli(paths[0], str(tpl))
+
+
 def test_unit_api_contract(st_engine):
     """dmp_predict_next_unit / issue_unit: 18 units per pass, blocks are the conv units, pass == units."""
     eng = st_engine.eng

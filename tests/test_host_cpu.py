@@ -156,3 +156,17 @@ def test_sharded_job_over_gloo_world_size_2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_batch_target_list_and_shards(tmp_path):
+    """Batch front end, host logic: the targets file parser and that the per-rank shards of a job
+    cover every target exactly once for 1..8 ranks."""
+    from dmpfold2_amd import shard
+    from dmpfold2_amd.batch import read_target_list
+    lst = tmp_path / "t.txt"
+    lst.write_text("a.aln\n\n# comment\nb.aln tpl.pdb  # trailing\n  c.aln\n")
+    assert read_target_list(str(lst)) == [("a.aln", None), ("b.aln", "tpl.pdb"), ("c.aln", None)]
+    costs = [shard.estimate_cost(L, N) for L, N in [(300, 2000), (82, 252), (500, 5000), (64, 3), (1000, 2000)] * 5]
+    for world in range(1, 9):
+        parts = shard.partition_targets(costs, world)
+        assert sorted(i for p in parts for i in p) == list(range(len(costs)))
