@@ -4,7 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         -m dmpfold2_amd.batch -l targets.txt -o out_dir
 
-`targets.txt` holds one alignment path per line, optionally followed by a template PDB path.  The
+`targets.txt` holds one alignment path per line (.aln, or .a3m converted as the reference's README
+describes), optionally followed by a template PDB path.  The
 reference has no batch mode (its CLI takes one alignment, predict.py:160-208); this is the
 "independent alignments shard embarrassingly" axis of SURVEY.md section 8e: every rank (one process
 per GPU) takes the targets `shard.partition_targets` assigns to it (longest first), runs them through
@@ -25,7 +26,7 @@ import torch
 
 from . import shard
 from .predict import (Pipeline, default_iterations, default_minsteps, encode_aln, load_state_dict,
-                      pdb_text, read_aln, read_template_ca)
+                      pdb_text, read_a3m, read_aln, read_template_ca)
 
 
 def read_target_list(path):
@@ -47,7 +48,7 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     os.makedirs(out_dir, exist_ok=True)
     parsed = []
     for aln_path, tpl_path in targets:
-        rows = read_aln(aln_path)
+        rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
         parsed.append((aln_path, tpl_path, encode_aln(rows)))
     costs = [shard.estimate_cost(m.shape[1], m.shape[0], iterations) for _, _, m in parsed]
     mine = shard.partition_targets(costs, world)[rank]

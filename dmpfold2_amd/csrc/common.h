@@ -150,6 +150,7 @@ struct dmp_ctx {
   uint16_t* xsplit = nullptr;  // [3][16][P][P][8] bf16 pieces of the current activations
   int conv_mode = 0;           // 0: f16x3 split products (default), 1: exact f32 MFMA, 2: bf16x6 split
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
+  bool conv_attr_set = false;  // hipFuncSetAttribute(max dynamic LDS) done for this context's device
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm

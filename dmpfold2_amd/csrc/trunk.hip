@@ -607,13 +607,12 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
   const int grid = round_up(nwork, 8);
   if (c->conv_mode != 1) {
     // float32-grade products from f16 / bf16 pieces on the 16-bit matrix cores
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!c->conv_attr_set) {       // per context (= per device): dynamic LDS above 64 KB needs the opt-in
       DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CONVQ_LDS_BYTES));
       DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CONVH_LDS_BYTES));
-      attr_set = true;
+      c->conv_attr_set = true;
     }
     if (!c->xsplit_current) {
       int rc = act_split(c, d_xpad, L, s);

@@ -49,6 +49,18 @@ def read_aln(input_file):
     return rows
 
 
+def read_a3m(input_file):
+    """An .a3m alignment as .aln rows: the reference README's conversion
+    `egrep -v "^>" x.a3m | sed 's/[a-z]//g' > x.aln` (drop header lines and the lower-case insert
+    columns), done in memory."""
+    rows = []
+    with open(input_file, "r") as fh:
+        for line in fh.readlines():
+            if not line.startswith(">"):
+                rows.append("".join(ch for ch in line.rstrip() if not ("a" <= ch <= "z")))
+    return rows
+
+
 def encode_aln(rows):
     """Residue letters -> uint8 codes (N, L), capped at 3000 rows (predict.py:124-132).
     Ragged input raises ValueError from the reshape, as in the reference."""

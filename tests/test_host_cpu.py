@@ -170,3 +170,13 @@ def test_batch_target_list_and_shards(tmp_path):
     for world in range(1, 9):
         parts = shard.partition_targets(costs, world)
         assert sorted(i for p in parts for i in p) == list(range(len(costs)))
+
+
+def test_read_a3m_matches_readme_recipe(tmp_path):
+    """egrep -v "^>" x.a3m | sed 's/[a-z]//g' (reference README.md:30-33)."""
+    from dmpfold2_amd.predict import read_a3m, read_aln
+    a3m = tmp_path / "x.a3m"
+    a3m.write_text(">query\nACDEFGHIKL\n>hit1 desc\nACd-EFGHikIKL\n>hit2\n-CDEFGHIK-\n")
+    aln = tmp_path / "x.aln"
+    aln.write_text("ACDEFGHIKL\nAC-EFGHIKL\n-CDEFGHIK-\n")
+    assert read_a3m(str(a3m)) == read_aln(str(aln))
