@@ -378,7 +378,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(conf, L);
   A_(gram, LL);
   A_(eig_a, LL);
-  A_(eig_ws, 3 * L + 16 + 8 * L + 40 * L + LL);
+  A_(eig_ws, 3 * L + 16 + 8 * L + 40 * L + LL + 2 * L + 8);
   A_(mds, L * 8);
   A_(ca, L * 3);
   A_(best_ca, L * 3);
@@ -409,6 +409,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   DMP_ARG(ctx && name, "null argument");
   const std::string k(name);
   if (k == "conv_f32_exact") { ctx->conv_mode = value ? 1 : 0; return DMP_OK; }
+  if (k == "tridiag_single") { ctx->tridiag_single = value ? 1 : 0; return DMP_OK; }
   if (k == "conv_mode") {
     DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
     ctx->conv_mode = value;
@@ -441,6 +442,7 @@ void dmp_ctx_destroy(dmp_ctx* c) {
   for (void* e : c->unit_ev)
     if (e) (void)hipEventDestroy((hipEvent_t)e);
   for (auto& kv : c->vgru_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
+  for (auto& kv : c->tri_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
   delete c;
 }
 

@@ -132,6 +132,8 @@ struct dmp_ctx {
   uint16_t* hH[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // same state as f16 pieces [2][64][Lb][8]
   uint8_t* vgru_run = nullptr;             // device VRun record read by the graph's step kernels
   std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
+  std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain
+  int tridiag_single = 0;                  // option: 1 = single-workgroup tridiagonalisation
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions
   float* seq_a = nullptr;   // [L][512]

@@ -1,6 +1,7 @@
 // Top-8 symmetric eigensolver for the MDS step (reference network.py:247-250: torch.symeig,
 // clamp, V*sqrt(lambda), last 8 columns), entirely on the device in float64:
-//   1. Householder tridiagonalisation  A = Q T Q^T          (one workgroup, A resident in L2)
+//   1. Householder tridiagonalisation  A = Q T Q^T          (one launch per step, up to 256 workgroups;
+//      option "tridiag_single" = 1 keeps everything in one workgroup)
 //   2. bisection (Sturm counts, 64-way multisection per wave) for the 8 largest eigenvalues of T
 //   3. inverse iteration with pivoted tridiagonal LU for their eigenvectors, Gram-Schmidt inside
 //      clusters of close eigenvalues
@@ -160,6 +161,112 @@ __global__ __launch_bounds__(1024) void tridiag_kernel(double* __restrict__ A, i
   if (tid == 0) {
     d[n - 1] = A[(int64_t)(n - 1) * n + (n - 1)];
     e[n - 1] = 0.0;
+  }
+}
+
+// ---- multi-workgroup tridiagonalisation: one launch per Householder step ------------------------
+// Step k applies the rank-2 update of step k-1 and, in the same pass over the trailing matrix, forms
+// the product with the NEW Householder vector:
+//   every workgroup rebuilds w_{k-1} = p_{k-1} - (tau/2)(p.v) v and the updated pivot row (O(n) work,
+//   redundantly), derives v_k, beta, tau from it, then for each of its rows r of the trailing block:
+//       a_rj <- a_rj - (v_r w_j + w_r v_j),      p_k[r] = tau_k * sum_j a_rj v_k[j]
+//   (a wave per row, lanes along the contiguous row).  A row's product needs no other workgroup, the
+//   dot p.v that couples rows is taken by the next launch.  The trailing matrix is read and written
+//   once per step by up to 256 workgroups instead of twice by one; the launches are replayed from a
+//   hipGraph chain (step = k0 + node index, k0 in a device record), 1.7 us apart.
+struct TriRun { int k0, n; };
+
+__global__ void tri_set_run_kernel(TriRun* run, int k0, int n) { run->k0 = k0; run->n = n; }
+
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grid: G workgroups   block: 256   dynamic LDS: 4 n doubles
+__global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ A, const TriRun* __restrict__ run,
+                                                           int idx, double* __restrict__ d,
+                                                           double* __restrict__ e, double* __restrict__ tau,
+                                                           double* __restrict__ V, double* __restrict__ P) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double red[4];
+  const int n = run->n, k = run->k0 + idx;
+  if (k > n - 1) return;
+  double* vp = sm;            // v_{k-1}, indexed from global row k
+  double* w = sm + n;         // w_{k-1}
+  double* vn = sm + 2 * n;    // v_k, indexed from global row k+1
+  double* x = sm + 3 * n;     // updated pivot row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mp = n - k;                                   // order of the block A[k.., k..]
+  double* A22p = A + (int64_t)k * n + k;
+  const double tkp = k > 0 ? tau[k - 1] : 0.0;
+  if (tkp != 0.0) {
+    const double* pp = P + (int64_t)((k - 1) & 1) * n;
+    double pv = 0.0;
+    for (int i = tid; i < mp; i += 256) {
+      const double vi = V[(int64_t)(k - 1) * n + i], pi = pp[i];
+      vp[i] = vi;
+      w[i] = pi;
+      pv += pi * vi;
+    }
+    const double a2 = -0.5 * tkp * block_sum_256(pv, red);
+    for (int i = tid; i < mp; i += 256) w[i] += a2 * vp[i];
+  } else {
+    for (int i = tid; i < mp; i += 256) { vp[i] = 0.0; w[i] = 0.0; }
+  }
+  __syncthreads();
+  // updated pivot row (local row 0), and from it the reflector of this step
+  const double v0 = vp[0], w0 = w[0];
+  double ss = 0.0;
+  for (int j = tid; j < mp; j += 256) {
+    const double xj = A22p[j] - (v0 * w[j] + w0 * vp[j]);
+    x[j] = xj;
+    if (j > 1) ss += xj * xj;
+  }
+  const double xnorm2 = block_sum_256(ss, red);
+  const int m = mp - 1;                                   // length of x[1..]
+  if (m == 0) {
+    if (blockIdx.x == 0 && tid == 0) { d[k] = x[0]; e[k] = 0.0; }
+    return;
+  }
+  const double alpha = x[1];
+  double beta, tk;
+  if (xnorm2 == 0.0) {
+    beta = alpha;
+    tk = 0.0;
+  } else {
+    const double nrm = sqrt(alpha * alpha + xnorm2);
+    beta = alpha >= 0.0 ? -nrm : nrm;
+    tk = (beta - alpha) / beta;
+  }
+  const double sc = tk != 0.0 ? 1.0 / (alpha - beta) : 0.0;
+  for (int i = tid; i < m; i += 256) vn[i] = (i == 0) ? 1.0 : x[1 + i] * sc;
+  if (blockIdx.x == 0) {
+    if (tid == 0) { d[k] = x[0]; e[k] = beta; tau[k] = tk; }
+    for (int i = tid; i < m; i += 256) V[(int64_t)k * n + i] = (i == 0) ? 1.0 : x[1 + i] * sc;
+  }
+  __syncthreads();
+  // rows of the trailing block: update with (v_{k-1}, w_{k-1}), product with v_k
+  double* pn = P + (int64_t)(k & 1) * n;
+  const bool upd = tkp != 0.0;
+  for (int r = 1 + blockIdx.x * 4 + wave; r < mp; r += 4 * gridDim.x) {
+    double* row = A22p + (int64_t)r * n;
+    const double vr = vp[r], wr = w[r];
+    double acc = 0.0;
+    for (int j = 1 + lane; j < mp; j += 64) {
+      double a = row[j];
+      if (upd) {
+        a -= vr * w[j] + wr * vp[j];
+        row[j] = a;
+      }
+      acc += a * vn[j - 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) pn[r - 1] = tk * acc;
   }
 }
 
@@ -429,6 +536,43 @@ __global__ __launch_bounds__(256) void backtransform_kernel(const double* __rest
   for (int i = rl; i < n; i += 32) mds[(int64_t)i * NEV + c] = (float)(sgn * z[i * NEV + c]) * scale;
 }
 
+constexpr int TRI_CHAIN = 64;     // Householder steps per graph replay
+
+// chain of TRI_CHAIN step nodes for matrices of order n (pointers and LDS size are baked into the nodes)
+static int tridiag_graph(dmp_ctx* c, int n, double* A, TriRun* run, double* d, double* e, double* tau,
+                         double* V, double* P, hipGraphExec_t* out) {
+  auto it = c->tri_graphs.find(n);
+  if (it != c->tri_graphs.end()) { *out = (hipGraphExec_t)it->second; return DMP_OK; }
+  const int grid = std::min(256, cdiv(n, 4));
+  const TriRun* crun = run;
+  hipGraph_t g;
+  DMP_HIP(hipGraphCreate(&g, 0));
+  hipGraphNode_t prev = nullptr;
+  for (int idx = 0; idx < TRI_CHAIN; ++idx) {
+    int idx_arg = idx;
+    void* params[8] = {(void*)&A, (void*)&crun, (void*)&idx_arg, (void*)&d, (void*)&e, (void*)&tau, (void*)&V,
+                       (void*)&P};
+    hipKernelNodeParams kp{};
+    kp.func = (void*)tridiag_step_kernel;
+    kp.gridDim = dim3(grid);
+    kp.blockDim = dim3(256);
+    kp.sharedMemBytes = (unsigned)(sizeof(double) * 4 * n);
+    kp.kernelParams = params;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    hipError_t err = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+    if (err != hipSuccess) { (void)hipGraphDestroy(g); return hip_fail(err, "hipGraphAddKernelNode", __FILE__, __LINE__); }
+    prev = node;
+  }
+  hipGraphExec_t ge;
+  hipError_t err = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (err != hipSuccess) return hip_fail(err, "hipGraphInstantiate", __FILE__, __LINE__);
+  c->tri_graphs[n] = (void*)ge;
+  *out = ge;
+  return DMP_OK;
+}
+
 int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) {
   const int n = L;
   double* A = c->eig_a;
@@ -442,9 +586,22 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
   double* V = F + (int64_t)5 * n * NEV;     // n*n
   hipLaunchKernelGGL(eig_load_kernel, dim3(cdiv(n, 256), n), dim3(256), 0, s, d_M, n, A);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tridiag_kernel, dim3(1), dim3(1024), sizeof(double) * (2 * n + 1024), s, A, n, d,
-                     e, tau, V);
-  DMP_LAUNCH_CHECK();
+  double* P = V + (int64_t)n * n;           // 2*n
+  TriRun* run = reinterpret_cast<TriRun*>(P + 2 * n);
+  if (c->tridiag_single) {
+    hipLaunchKernelGGL(tridiag_kernel, dim3(1), dim3(1024), sizeof(double) * (2 * n + 1024), s, A, n, d,
+                       e, tau, V);
+    DMP_LAUNCH_CHECK();
+  } else {
+    hipGraphExec_t ge;
+    int rc = tridiag_graph(c, n, A, run, d, e, tau, V, P, &ge);
+    if (rc) return rc;
+    for (int k0 = 0; k0 < n; k0 += TRI_CHAIN) {
+      hipLaunchKernelGGL(tri_set_run_kernel, dim3(1), dim3(1), 0, s, run, k0, n);
+      DMP_HIP(hipGraphLaunch(ge, s));
+    }
+    DMP_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(256), sizeof(double) * (2 + NEV) * n, s, d, e, n,
                      F, lam, Z);
   DMP_LAUNCH_CHECK();
