@@ -58,7 +58,10 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  *                checked on the device, reported by dmp_sync_check);
  *   1            the f32 matrix-core instruction (bitwise an fmaf chain);
  *   2            exact 3-way bf16 split, 6 bf16 MFMA products (no range limit, 2.7x the f32 rate).
- * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default). */
+ * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default).
+ * "tridiag_single" = 1 runs the Householder tridiagonalisation of the MDS eigensolver in a single
+ * workgroup (one launch) instead of one multi-workgroup launch per step; same algorithm, different
+ * summation order (results agree to float64 rounding). */
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value);
 /* Reset the device-side fault word read by dmp_sync_check (enqueued on `stream`). */
 int dmp_clear_faults(dmp_ctx* ctx, void* stream);

@@ -285,6 +285,24 @@ def test_eigh_top8_structured(st):
         assert (got[np.abs(got).argmax(axis=0), np.arange(8)] > 0).all()      # sign rule
 
 
+def test_eigh_single_and_multi_workgroup_tridiagonalisation_agree(st_engine, ocap):
+    """Option tridiag_single: the one-workgroup Householder kernel and the per-step multi-workgroup
+    one are the same algorithm; odd sizes exercise the chain padding (64 steps per graph replay)."""
+    rng = np.random.default_rng(5)
+    mats = [ocap["p0.M"].numpy()]
+    for L in (9, 64, 65, 127):
+        B = rng.standard_normal((L, L)).astype(np.float32)
+        mats.append(((B + B.T) * 3).astype(np.float32))
+    for M in mats:
+        a = st_engine.eigh_top8(st_engine.to(M)).cpu().numpy()
+        st_engine.eng.set_option("tridiag_single", 1)
+        try:
+            b = st_engine.eigh_top8(st_engine.to(M)).cpu().numpy()
+        finally:
+            st_engine.eng.set_option("tridiag_single", 0)
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+
+
 def test_coords_from_mds(st, ocap, oracle_weights):
     ref = O.coords_from_mds(oracle_weights, ocap["mat1d"], ocap["p0.mds"].unsqueeze(0))[0].numpy()
     got = st.coords_from_mds(st.to(ocap["mat1d"].numpy()), st.to(ocap["p0.mds"].numpy())).cpu().numpy()
