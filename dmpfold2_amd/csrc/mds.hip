@@ -188,6 +188,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 }
 
 // grid: G workgroups   block: 256   dynamic LDS: 4 n doubles
+// All global loads a step needs (previous reflector and product, pivot row, the wave's first row)
+// are issued before the first reduction, so a launch pays one memory round trip, not four.
 __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ A, const TriRun* __restrict__ run,
                                                            int idx, double* __restrict__ d,
                                                            double* __restrict__ e, double* __restrict__ tau,
@@ -203,29 +205,52 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mp = n - k;                                   // order of the block A[k.., k..]
   double* A22p = A + (int64_t)k * n + k;
-  const double tkp = k > 0 ? tau[k - 1] : 0.0;
-  if (tkp != 0.0) {
-    const double* pp = P + (int64_t)((k - 1) & 1) * n;
-    double pv = 0.0;
-    for (int i = tid; i < mp; i += 256) {
-      const double vi = V[(int64_t)(k - 1) * n + i], pi = pp[i];
-      vp[i] = vi;
-      w[i] = pi;
-      pv += pi * vi;
+  constexpr int NI = 5;                                   // 256 * 5 >= 1280 = largest order
+  constexpr int NJ = 5;                                   // prefetched columns of the first row: 64 * 5
+  const int kp = k > 0 ? k - 1 : 0;
+  const double* pp = P + (int64_t)(kp & 1) * n;
+  const double tkp = k > 0 ? tau[kp] : 0.0;
+  double vi[NI], pi[NI], xi[NI];
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int i = tid + 256 * u;
+    const bool in = i < mp;
+    vi[u] = (in && k > 0) ? V[(int64_t)kp * n + i] : 0.0;
+    pi[u] = (in && k > 0) ? pp[i] : 0.0;
+    xi[u] = in ? A22p[i] : 0.0;
+  }
+  const int r0 = 1 + blockIdx.x * 4 + wave;
+  double a0[NJ];
+#pragma unroll
+  for (int u = 0; u < NJ; ++u) {
+    const int j = 1 + lane + 64 * u;
+    a0[u] = (r0 < mp && j < mp) ? A22p[(int64_t)r0 * n + j] : 0.0;
+  }
+  const bool upd = tkp != 0.0;
+  double pv = 0.0;
+#pragma unroll
+  for (int u = 0; u < NI; ++u) pv += pi[u] * vi[u];
+  const double a2 = upd ? -0.5 * tkp * block_sum_256(pv, red) : 0.0;
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int i = tid + 256 * u;
+    if (i < mp) {
+      vp[i] = upd ? vi[u] : 0.0;
+      w[i] = upd ? pi[u] + a2 * vi[u] : 0.0;
     }
-    const double a2 = -0.5 * tkp * block_sum_256(pv, red);
-    for (int i = tid; i < mp; i += 256) w[i] += a2 * vp[i];
-  } else {
-    for (int i = tid; i < mp; i += 256) { vp[i] = 0.0; w[i] = 0.0; }
   }
   __syncthreads();
   // updated pivot row (local row 0), and from it the reflector of this step
   const double v0 = vp[0], w0 = w[0];
   double ss = 0.0;
-  for (int j = tid; j < mp; j += 256) {
-    const double xj = A22p[j] - (v0 * w[j] + w0 * vp[j]);
-    x[j] = xj;
-    if (j > 1) ss += xj * xj;
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int j = tid + 256 * u;
+    if (j < mp) {
+      const double xj = xi[u] - (v0 * w[j] + w0 * vp[j]);
+      x[j] = xj;
+      if (j > 1) ss += xj * xj;
+    }
   }
   const double xnorm2 = block_sum_256(ss, red);
   const int m = mp - 1;                                   // length of x[1..]
@@ -252,12 +277,25 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ 
   __syncthreads();
   // rows of the trailing block: update with (v_{k-1}, w_{k-1}), product with v_k
   double* pn = P + (int64_t)(k & 1) * n;
-  const bool upd = tkp != 0.0;
-  for (int r = 1 + blockIdx.x * 4 + wave; r < mp; r += 4 * gridDim.x) {
+  for (int r = r0; r < mp; r += 4 * gridDim.x) {
     double* row = A22p + (int64_t)r * n;
     const double vr = vp[r], wr = w[r];
     double acc = 0.0;
-    for (int j = 1 + lane; j < mp; j += 64) {
+    if (r == r0) {
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = 1 + lane + 64 * u;
+        if (j < mp) {
+          double a = a0[u];
+          if (upd) {
+            a -= vr * w[j] + wr * vp[j];
+            row[j] = a;
+          }
+          acc += a * vn[j - 1];
+        }
+      }
+    }
+    for (int j = 1 + lane + (r == r0 ? 64 * NJ : 0); j < mp; j += 64) {
       double a = row[j];
       if (upd) {
         a -= vr * w[j] + wr * vp[j];
@@ -270,23 +308,34 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ 
   }
 }
 
+// 1/b to float64 rounding error without the IEEE division sequence (v_div_scale/fmas/fixup is a
+// chain of about ten dependent instructions): hardware reciprocal + two Newton steps.  The callers
+// keep |b| away from zero and infinity (pivmin / tiny guards), and the Sturm recurrence and the
+// triangular solves are latency chains of one division per row.
+__device__ __forceinline__ double fast_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+
 __device__ __forceinline__ int sturm_count(const double* d, const double* e2, int n, double x,
                                            double pivmin) {
   double q = d[0] - x;
   if (fabs(q) < pivmin) q = -pivmin;
   int cnt = q < 0.0;
   for (int i = 1; i < n; ++i) {
-    q = d[i] - x - e2[i - 1] / q;
+    q = d[i] - x - e2[i - 1] * fast_rcp(q);
     if (fabs(q) < pivmin) q = -pivmin;
     cnt += q < 0.0;
   }
   return cnt;
 }
 
-// Bisection + inverse iteration on the tridiagonal matrix.  block: 256.
-// dynamic LDS: dd[n], e2[n], x[n][8] doubles.  Global scratch F: 5 arrays [n][8].
+// Bisection + inverse iteration on the tridiagonal matrix.  block: 512 (8 waves: one eigenvalue each).
+// dynamic LDS: dd[n], e2[n], x[n][8], ee[n] doubles.  Global scratch F: 5 arrays [n][8].
 // Outputs: lam[8] (ascending), Z[n][8] (unit eigenvectors of T).
-__global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__ d,
+__global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__ d,
                                                       const double* __restrict__ e, int n,
                                                       double* __restrict__ F,
                                                       double* __restrict__ lam_out,
@@ -295,18 +344,20 @@ __global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__
   double* dd = sm;
   double* e2 = sm + n;
   double* x = sm + 2 * n;              // [n][8]
+  double* ee = sm + (2 + NEV) * n;     // off-diagonal (the LU recurrence reads it n times per lane)
   __shared__ double lam[NEV];
   __shared__ double sh_scal[4];
-  __shared__ double red[4][NEV];
+  __shared__ double red[8][NEV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // Gershgorin interval and norms
   double lo = 1e300, hi = -1e300, emax = 0.0, nrm1 = 0.0;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += 512) {
     const double di = d[i];
     const double el = i > 0 ? fabs(e[i - 1]) : 0.0, er = i < n - 1 ? fabs(e[i]) : 0.0;
     dd[i] = di;
     e2[i] = (i < n - 1) ? e[i] * e[i] : 0.0;
+    ee[i] = (i < n - 1) ? e[i] : 0.0;
     lo = fmin(lo, di - el - er);
     hi = fmax(hi, di + el + er);
     emax = fmax(emax, er);
@@ -321,7 +372,7 @@ __global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__
   if (lane == 0) { red[wave][0] = lo; red[wave][1] = hi; red[wave][2] = emax; red[wave][3] = nrm1; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < 8; ++w) {
       red[0][0] = fmin(red[0][0], red[w][0]);
       red[0][1] = fmax(red[0][1], red[w][1]);
       red[0][2] = fmax(red[0][2], red[w][2]);
@@ -336,9 +387,10 @@ __global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__
   __syncthreads();
   const double glo = sh_scal[0], ghi = sh_scal[1], pivmin = sh_scal[2], tnorm = sh_scal[3];
 
-  // ---- bisection: wave w finds eigenvalues 2w and 2w+1 of the top 8 (ascending order)
-  for (int q = 0; q < 2; ++q) {
-    const int ev = 2 * wave + q;
+  // ---- bisection: wave w finds eigenvalue w of the top 8 (ascending order); a Sturm count is a
+  // chain of n float64 divisions, so the eight counts run side by side
+  {
+    const int ev = wave;
     const int idx = n - NEV + ev;           // 0-based index in the ascending spectrum
     double a = glo, b = ghi;
     for (int round = 0; round < 14; ++round) {
@@ -377,27 +429,33 @@ __global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__
     const double l = lam[tid];
     const double tiny = eps * fmax(tnorm, 1e-300);
     // LU with partial pivoting of T - l*I (rows k, k+1 at a time)
+    // (the stored U diagonal is its guarded reciprocal: the back substitution multiplies)
+    auto guarded_rcp = [&](double a) {
+      if (fabs(a) < tiny) a = a < 0.0 ? -tiny : tiny;
+      return fast_rcp(a);
+    };
     double ak = dd[0] - l;                                   // current diagonal of row k
-    double bk = n > 1 ? e[0] : 0.0;                          // current super-diagonal of row k
+    double bk = n > 1 ? ee[0] : 0.0;                         // current super-diagonal of row k
     for (int k = 0; k < n - 1; ++k) {
-      const double ck = e[k];                                // sub-diagonal entry (row k+1, col k)
+      const double ck = ee[k];                               // sub-diagonal entry (row k+1, col k)
       const double a1 = dd[k + 1] - l;                       // row k+1 diagonal
-      const double b1 = (k < n - 2) ? e[k + 1] : 0.0;        // row k+1 super-diagonal
+      const double b1 = (k < n - 2) ? ee[k + 1] : 0.0;       // row k+1 super-diagonal
       double ua, ub, ud, mult, na1, nb1;
       double flag;
       if (fabs(ck) <= fabs(ak)) {
         flag = 0.0;
-        mult = (ak != 0.0) ? ck / ak : 0.0;
+        mult = (ak != 0.0) ? ck * fast_rcp(ak) : 0.0;
         ua = ak; ub = bk; ud = 0.0;
         na1 = a1 - mult * bk;
         nb1 = b1;
       } else {
         flag = 1.0;
-        mult = ak / ck;
+        mult = ak * fast_rcp(ck);
         ua = ck; ub = a1; ud = b1;
         na1 = bk - mult * a1;
         nb1 = -mult * b1;
       }
+      ua = guarded_rcp(ua);
       fa[(int64_t)k * NEV + tid] = ua;
       fb[(int64_t)k * NEV + tid] = ub;
       fd[(int64_t)k * NEV + tid] = ud;
@@ -406,7 +464,7 @@ __global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__
       ak = na1;
       bk = nb1;
     }
-    fa[(int64_t)(n - 1) * NEV + tid] = ak;
+    fa[(int64_t)(n - 1) * NEV + tid] = guarded_rcp(ak);
     fb[(int64_t)(n - 1) * NEV + tid] = 0.0;
     fd[(int64_t)(n - 1) * NEV + tid] = 0.0;
     // start vector: deterministic, no special structure
@@ -418,122 +476,160 @@ __global__ __launch_bounds__(256) void tri_eig_kernel(const double* __restrict__
     (void)tiny;
   }
   __syncthreads();
-  for (int iter = 0; iter < 5; ++iter) {
-    __threadfence_block();
-    if (tid < NEV) {
-      const double tiny = eps * fmax(tnorm, 1e-300);
-      // forward substitution with the recorded interchanges
-      double yk = x[tid];
-      for (int k = 0; k < n - 1; ++k) {
-        const double mult = fc[(int64_t)k * NEV + tid];
-        const double y1 = x[(k + 1) * NEV + tid];
-        if (fp[(int64_t)k * NEV + tid] == 0.0) {
-          x[k * NEV + tid] = yk;
-          yk = y1 - mult * yk;
-        } else {
-          x[k * NEV + tid] = y1;
-          yk = yk - mult * y1;
+  // From here on only wave 0 works (lanes 0..7 solve, then all 64 lanes orthonormalise with wave
+  // shuffles): no workgroup barrier inside the iteration loop.
+  if (wave == 0) {
+    for (int iter = 0; iter < 5; ++iter) {
+      if (lane < NEV) {
+        const double tiny = eps * fmax(tnorm, 1e-300);
+        // forward substitution with the recorded interchanges.  The factors live in global memory
+        // (L2): they are fetched eight steps at a time ahead of the recurrence, which only touches LDS.
+        double yk = x[lane];
+        for (int k0 = 0; k0 < n - 1; k0 += 8) {
+          double mu[8], fl[8], xs[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u < n - 1 ? k0 + u : n - 2;
+            mu[u] = fc[(int64_t)k * NEV + lane];
+            fl[u] = fp[(int64_t)k * NEV + lane];
+            xs[u] = x[(k + 1) * NEV + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u;
+            if (k < n - 1) {
+              const double y1 = xs[u];
+              if (fl[u] == 0.0) {
+                x[k * NEV + lane] = yk;
+                yk = y1 - mu[u] * yk;
+              } else {
+                x[k * NEV + lane] = y1;
+                yk = yk - mu[u] * y1;
+              }
+            }
+          }
+        }
+        x[(n - 1) * NEV + lane] = yk;
+        // back substitution
+        double x1 = 0.0, x2 = 0.0;
+        for (int k0 = n - 1; k0 >= 0; k0 -= 8) {
+          double ua[8], ub[8], ud[8], xs[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 - u >= 0 ? k0 - u : 0;
+            ua[u] = fa[(int64_t)k * NEV + lane];        // reciprocal of the (guarded) U diagonal
+            ub[u] = fb[(int64_t)k * NEV + lane];
+            ud[u] = fd[(int64_t)k * NEV + lane];
+            xs[u] = x[k * NEV + lane];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 - u;
+            if (k >= 0) {
+              const double t = (xs[u] - ub[u] * x1 - ud[u] * x2) * ua[u];
+              x[k * NEV + lane] = t;
+              x2 = x1;
+              x1 = t;
+            }
+          }
         }
       }
-      x[(n - 1) * NEV + tid] = yk;
-      // back substitution
-      double x1 = 0.0, x2 = 0.0;
-      for (int k = n - 1; k >= 0; --k) {
-        double t = x[k * NEV + tid] - fb[(int64_t)k * NEV + tid] * x1 - fd[(int64_t)k * NEV + tid] * x2;
-        double ak = fa[(int64_t)k * NEV + tid];
-        if (fabs(ak) < tiny) ak = ak < 0.0 ? -tiny : tiny;
-        t /= ak;
-        x[k * NEV + tid] = t;
-        x2 = x1;
-        x1 = t;
+      __builtin_amdgcn_wave_barrier();
+      // modified Gram-Schmidt inside clusters + normalisation
+      for (int j = 0; j < NEV; ++j) {
+        for (int i = j - 1; i >= 0; --i) {
+          if (lam[i + 1] - lam[i] > ortol) break;          // cluster chain ends
+          double dot = 0.0;
+          for (int r = lane; r < n; r += 64) dot += x[r * NEV + i] * x[r * NEV + j];
+          for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+          for (int r = lane; r < n; r += 64) x[r * NEV + j] -= dot * x[r * NEV + i];
+        }
+        double nn = 0.0;
+        for (int r = lane; r < n; r += 64) nn += x[r * NEV + j] * x[r * NEV + j];
+        for (int off = 32; off > 0; off >>= 1) nn += __shfl_xor(nn, off, 64);
+        const double nrm = sqrt(nn);
+        const double sc = nrm > 0.0 ? 1.0 / nrm : 0.0;
+        for (int r = lane; r < n; r += 64) x[r * NEV + j] *= sc;
       }
-    }
-    __syncthreads();
-    // modified Gram-Schmidt inside clusters + normalisation, all threads
-    for (int j = 0; j < NEV; ++j) {
-      for (int i = j - 1; i >= 0; --i) {
-        if (lam[i + 1] - lam[i] > ortol) break;          // cluster chain ends
-        double part = 0.0;
-        for (int r = tid; r < n; r += 256) part += x[r * NEV + i] * x[r * NEV + j];
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        __syncthreads();
-        if (lane == 0) red[wave][0] = part;
-        __syncthreads();
-        const double dot = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        for (int r = tid; r < n; r += 256) x[r * NEV + j] -= dot * x[r * NEV + i];
-        __syncthreads();
-      }
-      double part = 0.0;
-      for (int r = tid; r < n; r += 256) part += x[r * NEV + j] * x[r * NEV + j];
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-      __syncthreads();
-      if (lane == 0) red[wave][0] = part;
-      __syncthreads();
-      const double nrm = sqrt(red[0][0] + red[1][0] + red[2][0] + red[3][0]);
-      const double sc = nrm > 0.0 ? 1.0 / nrm : 0.0;
-      for (int r = tid; r < n; r += 256) x[r * NEV + j] *= sc;
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
   }
-  for (int r = tid; r < n * NEV; r += 256) Z[r] = x[r];
+  __syncthreads();
+  for (int r = tid; r < n * NEV; r += 512) Z[r] = x[r];
   if (tid < NEV) lam_out[tid] = lam[tid];
 }
 
-// Z <- Q Z with Q = H_0 H_1 ... H_{n-2}; then sign rule and scaling.  block: 256.
-// dynamic LDS: z[n][8] doubles.
-__global__ __launch_bounds__(256) void backtransform_kernel(const double* __restrict__ V,
+// Z <- Q Z with Q = H_0 H_1 ... H_{n-2}; then sign rule and scaling.
+// One wave per eigenvector column, the column in registers (row i = lane + 64 t): applying a
+// reflector is a dot product and an axpy inside the wave - shuffles, no workgroup barrier (the
+// previous version spent its 1.0 ms at L = 300 in 600 barriers).  The reflector rows are fetched G
+// steps ahead.  block: 512 (8 waves = 8 columns); T = ceil(n / 64) rows per lane.
+template <int T, int G>
+__global__ __launch_bounds__(512) void backtransform_kernel(const double* __restrict__ V,
                                                             const double* __restrict__ tau,
                                                             const double* __restrict__ lam,
                                                             const double* __restrict__ Z, int n,
                                                             float* __restrict__ mds) {
-  extern __shared__ __attribute__((aligned(16))) double z[];
-  __shared__ double red[4][NEV];
-  __shared__ double bestv[4][NEV];
-  __shared__ int besti[4][NEV];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = tid & 7, rl = tid >> 3;            // column, row lane (32 row lanes)
-  for (int r = tid; r < n * NEV; r += 256) z[r] = Z[r];
-  __syncthreads();
-  for (int k = n - 2; k >= 0; --k) {
-    const double tk = tau[k];
-    if (tk == 0.0) continue;
-    const int m = n - k - 1;
-    const double* vk = V + (int64_t)k * n;
-    double part = 0.0;
-    for (int i = rl; i < m; i += 32) part += vk[i] * z[(k + 1 + i) * NEV + c];
-    part += __shfl_xor(part, 8, 64);
-    part += __shfl_xor(part, 16, 64);
-    part += __shfl_xor(part, 32, 64);
-    if (lane < NEV) red[wave][lane] = part;
-    __syncthreads();
-    const double s = tk * (red[0][c] + red[1][c] + red[2][c] + red[3][c]);
-    for (int i = rl; i < m; i += 32) z[(k + 1 + i) * NEV + c] -= s * vk[i];
-    __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double z[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = lane + 64 * t;
+    z[t] = i < n ? Z[(int64_t)i * NEV + c] : 0.0;
+  }
+  for (int kg = n - 2; kg >= 0; kg -= G) {
+    double vv[G][T];
+    double tk[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k = kg - g;
+      tk[g] = k >= 0 ? tau[k] : 0.0;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int ip = lane + 64 * t - (k + 1);          // index into reflector k (acts on rows k+1..)
+        vv[g][t] = (k >= 0 && ip >= 0 && lane + 64 * t < n) ? V[(int64_t)k * n + ip] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (tk[g] == 0.0) continue;                        // uniform
+      double part = 0.0;
+#pragma unroll
+      for (int t = 0; t < T; ++t) part += vv[g][t] * z[t];
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      const double s = tk[g] * part;
+#pragma unroll
+      for (int t = 0; t < T; ++t) z[t] -= s * vv[g][t];
+    }
   }
   // sign rule: largest |component| positive, first index on ties
   double bv = -1.0;
   int bi = 0x7fffffff;
-  for (int i = rl; i < n; i += 32) {
-    const double a = fabs(z[i * NEV + c]);
-    if (a > bv) { bv = a; bi = i; }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = lane + 64 * t;
+    const double a = fabs(z[t]);
+    if (i < n && a > bv) { bv = a; bi = i; }
   }
-  for (int off = 8; off < 64; off <<= 1) {
+  double bz = 0.0;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    if (lane + 64 * t == bi) bz = z[t];
+  for (int off = 1; off < 64; off <<= 1) {
     const double ov = __shfl_xor(bv, off, 64);
     const int oi = __shfl_xor(bi, off, 64);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    const double oz = __shfl_xor(bz, off, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bz = oz; }
   }
-  if (lane < NEV) { bestv[wave][lane] = bv; besti[wave][lane] = bi; }
-  __syncthreads();
-  bv = bestv[0][c]; bi = besti[0][c];
-  for (int w = 1; w < 4; ++w) {
-    const double ov = bestv[w][c];
-    const int oi = besti[w][c];
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-  }
-  const double sgn = z[bi * NEV + c] < 0.0 ? -1.0 : 1.0;
+  const double sgn = bz < 0.0 ? -1.0 : 1.0;
   const float lf = (float)lam[c];
   const float scale = sqrtf(fmaxf(fmaxf(lf, 0.0f), 1e-8f));
-  for (int i = rl; i < n; i += 32) mds[(int64_t)i * NEV + c] = (float)(sgn * z[i * NEV + c]) * scale;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = lane + 64 * t;
+    if (i < n) mds[(int64_t)i * NEV + c] = (float)(sgn * z[t]) * scale;
+  }
 }
 
 constexpr int TRI_CHAIN = 64;     // Householder steps per graph replay
@@ -602,11 +698,16 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
     }
     DMP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(256), sizeof(double) * (2 + NEV) * n, s, d, e, n,
+  hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(512), sizeof(double) * (3 + NEV) * n, s, d, e, n,
                      F, lam, Z);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(backtransform_kernel, dim3(1), dim3(256), sizeof(double) * NEV * n, s, V, tau,
-                     lam, Z, n, d_mds);
+  if (n <= 320)
+    hipLaunchKernelGGL((backtransform_kernel<5, 4>), dim3(1), dim3(512), 0, s, V, tau, lam, Z, n, d_mds);
+  else if (n <= 640)
+    hipLaunchKernelGGL((backtransform_kernel<10, 2>), dim3(1), dim3(512), 0, s, V, tau, lam, Z, n, d_mds);
+  else if (n <= 1280)
+    hipLaunchKernelGGL((backtransform_kernel<20, 1>), dim3(1), dim3(512), 0, s, V, tau, lam, Z, n, d_mds);
+  else { set_error("eigh_top8: order %d exceeds 1280", n); return DMP_ERR_CAPACITY; }
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
