@@ -153,6 +153,7 @@ struct dmp_ctx {
   int conv_mode = 0;           // 0: f16x3 split products (default), 1: exact f32 MFMA, 2: bf16x6 split
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
   bool conv_attr_set = false;  // hipFuncSetAttribute(max dynamic LDS) done for this context's device
+  int conv_lds = 0;            // dynamic LDS bytes requested for the f16x3 convolution
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm

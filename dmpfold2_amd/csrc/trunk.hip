@@ -610,8 +610,12 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
     if (!c->conv_attr_set) {       // per context (= per device): dynamic LDS above 64 KB needs the opt-in
       DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, CONVQ_LDS_BYTES));
+      // tuning experiment: DMP_CONV_LDS=<bytes> requests more LDS than the kernel uses (> 80 KB leaves
+      // one convolution workgroup per CU and room for other kernels beside it)
+      const char* env = getenv("DMP_CONV_LDS");
+      c->conv_lds = env ? std::max(atoi(env), (int)CONVH_LDS_BYTES) : (int)CONVH_LDS_BYTES;
       DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, CONVH_LDS_BYTES));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, c->conv_lds));
       c->conv_attr_set = true;
     }
     if (!c->xsplit_current) {
@@ -622,7 +626,7 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
       hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(grid), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
                          B.bias, L, P, tiles, nwork, d_u, c->part);
     else
-      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,
+      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), c->conv_lds, s, c->xsplit, B.wh,
                          B.bias, B.wh_inv_scale, L, P, tiles, nwork, d_u, c->part);
     DMP_LAUNCH_CHECK();
     return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;

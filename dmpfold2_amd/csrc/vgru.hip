@@ -21,8 +21,8 @@
 // Workgroup = 8 waves = two groups of four, each group one K = 512 product on a (32 hidden x 32
 // column) tile split four ways (layer 1: recurrent and input product of one tile; layer 0: the
 // recurrent products of two tiles, the K = 22 -> 32 one-hot input product generated in registers by
-// wave 0 of the group).  The K slices are summed through LDS behind one barrier and four waves per
-// tile apply the gate maths (ATen gru_cell: h' = (h - n) z + n).
+// wave 0 of the group).  The K slices are summed through LDS (two rounds: r and z, then the third
+// gate) and four waves per tile apply the gate maths (ATen gru_cell: h' = (h - n) z + n).
 // Block b runs on XCD b % 8; XCD x owns hidden tiles 2x, 2x+1 of both layers, so the weights it
 // streams every step (1.6 MB) stay in its 4 MB L2.
 // The N + 1 dependent launches are replayed from hipGraph chains of 128 (or 16) step nodes; what
@@ -32,10 +32,11 @@
 namespace dmp {
 
 #ifndef VG_CH
-#define VG_CH 2      // MFMA steps per load chunk (double-buffered)
+#define VG_CH 1      // MFMA steps per load chunk (double-buffered)
 #endif
 #ifndef VG_OCC
-#define VG_OCC 2     // waves per SIMD the register budget is compiled for (2 = one workgroup per CU)
+#define VG_OCC 4     // waves per SIMD the register budget is compiled for (4 = 128 VGPRs: two step
+                     // workgroups per CU, or one beside a convolution workgroup)
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 vg_f16x8 __attribute__((ext_vector_type(8)));
@@ -123,7 +124,13 @@ __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const u
   }
 }
 
-constexpr int VG_LDS_BYTES = (8 * 3 + 2) * 16 * 64 * 4;   // 106496: per-wave partial sums + layer-0 input part
+#ifndef VG_LDS2
+#define VG_LDS2 1    // 1: two-round K reduction through 72 KB of LDS instead of one round through 104 KB.
+                     // Standalone both take 24.5 ms at L=300, N=2000; in throughput mode the small
+                     // footprint (72 KB, 128 VGPRs) fits beside one convolution workgroup of another
+                     // target: 5.95 -> 6.13 structures/s
+#endif
+constexpr int VG_LDS_BYTES = (8 * (VG_LDS2 ? 2 : 3) + 2) * 16 * 64 * 4;   // per-wave partial sums + layer-0 input part
 
 // column pitch of the state buffers / number of workgroups of a step: per XCD 2 hidden tiles x
 // (nbt layer-1 tiles + ceil(nbt/2) layer-0 pairs)
@@ -224,10 +231,15 @@ __global__ __launch_bounds__(512, VG_OCC) void vgru_step_kernel(VStatic st, cons
   const float4 bH = *reinterpret_cast<const float4*>(bias + 1536 + j4);
   const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
   const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
-  float* mine = vg_red + (int64_t)wave * (3 * 16 * 64);
-  float* red_in = vg_red + 8 * 3 * 16 * 64 + grp * (16 * 64);
-  const float* g0 = vg_red + (int64_t)(layer ? 0 : 4 * grp) * (3 * 16 * 64);   // the recurrent group's 4 waves
-  const float* g1 = vg_red + (int64_t)4 * (3 * 16 * 64);                        // layer 1: the input group's
+  // Partial sums per wave: all three gates at once (VG_LDS2 = 0: 104 KB of LDS, one barrier) or r, z
+  // first and the third gate in a second round through the same buffer (VG_LDS2 = 1: 72 KB, three
+  // barriers) - the smaller footprint lets a step workgroup share a CU with a convolution workgroup.
+  constexpr int WS = (VG_LDS2 ? 2 : 3) * 16 * 64;           // floats per wave
+  float* mine = vg_red + (int64_t)wave * WS;
+  float* red_in = vg_red + 8 * WS + grp * (16 * 64);
+  const float* g0 = vg_red + (int64_t)(layer ? 0 : 4 * grp) * WS;   // the recurrent group's 4 waves
+  const float* g1 = vg_red + (int64_t)4 * WS;                        // layer 1: the input group's
+  auto sum4 = [&](const float* p) { return (p[0] + p[WS]) + (p[2 * WS] + p[3 * WS]); };
 
 #pragma unroll
   for (int n = 0; n < VG_NSUB; ++n) {
@@ -237,13 +249,42 @@ __global__ __launch_bounds__(512, VG_OCC) void vgru_step_kernel(VStatic st, cons
     for (int r = 0; r < 16; ++r) {
       mine[(0 * 16 + r) * 64 + lane] = A.r[n][r];
       mine[(1 * 16 + r) * 64 + lane] = A.z[n][r];
-      mine[(2 * 16 + r) * 64 + lane] = A.t[n][r];
+      if (!VG_LDS2) mine[(2 * 16 + r) * 64 + lane] = A.t[n][r];
     }
     if (layer == 0 && w == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red_in[r * 64 + lane] = acc_in[n][r];
     }
     __syncthreads();
+    float S[4][4];      // [q][r, z, in, hn]
+    if (finisher) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = w * 4 + q;
+#pragma unroll
+        for (int g = 0; g < (VG_LDS2 ? 2 : 3); ++g) {
+          float v = sum4(g0 + (g * 16 + r) * 64 + lane);
+          if (layer && g < 2) v += sum4(g1 + (g * 16 + r) * 64 + lane);
+          S[q][g == 2 ? 3 : g] = v;
+        }
+        if (!VG_LDS2 && layer) S[q][2] = sum4(g1 + (2 * 16 + r) * 64 + lane);
+        if (!layer) S[q][2] = red_in[r * 64 + lane];
+      }
+    }
+    if (VG_LDS2) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = A.t[n][r];
+      __syncthreads();
+      if (finisher) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = w * 4 + q;
+          S[q][3] = sum4(g0 + r * 64 + lane);
+          if (layer) S[q][2] = sum4(g1 + r * 64 + lane);
+        }
+      }
+    }
     if (!finisher) continue;
     const int b = b0 + 32 * n + li;
     const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
@@ -253,23 +294,7 @@ __global__ __launch_bounds__(512, VG_OCC) void vgru_step_kernel(VStatic st, cons
     unsigned short q0[4], q1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int r = w * 4 + q;
-      float s[4];      // r, z, in, hn
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const float* p = g0 + (g * 16 + r) * 64 + lane;
-        s[g == 2 ? 3 : g] = (p[0] + p[3 * 16 * 64]) + (p[2 * 3 * 16 * 64] + p[3 * 3 * 16 * 64]);
-      }
-      if (layer) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const float* p = g1 + (g * 16 + r) * 64 + lane;
-          const float v = (p[0] + p[3 * 16 * 64]) + (p[2 * 3 * 16 * 64] + p[3 * 3 * 16 * 64]);
-          if (g == 2) s[2] = v; else s[g] += v;
-        }
-      } else {
-        s[2] = red_in[r * 64 + lane];
-      }
+      const float* s = S[q];
       const float rg = vsigmoid(s[0] * inv + br[q]);
       const float zg = vsigmoid(s[1] * inv + bz[q]);
       const float ng = tanhf((s[2] * inv + bi[q]) + rg * (s[3] * inv + bh[q]));
