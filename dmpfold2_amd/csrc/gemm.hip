@@ -9,7 +9,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 16, LDS_PITCH = 132;
 
-template <bool A_MCONTIG, bool B_NCONTIG>
+// TWO_LEVEL (K > 256 only) costs 64 more VGPRs; without it the kernel stays under the 160 registers
+// that are free beside two f16x3 convolution workgroups per CU.
+template <bool A_MCONTIG, bool B_NCONTIG, bool TWO_LEVEL>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ float As[2][BK][LDS_PITCH];
   __shared__ float Bs[2][BK][LDS_PITCH];
@@ -59,13 +61,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // single float32 chain over thousands of equal-signed terms drifts (covariance diagonal at
   // N = 2000: 1.7e-5 relative, tests/test_gpu_fullsize.py); chunks of 256 keep it at the 1e-7 level
   // of a blocked CPU GEMM.  K <= 256 (Gauss-Jordan updates) is unchanged.
-  f32x16 tot[2][2];
+  f32x16 tot[TWO_LEVEL ? 2 : 1][TWO_LEVEL ? 2 : 1];
+  if constexpr (TWO_LEVEL) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  }
 
   const int nk = (g.K + BK - 1) / BK;
   load_tiles(0);
@@ -86,13 +90,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if ((kt & 15) == 15 && kt + 1 < nk) {
+    if (TWO_LEVEL && (kt & 15) == 15 && kt + 1 < nk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+          for (int r = 0; r < 16; ++r) { tot[TWO_LEVEL ? i : 0][TWO_LEVEL ? j : 0][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
     __syncthreads();
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (gm >= g.M) continue;
         float* p = g.C + (int64_t)gm * g.ldc + gn;
-        float v = g.alpha * (tot[i][j][r] + acc[i][j][r]) + bn;
+        float v = g.alpha * (TWO_LEVEL ? tot[TWO_LEVEL ? i : 0][TWO_LEVEL ? j : 0][r] + acc[i][j][r] : acc[i][j][r]) + bn;
         if (g.beta != 0.f) v += g.beta * *p;
         *p = v;
       }
@@ -122,10 +126,17 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0) return DMP_OK;
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
   const bool am = (g.sam == 1), bn = (g.sbn == 1);
-  if (am && bn) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, g);
-  else if (am && !bn) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, g);
-  else if (!am && bn) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, g);
+  const bool two = g.K > 256;
+#define GEMM_LAUNCH(A_, B_)                                                                   \
+  do {                                                                                        \
+    if (two) hipLaunchKernelGGL((gemm_kernel<A_, B_, true>), grid, dim3(256), 0, s, g);       \
+    else hipLaunchKernelGGL((gemm_kernel<A_, B_, false>), grid, dim3(256), 0, s, g);          \
+  } while (0)
+  if (am && bn) GEMM_LAUNCH(true, true);
+  else if (am && !bn) GEMM_LAUNCH(true, false);
+  else if (!am && bn) GEMM_LAUNCH(false, true);
+  else GEMM_LAUNCH(false, false);
+#undef GEMM_LAUNCH
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

@@ -643,6 +643,9 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
 //   out_c = (y_c*cse_c + y_c*s) + x_c
 // ---------------------------------------------------------------------------------------
 // SPLIT: -1 = float32 output only, 0 / 2 = also write f16 / bf16 pieces (store_pieces)
+// Two threads per pixel (lane halves of a wave, 64 channels each: about 100 VGPRs).  Two f16x3
+// convolution workgroups per CU leave 512 - 2*176 = 160 registers per SIMD lane, so this kernel's
+// waves can run beside the convolutions of another target (with one thread per pixel it needed 170).
 template <int SPLIT>
 __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     const float* __restrict__ u, const float* __restrict__ ab, const float* __restrict__ cse,
@@ -656,26 +659,34 @@ __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     sh_w[threadIdx.x] = sse_w[threadIdx.x];
   }
   __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5;                       // channels [64 half, 64 half + 64)
   const int y = blockIdx.y;
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x >= L) return;
+  const int x = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const bool live = x < L;
+  const int xc = live ? x : L - 1;                  // clamped lanes compute, do not store
   const int64_t LL = (int64_t)L * L, PP = (int64_t)P * P;
-  const int64_t p = (int64_t)y * L + x, pp = (int64_t)(y + 2) * P + x + 2;
-  float yv[CW];
+  const int64_t p = (int64_t)y * L + xc, pp = (int64_t)(y + 2) * P + xc + 2;
+  constexpr int HC = CW / 2;
+  float yv[HC];
   float dot = 0.f;
 #pragma unroll
-  for (int c = 0; c < CW; ++c) {
-    yv[c] = u[c * LL + p] * sh_a[c] + sh_b[c];
-    dot = fmaf(sh_w[c], yv[c], dot);
+  for (int i = 0; i < HC; ++i) {
+    const int c = half * HC + i;
+    yv[i] = u[c * LL + p] * sh_a[c] + sh_b[c];
+    dot = fmaf(sh_w[c], yv[i], dot);
   }
-  const float sg = sigmoid_f(dot + sse_b);
+  const float other = __shfl_xor(dot, 32, 64);
+  const float sg = sigmoid_f((half ? other + dot : dot + other) + sse_b);   // channels 0..63 first, then 64..127
+  if (!live) return;
 #pragma unroll
-  for (int cgp = 0; cgp < CW / 8; ++cgp) {
+  for (int g8 = 0; g8 < HC / 8; ++g8) {
+    const int cgp = half * (HC / 8) + g8;
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = cgp * 8 + e;
-      const float t = yv[c] * sh_g[c] + yv[c] * sg;      // contraction is off for this file
+      const float t = yv[g8 * 8 + e] * sh_g[c] + yv[g8 * 8 + e] * sg;      // contraction is off for this file
       o[e] = t + xin[c * PP + pp];
       xout[c * PP + pp] = o[e];
     }
@@ -694,7 +705,7 @@ int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const dou
   DMP_LAUNCH_CHECK();
   // inside a trunk pass the kernel also emits the pieces the next convolution reads
   const int split = (c->conv_mode != 1 && c->xsplit_current) ? c->conv_mode : -1;
-  dim3 grid(cdiv(L, 256), L);
+  dim3 grid(cdiv(L, 128), L);
 #define NORM_LAUNCH(S)                                                                              \
   hipLaunchKernelGGL(norm_scse_residual_kernel<S>, grid, dim3(256), 0, s, d_u, c->ab, B.cse, B.sse_w, \
                      B.sse_b, d_xpad_in, L, P, d_xpad_out, c->xsplit, c->seq_abort)
