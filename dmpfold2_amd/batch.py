@@ -43,7 +43,7 @@ def read_target_list(path):
 
 
 def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_minsteps,
-              weights_file=None, state_dict=None, streams=3, device=None, rank=0, world=1):
+              weights_file=None, state_dict=None, streams=4, device=None, rank=0, world=1):
     """Predict the targets of this rank's shard; returns (number done, seconds, [output paths])."""
     os.makedirs(out_dir, exist_ok=True)
     parsed = []
@@ -89,7 +89,7 @@ def main(argv=None):
     ap.add_argument("-n", "--iterations", type=int, default=default_iterations)
     ap.add_argument("-m", "--minsteps", type=int, default=default_minsteps)
     ap.add_argument("-w", "--model_weights", type=str, default=None)
-    ap.add_argument("--streams", type=int, default=3, help="targets in flight per GPU")
+    ap.add_argument("--streams", type=int, default=4, help="targets in flight per GPU")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))

@@ -335,6 +335,10 @@ class Pipeline:
         lib = self.lib
         gated = len(self.engines) > 1
         progressed = False
+        # engines whose next unit is a residual block: when there is only one, nobody else can use the
+        # lane, so it may queue its next block behind the running one instead of draining first
+        n_conv = sum(1 for s, e in enumerate(self.engines)
+                     if self._slot[s] is not None and lib.dmp_predict_next_unit(e.ctx) == 2) if gated else 0
         for s, e in enumerate(self.engines):
             if self._slot[s] is None:
                 if not self._pending:
@@ -365,7 +369,7 @@ class Pipeline:
                     # a convolution is handed the lane only when it can start at once; light units
                     # are kept one deep so this loop returns to the other engines quickly
                     busy = _lib.check(lib.dmp_ctx_pending(e.ctx))
-                    if busy > (0 if kind == 2 else 1):
+                    if busy > (0 if (kind == 2 and n_conv > 1) else 1):
                         break
                 _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
                 progressed = True
