@@ -42,6 +42,9 @@ constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slo
 #ifndef CH_MAP_PAIR
 #define CH_MAP_PAIR 1        // 1: each XCD handles two of the four channel splits (see the kernel);
 #endif                       //    same time, fabric reads per launch 361 -> 257 MB (tools/pmc_fetch.sh)
+#ifndef CH_VGPR_CAP
+#define CH_VGPR_CAP          // e.g. __attribute__((amdgpu_waves_per_eu(3, 3))) caps the kernel at 168 VGPRs
+#endif
 // number of workgroups to launch for tiles x tiles pixel tiles
 inline int conv_f16_grid(int tiles) {
   const int ntiles = tiles * tiles;
@@ -108,7 +111,7 @@ __device__ __forceinline__ ch_f32x16 ch_mfma(uint4 a, uint4 b, ch_f32x16 c) {
 }
 
 // grid: conv_f16_grid(tiles) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
-__global__ __launch_bounds__(256, CH_OCC) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
+__global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
                                                                const uint16_t* __restrict__ wq,
                                                                const float* __restrict__ bias, float inv_scale,
                                                                int L, int P, int tiles, int nwork,

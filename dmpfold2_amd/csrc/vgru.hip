@@ -71,7 +71,6 @@ struct VRun {
 constexpr int VG_NSUB = VG_NSUB_N;     // 32-column subtiles per wave: the weight operands are reused VG_NSUB times
 constexpr int VG_TB = 32 * VG_NSUB;    // columns per tile
 
-struct VAcc { f32x16 r[VG_NSUB], z[VG_NSUB], t[VG_NSUB]; };
 
 // One wave's quarter of a K = 512 contraction: MFMA steps s = w, w+4, ..., w+28 (16 k each), three
 // gate accumulators per column subtile.  Hand-staged: the loads of the next chunk are issued before
@@ -83,235 +82,181 @@ struct VAcc { f32x16 r[VG_NSUB], z[VG_NSUB], t[VG_NSUB]; };
 // reused from registers, 0.6x the total L2 traffic, but half as many workgroups pulling 1.25x the
 // bytes each) run 18 us per step.
 __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const uint4* __restrict__ xp, int Lb,
-                                           int w, int kk, VAcc& A) {
-  uint4 wv[2][VG_CH][3][2];          // [buffer][step][gate][piece]
-  uint4 xv[2][VG_CH][VG_NSUB][2];    // [buffer][step][subtile][piece]
-  auto load_chunk = [&](int buf, int c) {
+                                           int w, int kk, f32x16& ar, f32x16& az, f32x16& at) {
+  // Two operand sets (6 weight + 2 state loads of 16 bytes each) alternate: the loads of step c+1
+  // are in flight during the nine MFMAs of step c.  The loop is kept rolled (two steps per trip) so
+  // the kernel stays inside the register budget that lets it share a CU with two convolution
+  // workgroups; fully unrolled the compiler hoists loads and needs 200 registers.
+  const uint4* wq = wp + (int64_t)(2 * w + kk) * 512;
+  const uint4* xq = xp + (int64_t)(2 * w + kk) * Lb;
+  uint4 a0[6], b0[2], a1[6], b1[2];
+  auto load = [&](uint4* a, uint4* b, int c) {           // step c of this wave: k octet pair 8c + 2w + kk
 #pragma unroll
-    for (int u = 0; u < VG_CH; ++u) {
-      const int kq = 2 * (w + 4 * (VG_CH * c + u)) + kk;
+    for (int p = 0; p < 2; ++p) {
+      b[p] = xq[(int64_t)(p * 64 + 8 * c) * Lb];
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-#pragma unroll
-        for (int n = 0; n < VG_NSUB; ++n) xv[buf][u][n][p] = xp[(int64_t)(p * 64 + kq) * Lb + 32 * n];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) wv[buf][u][g][p] = wp[(int64_t)((p * 3 + g) * 64 + kq) * 512];
-      }
+      for (int g = 0; g < 3; ++g) a[p * 3 + g] = wq[(int64_t)((p * 3 + g) * 64 + 8 * c) * 512];
     }
   };
-  load_chunk(0, 0);
-#pragma unroll
-  for (int c = 0; c < 8 / VG_CH; ++c) {
-    if (c + 1 < 8 / VG_CH) load_chunk((c + 1) & 1, c + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < VG_CH; ++u) {
-#pragma unroll
-      for (int n = 0; n < VG_NSUB; ++n) {
-        const uint4 x0 = xv[c & 1][u][n][0], x1 = xv[c & 1][u][n][1];
-        A.r[n] = vg_mfma(wv[c & 1][u][0][0], x1, A.r[n]);
-        A.z[n] = vg_mfma(wv[c & 1][u][1][0], x1, A.z[n]);
-        A.t[n] = vg_mfma(wv[c & 1][u][2][0], x1, A.t[n]);
-        A.r[n] = vg_mfma(wv[c & 1][u][0][1], x0, A.r[n]);
-        A.z[n] = vg_mfma(wv[c & 1][u][1][1], x0, A.z[n]);
-        A.t[n] = vg_mfma(wv[c & 1][u][2][1], x0, A.t[n]);
-        A.r[n] = vg_mfma(wv[c & 1][u][0][0], x0, A.r[n]);
-        A.z[n] = vg_mfma(wv[c & 1][u][1][0], x0, A.z[n]);
-        A.t[n] = vg_mfma(wv[c & 1][u][2][0], x0, A.t[n]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  auto mfma9 = [&](const uint4* a, const uint4* b) {     // a[piece*3 + gate], b[piece]
+    ar = vg_mfma(a[0], b[1], ar);
+    az = vg_mfma(a[1], b[1], az);
+    at = vg_mfma(a[2], b[1], at);
+    ar = vg_mfma(a[3], b[0], ar);
+    az = vg_mfma(a[4], b[0], az);
+    at = vg_mfma(a[5], b[0], at);
+    ar = vg_mfma(a[0], b[0], ar);
+    az = vg_mfma(a[1], b[0], az);
+    at = vg_mfma(a[2], b[0], at);
+  };
+  load(a0, b0, 0);
+#pragma unroll 1
+  for (int c = 0; c < 8; c += 2) {
+    load(a1, b1, c + 1);
+    mfma9(a0, b0);
+    if (c + 2 < 8) load(a0, b0, c + 2);
+    mfma9(a1, b1);
   }
 }
 
-#ifndef VG_LDS2
-#define VG_LDS2 1    // 1: two-round K reduction through 72 KB of LDS instead of one round through 104 KB.
-                     // Standalone both take 24.5 ms at L=300, N=2000; in throughput mode the small
-                     // footprint (72 KB, 128 VGPRs) fits beside one convolution workgroup of another
-                     // target: 5.95 -> 6.13 structures/s
-#endif
-constexpr int VG_LDS_BYTES = (8 * (VG_LDS2 ? 2 : 3) + 2) * 16 * 64 * 4;   // per-wave partial sums + layer-0 input part
+constexpr int VG_LDS_BYTES = 4 * 2 * 16 * 64 * 4;   // 32 KB: partial sums of two gates from four waves
 
 // column pitch of the state buffers / number of workgroups of a step: per XCD 2 hidden tiles x
-// (nbt layer-1 tiles + ceil(nbt/2) layer-0 pairs)
+// (nbt layer-1 tiles + nbt layer-0 tiles)
 __host__ __device__ inline int vgru_pitch(int L) { return (L + VG_TB - 1) / VG_TB * VG_TB; }
-__host__ __device__ inline int vgru_grid(int Lb) {
-  const int nbt = Lb / VG_TB;
-  return 8 * 2 * (nbt + ((nbt + 1) >> 1));
-}
+__host__ __device__ inline int vgru_grid(int Lb) { return 8 * 2 * 2 * (Lb / VG_TB); }
 
-// Every workgroup is two groups of four waves, each group one K = 512 product split four ways on a
-// (32 hidden x 64 column) tile:
-//   layer 1:  group 0 = W_hh h1, group 1 = W_ih h0 of the SAME tile;
-//   layer 0:  group g = W_hh h0 of column tile 2p+g (two tiles per workgroup); the K = 32 one-hot
-//             input product of a tile is done by wave 0 of its group.
-// All workgroups therefore carry the same load (8 waves x 8 MFMA steps x 2 subtiles); at L = 300
-// the 128 of them run as a single round.  Per column subtile: every wave stores its partial sums,
-// barrier, four waves per tile add them up and apply the gate maths.
-// grid: vgru_grid(Lb)   block: 512   dynamic LDS: VG_LDS_BYTES
-__global__ __launch_bounds__(512, VG_OCC) void vgru_step_kernel(VStatic st, const VRun* __restrict__ run,
-                                                                int idx) {
-  extern __shared__ __attribute__((aligned(16))) float vg_red[];   // [8 waves][3][16][64] | [2 groups][16][64]
+// Workgroup = 4 waves (one per SIMD) on one (32 hidden x 32 column) tile of one layer; wave w takes
+// the K quarter {w, w+4, ...} of the recurrent product and, for layer 1, of the input product as
+// well (the r and z accumulators are shared, W_hn h and W_in x are kept apart); for layer 0 wave 0
+// adds the K = 32 one-hot input product.  The partial sums go through LDS two gates at a time
+// (32 KB); every wave then finishes a quarter of the tile's rows.
+// Footprint: 4 waves of at most 160 VGPRs and 32 KB of LDS - exactly what two f16x3 convolution
+// workgroups leave free on a CU (512 - 2*176 registers per SIMD lane, 160 - 2*62 KB), so the steps of
+// one target run beside the convolutions of another (7.3 structures/s if this kernel cost nothing,
+// 6.4 with the previous 8-wave / 72 KB version that needed one of the two convolution slots).
+// grid: vgru_grid(Lb)   block: 256   dynamic LDS: VG_LDS_BYTES
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void vgru_step_kernel(VStatic st, const VRun* __restrict__ run, int idx) {
+  extern __shared__ __attribute__((aligned(16))) float vg_red[];   // [4 waves][2 gates][16][64]
   const int t = run->t0 + idx;
   if (t >= run->t_end) return;
   const int N = run->N, L = run->L, Lb = run->Lb;
   const int nbt = Lb / VG_TB;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int rest = slot >> 1;                       // [0, nbt): layer 1 tiles, [nbt, nbt + ceil(nbt/2)): layer 0 pairs
+  const int rest = slot >> 1;                       // [0, nbt): layer 1 tiles, [nbt, 2 nbt): layer 0 tiles
   const int layer = rest < nbt ? 1 : 0;
   if (layer == 0 && !(t < N)) return;
   if (layer == 1 && !(t >= 1)) return;
   const int par = t & 1;      // layer 0 reads parity t, writes t+1; layer 1 (step t-1) reads t+1, writes t
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, w = wave & 3;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = lane >> 5, li = lane & 31;
   const int j0 = (2 * xcd + (slot & 1)) * 32;
-  const int bt = layer ? rest : 2 * (rest - nbt) + grp;      // this group's column tile
-  const bool valid = bt < nbt;                               // odd tile count: the last pair is half empty
-  const int b0 = bt * VG_TB;
+  const int b0 = (layer ? rest : rest - nbt) * VG_TB;
 
-  VAcc A;                                 // A.t = W_hn h (recurrent groups) or W_in x (layer-1 input group)
-  f32x16 acc_in[VG_NSUB];                 // layer 0, wave 0 of a group: W_in x of the one-hot input
+  f32x16 acc_r, acc_z, acc_hn, acc_in;    // r and z: both products; W_hn h; W_in x
 #pragma unroll
-  for (int n = 0; n < VG_NSUB; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { A.r[n][r] = 0.f; A.z[n][r] = 0.f; A.t[n][r] = 0.f; acc_in[n][r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_hn[r] = 0.f; acc_in[r] = 0.f; }
 
   if (layer == 1) {
-    const uint4* wp = (grp == 0 ? st.wh[1] : st.wx[1]) + (j0 + li);
-    const uint4* xp = reinterpret_cast<const uint4*>(grp == 0 ? st.hH[1][par ^ 1] : st.hH[0][par]) + (b0 + li);
-    k512_steps(wp, xp, Lb, w, kk, A);
-  } else if (valid) {
-    k512_steps(st.wh[0] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[0][par]) + (b0 + li), Lb, w, kk, A);
+    k512_steps(st.wh[1] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[1][par ^ 1]) + (b0 + li), Lb, w, kk,
+               acc_r, acc_z, acc_hn);
+    k512_steps(st.wx[1] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[0][par]) + (b0 + li), Lb, w, kk,
+               acc_r, acc_z, acc_in);
+  } else {
+    k512_steps(st.wh[0] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[0][par]) + (b0 + li), Lb, w, kk,
+               acc_r, acc_z, acc_hn);
     if (w == 0) {
       // layer 0 input: one-hot of the residue code (value 1024 = the state scale), K = 32 (rows
       // 22..31 of the packed weights are 0)
       const uint4* wp = st.wx[0] + (j0 + li);
+      const int b = b0 + li;
+      const int code = (b < L) ? (int)run->msa[(int64_t)t * L + b] : 0;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kq = 2 * s + kk;
-        uint4 wq[3][2];
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) wq[g][p] = wp[(int64_t)((p * 3 + g) * 4 + kq) * 512];
-#pragma unroll
-        for (int n = 0; n < VG_NSUB; ++n) {
-          const int b = b0 + 32 * n + li;
-          const int code = (b < L) ? (int)run->msa[(int64_t)t * L + b] : 0;
-          const int d = code - 8 * kq;                   // position of the hot element among this lane's 8 k
-          const unsigned hot = (d >= 0 && d < 8) ? (0x6400u << (16 * (d & 1))) : 0u;
-          uint4 x;
-          x.x = (d >> 1) == 0 ? hot : 0u;
-          x.y = (d >> 1) == 1 ? hot : 0u;
-          x.z = (d >> 1) == 2 ? hot : 0u;
-          x.w = (d >> 1) == 3 ? hot : 0u;
-          A.r[n] = vg_mfma(wq[0][1], x, A.r[n]);
-          A.z[n] = vg_mfma(wq[1][1], x, A.z[n]);
-          acc_in[n] = vg_mfma(wq[2][1], x, acc_in[n]);
-          A.r[n] = vg_mfma(wq[0][0], x, A.r[n]);
-          A.z[n] = vg_mfma(wq[1][0], x, A.z[n]);
-          acc_in[n] = vg_mfma(wq[2][0], x, acc_in[n]);
-        }
+        const int d = code - 8 * kq;                     // position of the hot element among this lane's 8 k
+        const unsigned hot = (d >= 0 && d < 8) ? (0x6400u << (16 * (d & 1))) : 0u;
+        uint4 x;
+        x.x = (d >> 1) == 0 ? hot : 0u;
+        x.y = (d >> 1) == 1 ? hot : 0u;
+        x.z = (d >> 1) == 2 ? hot : 0u;
+        x.w = (d >> 1) == 3 ? hot : 0u;
+        acc_r = vg_mfma(wp[(int64_t)((1 * 3 + 0) * 4 + kq) * 512], x, acc_r);
+        acc_z = vg_mfma(wp[(int64_t)((1 * 3 + 1) * 4 + kq) * 512], x, acc_z);
+        acc_in = vg_mfma(wp[(int64_t)((1 * 3 + 2) * 4 + kq) * 512], x, acc_in);
+        acc_r = vg_mfma(wp[(int64_t)((0 * 3 + 0) * 4 + kq) * 512], x, acc_r);
+        acc_z = vg_mfma(wp[(int64_t)((0 * 3 + 1) * 4 + kq) * 512], x, acc_z);
+        acc_in = vg_mfma(wp[(int64_t)((0 * 3 + 2) * 4 + kq) * 512], x, acc_in);
       }
     }
   }
 
-  const bool finisher = layer == 1 ? grp == 0 : valid;      // layer 1: waves 0-3; layer 0: every valid group
   const float* bias = st.bias[layer];
   const float inv = st.inv_scale[layer];
   const float* hprev = layer ? st.hT[1][par ^ 1] : st.hT[0][par];
   float* hnext = layer ? st.hT[1][par] : st.hT[0][par ^ 1];
   uint16_t* gnext = layer ? st.hH[1][par] : st.hH[0][par ^ 1];
   const int j4 = j0 + 8 * w + 4 * kk;              // rows (4w+q): j = j4 + q, q = 0..3
-  const float4 bR = *reinterpret_cast<const float4*>(bias + j4);
-  const float4 bZ = *reinterpret_cast<const float4*>(bias + 512 + j4);
-  const float4 bI = *reinterpret_cast<const float4*>(bias + 1024 + j4);
-  const float4 bH = *reinterpret_cast<const float4*>(bias + 1536 + j4);
-  const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
-  const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
-  // Partial sums per wave: all three gates at once (VG_LDS2 = 0: 104 KB of LDS, one barrier) or r, z
-  // first and the third gate in a second round through the same buffer (VG_LDS2 = 1: 72 KB, three
-  // barriers) - the smaller footprint lets a step workgroup share a CU with a convolution workgroup.
-  constexpr int WS = (VG_LDS2 ? 2 : 3) * 16 * 64;           // floats per wave
-  float* mine = vg_red + (int64_t)wave * WS;
-  float* red_in = vg_red + 8 * WS + grp * (16 * 64);
-  const float* g0 = vg_red + (int64_t)(layer ? 0 : 4 * grp) * WS;   // the recurrent group's 4 waves
-  const float* g1 = vg_red + (int64_t)4 * WS;                        // layer 1: the input group's
+  const int b = b0 + li;
+  const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
+  constexpr int WS = 2 * 16 * 64;                  // floats per wave and round
+  float* mine = vg_red + (int64_t)w * WS;
   auto sum4 = [&](const float* p) { return (p[0] + p[WS]) + (p[2 * WS] + p[3 * WS]); };
-
+  float rg[4], zg[4];
+  // round 1: r, z
 #pragma unroll
-  for (int n = 0; n < VG_NSUB; ++n) {
-    // ---- every wave stores its partial sums of subtile n; barrier; four waves per tile finish it
-    if (n > 0) __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      mine[(0 * 16 + r) * 64 + lane] = A.r[n][r];
-      mine[(1 * 16 + r) * 64 + lane] = A.z[n][r];
-      if (!VG_LDS2) mine[(2 * 16 + r) * 64 + lane] = A.t[n][r];
-    }
-    if (layer == 0 && w == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red_in[r * 64 + lane] = acc_in[n][r];
-    }
-    __syncthreads();
-    float S[4][4];      // [q][r, z, in, hn]
-    if (finisher) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = w * 4 + q;
-#pragma unroll
-        for (int g = 0; g < (VG_LDS2 ? 2 : 3); ++g) {
-          float v = sum4(g0 + (g * 16 + r) * 64 + lane);
-          if (layer && g < 2) v += sum4(g1 + (g * 16 + r) * 64 + lane);
-          S[q][g == 2 ? 3 : g] = v;
-        }
-        if (!VG_LDS2 && layer) S[q][2] = sum4(g1 + (2 * 16 + r) * 64 + lane);
-        if (!layer) S[q][2] = red_in[r * 64 + lane];
-      }
-    }
-    if (VG_LDS2) {
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = A.t[n][r];
-      __syncthreads();
-      if (finisher) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = w * 4 + q;
-          S[q][3] = sum4(g0 + r * 64 + lane);
-          if (layer) S[q][2] = sum4(g1 + r * 64 + lane);
-        }
-      }
-    }
-    if (!finisher) continue;
-    const int b = b0 + 32 * n + li;
-    const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
-    const float4 hp4 = *reinterpret_cast<const float4*>(hprev + hoff);
-    const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
-    float hn[4];
-    unsigned short q0[4], q1[4];
+  for (int r = 0; r < 16; ++r) {
+    mine[(0 * 16 + r) * 64 + lane] = acc_r[r];
+    mine[(1 * 16 + r) * 64 + lane] = acc_z[r];
+  }
+  __syncthreads();
+  {
+    const float4 bR = *reinterpret_cast<const float4*>(bias + j4);
+    const float4 bZ = *reinterpret_cast<const float4*>(bias + 512 + j4);
+    const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float* s = S[q];
-      const float rg = vsigmoid(s[0] * inv + br[q]);
-      const float zg = vsigmoid(s[1] * inv + bz[q]);
-      const float ng = tanhf((s[2] * inv + bi[q]) + rg * (s[3] * inv + bh[q]));
-      hn[q] = (hp[q] - ng) * zg + ng;
-      const float hs = hn[q] * VGRU_STATE_SCALE;
-      const _Float16 p0 = (_Float16)hs;
-      const _Float16 p1 = (_Float16)(hs - (float)p0);
-      q0[q] = __builtin_bit_cast(unsigned short, p0);
-      q1[q] = __builtin_bit_cast(unsigned short, p1);
+      const int r = w * 4 + q;
+      rg[q] = vsigmoid(sum4(vg_red + (0 * 16 + r) * 64 + lane) * inv + br[q]);
+      zg[q] = vsigmoid(sum4(vg_red + (1 * 16 + r) * 64 + lane) * inv + bz[q]);
     }
-    *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-    const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
-    *reinterpret_cast<uint2*>(gnext + goff) =
-        make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
-    *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
-        make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
   }
+  __syncthreads();
+  // round 2: W_in x, W_hn h
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    mine[(0 * 16 + r) * 64 + lane] = acc_in[r];
+    mine[(1 * 16 + r) * 64 + lane] = acc_hn[r];
+  }
+  const float4 hp4 = *reinterpret_cast<const float4*>(hprev + hoff);
+  __syncthreads();
+  const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+  const float4 bI = *reinterpret_cast<const float4*>(bias + 1024 + j4);
+  const float4 bH = *reinterpret_cast<const float4*>(bias + 1536 + j4);
+  const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
+  float hn[4];
+  unsigned short q0[4], q1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = w * 4 + q;
+    const float s_in = sum4(vg_red + (0 * 16 + r) * 64 + lane);
+    const float s_hn = sum4(vg_red + (1 * 16 + r) * 64 + lane);
+    const float ng = tanhf((s_in * inv + bi[q]) + rg[q] * (s_hn * inv + bh[q]));
+    hn[q] = (hp[q] - ng) * zg[q] + ng;
+    const float hs = hn[q] * VGRU_STATE_SCALE;
+    const _Float16 p0 = (_Float16)hs;
+    const _Float16 p1 = (_Float16)(hs - (float)p0);
+    q0[q] = __builtin_bit_cast(unsigned short, p0);
+    q1[q] = __builtin_bit_cast(unsigned short, p1);
+  }
+  *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
+  *reinterpret_cast<uint2*>(gnext + goff) =
+      make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
+  *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
+      make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
 }
 
 // out[l][j] = hP[j/4][l][j%4]
@@ -358,7 +303,7 @@ static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
     hipKernelNodeParams kp{};
     kp.func = (void*)vgru_step_kernel;
     kp.gridDim = dim3(grid);
-    kp.blockDim = dim3(512);
+    kp.blockDim = dim3(256);
     kp.sharedMemBytes = VG_LDS_BYTES;
     kp.kernelParams = params;
     kp.extra = nullptr;
