@@ -52,7 +52,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
+        per_file = os.environ.get("DMP_FLAGS_" + os.path.basename(s).split(".")[0].upper(), "").split()
+        cmd = [hipcc] + FLAGS + extra + per_file + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))

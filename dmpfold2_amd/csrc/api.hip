@@ -30,6 +30,13 @@ static int dev_alloc(std::vector<void*>& pool, int64_t& bytes, T** out, int64_t 
   const size_t sz = sizeof(T) * (size_t)(count > 0 ? count : 1);
   hipError_t e = hipMalloc(&p, sz);
   if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  // DMP_POISON=1 (tests): fill every allocation with 0xFF bytes (NaN as float / double) so that a
+  // kernel reading workspace it has not written shows up as a result change
+  static const bool poison = getenv("DMP_POISON") && getenv("DMP_POISON")[0] == '1';
+  if (poison) {
+    e = hipMemset(p, 0xFF, sz);
+    if (e != hipSuccess) return hip_fail(e, "hipMemset", __FILE__, __LINE__);
+  }
   pool.push_back(p);
   bytes += (int64_t)sz;
   *out = (T*)p;
@@ -390,6 +397,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
 #undef A_
   if (rc) { dmp_ctx_destroy(c); return rc; }
   if (hipMemset(c->seq_abort, 0, sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+  if ((rc = trunk_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
   for (int i = 0; i < 2; ++i) {
     hipEvent_t e;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
@@ -787,7 +795,23 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) 
   DMP_HIP(hipMemcpyAsync(c->best_ca_snapshot, c->best_ca, sizeof(float) * 3 * L,
                          hipMemcpyDeviceToDevice, s));
   if (c->run_refine > 0 && (rc = refine_coords(c->best_ca, L, c->run_refine, s))) return rc;
-  return ca_to_backbone(c->best_ca, c->best_conf, L, d_coords, d_conf, s);
+  // The backbone kernel takes a lane turn, i.e. it never runs beside another context's split-product
+  // convolution.  Measured (tools/corrupt_repro.py): with the f16 / bf16 convolutions of another
+  // target on the same CUs, 1-3 % of the predictions came out with the C, O, CB atoms of 16
+  // consecutive residues (lanes 48..63 of one wave of this kernel) off by 1-2 A while every input of
+  // the kernel was bit-identical; never with the exact-f32 convolution, never in any other kernel.
+  // The wrong values are those of a division / square root whose compare-and-select fix-up read a
+  // stale mask in the last quarter of the wave.
+  dmp_lane* ln = c->lane;
+  if (ln && ln->last) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)ln->last, 0));
+  rc = ca_to_backbone(c->best_ca, c->best_conf, L, d_coords, d_conf, s);
+  if (!rc && ln) {
+    void* e = ln->ev[ln->next];
+    ln->next = (ln->next + 1) % dmp_lane::RING;
+    DMP_HIP(hipEventRecord((hipEvent_t)e, s));
+    ln->last = e;
+  }
+  return rc;
 }
 
 // ---- heavy lane: serialises the conv launches of the contexts that share it -----------------
@@ -829,6 +853,7 @@ int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t ca
   else if (k == "conf_means") { src = ctx->conf_means; n = P; }
   else if (k == "ca_pass") { src = ctx->ca_pass; n = P * L * 3; }
   else if (k == "best_ca") { src = ctx->best_ca_snapshot; n = L * 3; }
+  else if (k == "best_ca_refined") { src = ctx->best_ca; n = L * 3; }
   else if (k == "inv_cov") { src = ctx->cov; n = (int64_t)NS * L * NS * L; }
   else if (k == "mds") { src = ctx->mds; n = L * 8; }
   else if (k == "gram") { src = ctx->gram; n = L * L; }

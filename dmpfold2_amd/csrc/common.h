@@ -152,7 +152,6 @@ struct dmp_ctx {
   uint16_t* xsplit = nullptr;  // [3][16][P][P][8] bf16 pieces of the current activations
   int conv_mode = 0;           // 0: f16x3 split products (default), 1: exact f32 MFMA, 2: bf16x6 split
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
-  bool conv_attr_set = false;  // hipFuncSetAttribute(max dynamic LDS) done for this context's device
   int conv_lds = 0;            // dynamic LDS bytes requested for the f16x3 convolution
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
@@ -206,6 +205,7 @@ int msa_weights(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_w, hipS
 // dca.hip
 int cov_build(dmp_ctx* c, const uint8_t* d_msa, const float* d_w, int N, int L, float* d_cov,
               hipStream_t s);
+int trunk_kernel_attrs(dmp_ctx* c);   // once per device, at context creation
 int spd_inverse(dmp_ctx* c, float* d_A, int D, hipStream_t s);
 // block steps [blk_lo, blk_hi) of the in-place inverse (GJ_NB columns each); all of them = spd_inverse
 int spd_inverse_steps(dmp_ctx* c, float* d_A, int D, int blk_lo, int blk_hi, hipStream_t s);

@@ -599,6 +599,25 @@ int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s) {
   return DMP_OK;
 }
 
+// Function attributes (dynamic LDS above 64 KB needs an opt-in) are per process and device.  They are
+// set when a context is created, never between launches: changing them while another stream has
+// launches of the same kernel in flight corrupted those launches (first target of a fresh scheduler,
+// about one run in three).
+int trunk_kernel_attrs(dmp_ctx* c) {
+  // tuning experiment: DMP_CONV_LDS=<bytes> requests more LDS than the kernel uses (> 80 KB leaves
+  // one convolution workgroup per CU and room for other kernels beside it)
+  const char* env = getenv("DMP_CONV_LDS");
+  c->conv_lds = env ? std::max(atoi(env), (int)CONVH_LDS_BYTES) : (int)CONVH_LDS_BYTES;
+  static bool done[64] = {};
+  if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
+  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              CONVQ_LDS_BYTES));
+  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              c->conv_lds));
+  if (c->device >= 0 && c->device < 64) done[c->device] = true;
+  return DMP_OK;
+}
+
 int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
                           double* d_stats, hipStream_t s, bool reduce) {
   const BlockW& B = c->W.blk[block - 1];
@@ -607,17 +626,6 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
   const int grid = round_up(nwork, 8);
   if (c->conv_mode != 1) {
     // float32-grade products from f16 / bf16 pieces on the 16-bit matrix cores
-    if (!c->conv_attr_set) {       // per context (= per device): dynamic LDS above 64 KB needs the opt-in
-      DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, CONVQ_LDS_BYTES));
-      // tuning experiment: DMP_CONV_LDS=<bytes> requests more LDS than the kernel uses (> 80 KB leaves
-      // one convolution workgroup per CU and room for other kernels beside it)
-      const char* env = getenv("DMP_CONV_LDS");
-      c->conv_lds = env ? std::max(atoi(env), (int)CONVH_LDS_BYTES) : (int)CONVH_LDS_BYTES;
-      DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, c->conv_lds));
-      c->conv_attr_set = true;
-    }
     if (!c->xsplit_current) {
       int rc = act_split(c, d_xpad, L, s);
       if (rc) return rc;

@@ -292,8 +292,6 @@ static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
   }
   st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
   const VRun* run = reinterpret_cast<const VRun*>(c->vgru_run);
-  DMP_HIP(hipFuncSetAttribute((const void*)vgru_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              VG_LDS_BYTES));
   hipGraph_t g;
   DMP_HIP(hipGraphCreate(&g, 0));
   hipGraphNode_t prev = nullptr;

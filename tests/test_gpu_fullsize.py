@@ -135,9 +135,12 @@ def test_ns_end_to_end_deterministic_and_scheduler_equal(ns, ns_msa, synth_sd):
     d_a, d_b = torch.from_numpy(ns_msa).to(dev), torch.from_numpy(other).to(dev)
     res = pipe.run([d_a, d_b, d_a, d_b, d_a], 10, 100)
     pipe.sync_check()
-    for i in (0, 2, 4):
-        assert torch.equal(res[i][0], c1) and torch.equal(res[i][1], f1)
-    assert torch.equal(res[1][0], res[3][0])
+    cb, fb = ns.eng.predict(other, None, 10, 100)
+    ns.eng.sync_check()
+    same = [bool(torch.equal(res[i][0], c1 if i % 2 == 0 else cb)) and
+            bool(torch.equal(res[i][1], f1 if i % 2 == 0 else fb)) for i in range(5)]
+    dev_max = [float((res[i][0] - (c1 if i % 2 == 0 else cb)).abs().max()) for i in range(5)]
+    assert all(same), (same, dev_max)
     pipe.close()
 
 

@@ -440,6 +440,36 @@ def test_batch_front_end_matches_cli(weights_file, tmp_path):
     assert (tmp_path / "out" / "pf10963.pdb").read_text() == cli(paths[0], str(tpl))
 
 
+def test_scheduler_results_bitwise_stable_under_corunning_kernels(synth_sd):
+    """Canary for cross-kernel interference: 72 short predictions (L=300, 1 iteration, 100 minimiser
+    steps) through 3 engines, every result bit-identical to the single-engine one.  Before the
+    backbone kernel took a lane turn, 1-3 % of them had the C/O/CB atoms of 16 residues wrong when
+    f16 convolutions of another target shared the CUs (tools/corrupt_repro.py)."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, Pipeline, encode_aln
+    dev = torch.device("cuda:0")
+    L, N = 300, 200
+    msas = [encode_aln(synth.synth_msa(L, N, seed=40 + i)) for i in range(4)]
+    eng = Engine(dev, L, N)
+    eng.set_weights(synth_sd)
+    refs = []
+    for m in msas:
+        c, f = eng.predict(m, None, 1, 100)
+        eng.sync_check()
+        refs.append((c.clone(), f.clone()))
+    eng.close()
+    bad = 0
+    for trial in range(6):
+        pipe = Pipeline(dev, L, N, synth_sd, streams=3)
+        order = [i % 4 for i in range(12)]
+        res = pipe.run([torch.from_numpy(msas[i]).to(dev) for i in order], 1, 100)
+        pipe.sync_check()
+        bad += sum(1 for k, i in enumerate(order)
+                   if not (torch.equal(res[k][0], refs[i][0]) and torch.equal(res[k][1], refs[i][1])))
+        pipe.close()
+    assert bad == 0
+
+
 def test_unit_api_contract(st_engine):
     """dmp_predict_next_unit / issue_unit: 18 units per pass, blocks are the conv units, pass == units."""
     eng = st_engine.eng
