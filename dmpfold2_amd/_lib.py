@@ -47,6 +47,7 @@ SIGNATURES = {
     "dmp_predict_pass": (_i, [_vp, _vp]),
     "dmp_predict_end": (_i, [_vp, _fp, _fp, _vp]),
     "dmp_predict_next_unit": (_i, [_vp]),
+    "dmp_predict_end_refine": (_i, [_vp, _vp]),
     "dmp_predict_issue_unit": (_i, [_vp, _vp]),
     "dmp_ctx_pending": (_i, [_vp]),
     "dmp_predict_begin_units": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i]),

@@ -705,6 +705,7 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->last_N = N;
   c->passes_done = 0;
   c->unit_next = 0;
+  c->end_refined = false;
   c->run_nloops = nloops < 0 ? 0 : nloops;
   c->run_refine = refine_steps < 0 ? 0 : refine_steps;
   c->run_msa = d_msa;
@@ -784,17 +785,31 @@ int dmp_predict_pass(dmp_ctx* ctx, void* stream) {
   return DMP_OK;
 }
 
-int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) {
-  DMP_ARG(ctx && d_coords && d_conf, "null argument");
+// final refinement of the best trace; optional first half of dmp_predict_end (a scheduler issues it,
+// waits for dmp_ctx_pending() == 0 and then calls dmp_predict_end, whose lane turn is then short)
+int dmp_predict_end_refine(dmp_ctx* ctx, void* stream) {
+  DMP_ARG(ctx != nullptr, "null context");
   dmp_ctx* c = ctx;
   DMP_ARG(c->fe_next >= c->fe_total && c->passes_done == c->run_nloops + 1,
           "dmp_predict_end before all passes were issued");
+  if (c->end_refined) return DMP_OK;
   hipStream_t s = STREAM;
   const int L = c->last_L;
   int rc;
   DMP_HIP(hipMemcpyAsync(c->best_ca_snapshot, c->best_ca, sizeof(float) * 3 * L,
                          hipMemcpyDeviceToDevice, s));
   if (c->run_refine > 0 && (rc = refine_coords(c->best_ca, L, c->run_refine, s))) return rc;
+  c->end_refined = true;
+  return record_unit(c, s);
+}
+
+int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) {
+  DMP_ARG(ctx && d_coords && d_conf, "null argument");
+  dmp_ctx* c = ctx;
+  int rc = dmp_predict_end_refine(ctx, stream);
+  if (rc) return rc;
+  hipStream_t s = STREAM;
+  const int L = c->last_L;
   // The backbone kernel takes a lane turn, i.e. it never runs beside another context's split-product
   // convolution.  Measured (tools/corrupt_repro.py): with the f16 / bf16 convolutions of another
   // target on the same CUs, 1-3 % of the predictions came out with the C, O, CB atoms of 16

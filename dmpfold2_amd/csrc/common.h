@@ -171,6 +171,7 @@ struct dmp_ctx {
   float* ca_pass = nullptr;    // [P][L][3]
   float* best_ca_snapshot = nullptr;
   int passes_done = 0;
+  bool end_refined = false;    // dmp_predict_end_refine already issued for the prediction in flight
   int unit_next = 0;           // next unit of the current pass (0 open, 1..16 blocks, 17 close + MDS + coordinates)
   float *trunk_cur = nullptr, *trunk_oth = nullptr;   // ping-pong activations of the pass in flight
   void* unit_ev[2] = {nullptr, nullptr};   // hipEvent_t ring: recorded after each unit issued
