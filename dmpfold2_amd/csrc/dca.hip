@@ -215,6 +215,9 @@ typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GJT_SCHED
 #define GJT_SCHED 0     // 1: pin the load / MFMA order with scheduling barriers
 #endif
+#ifndef GJT_SYM
+#define GJT_SYM 1       // 1: only tiles on / below the diagonal, mirrored as signed transposes
+#endif
 #ifndef GJT_PRELOAD
 #define GJT_PRELOAD 0   // 1: accumulators start at -A (tile read before the MFMA chain), 0: read-modify-write after it
 #endif
@@ -225,6 +228,15 @@ __global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __rest
   const int nt = Dp >> 7;
   const int tm = blockIdx.x / nt, tn = blockIdx.x % nt, kb = k0 >> 7;
   if (tm == kb) return;
+#if GJT_SYM
+  // Gauss-Jordan on a symmetric matrix keeps M_ij = t_i t_j M_ji^T with t = -1 for processed blocks
+  // (including this step's) and +1 otherwise, so outside block row / column k only the tiles on and
+  // below the diagonal are computed and each is also stored as its signed transpose.
+  if (tn != kb && tn > tm) return;
+  const bool mirror = (tn != kb && tn < tm);
+  const float msign = ((tm < kb) != (tn < kb)) ? -1.f : 1.f;
+  __shared__ float tr[4][32][33];
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 5, li = lane & 31;
   const int m0 = tm * 128 + (wave >> 1) * 64, n0 = tn * 128 + (wave & 1) * 64;
@@ -288,11 +300,30 @@ __global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
+        float v = 0.f;
         if (row < D && col < D) {
           float* p = A + (int64_t)row * D + col;
-          *p = GJT_PRELOAD ? -acc[mi][ni][r] : (blockcol ? 0.f : *p) - acc[mi][ni][r];
+          v = GJT_PRELOAD ? -acc[mi][ni][r] : (blockcol ? 0.f : *p) - acc[mi][ni][r];
+          *p = v;
         }
+#if GJT_SYM
+        if (mirror) tr[wave][li][8 * (r >> 2) + 4 * kk + (r & 3)] = msign * v;     // [column][row]
+#endif
       }
+#if GJT_SYM
+      if (mirror) {
+        // the wave's 32 x 32 block, transposed through LDS: lanes run along the new rows' columns
+        __builtin_amdgcn_wave_barrier();
+        const int rr = lane & 31;
+        const int grow0 = n0 + 32 * ni, gcol = m0 + 32 * mi + rr;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+          const int cl = 16 * (lane >> 5) + cc;
+          if (grow0 + cl < D && gcol < D) A[(int64_t)(grow0 + cl) * D + gcol] = tr[wave][cl][rr];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+#endif
     }
 }
 
