@@ -385,14 +385,16 @@ class Pipeline:
 
     def pump(self):
         """Schedule until every queued target has been started on an engine."""
-        while self._pending:
-            self._pump()
+        with torch.cuda.device(self.device):          # launches and graph builds need the current device
+            while self._pending:
+                self._pump()
 
     def drain(self):
         """Schedule until every queued target is fully enqueued; the current stream then waits for
         the engines' streams (nothing is synchronised with the host)."""
-        while self._pending or any(x is not None for x in self._slot):
-            self._pump()
+        with torch.cuda.device(self.device):
+            while self._pending or any(x is not None for x in self._slot):
+                self._pump()
         cur = torch.cuda.current_stream(self.device)
         for e in self.engines:
             cur.wait_stream(e._stream)

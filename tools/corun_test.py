@@ -26,10 +26,13 @@ what = sys.argv[1] if len(sys.argv) > 1 else "gru_vertical"
 L, N = 300, 2000
 dev = torch.device("cuda:0")
 sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_scale=5.0).items()}
-sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+pa = int(os.environ.get('CORUN_PRIO_A', '0')); pb = int(os.environ.get('CORUN_PRIO_B', '0'))
+sa, sb = torch.cuda.Stream(dev, priority=pa), torch.cuda.Stream(dev, priority=pb)
 ea, eb = Engine(dev, L, N, stream=sa), Engine(dev, L, N, stream=sb)
 ea.set_weights(sd)
 eb.set_weights(sd)
+if os.environ.get("CORUN_CONV_MODE"):
+    eb.set_option("conv_mode", int(os.environ["CORUN_CONV_MODE"]))
 lib = ea.lib
 msa = torch.from_numpy(encode_aln(synth.synth_msa(L, N, seed=3))).to(dev)
 out = torch.empty(L, 512, device=dev)
@@ -77,7 +80,7 @@ stage_a(1)
 torch.cuda.synchronize()
 reps = {"gru_vertical": 4, "spd_inverse": 8, "eigh": 40}[what]
 ta = timed(lambda: stage_a(reps))
-nconv = max(10, int(ta / 0.73))
+nconv = max(10, int(ta / (2.3 if os.environ.get('CORUN_CONV_MODE') == '1' else 0.73)))
 # dmp_time_conv5x5 synchronises its stream itself, so the joint run issues stage A first (asynchronous)
 tb = timed(lambda: convs(nconv))
 tj = timed(lambda: (stage_a(reps), convs(nconv)))
