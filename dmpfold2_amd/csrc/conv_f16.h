@@ -41,7 +41,8 @@ constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slo
 #endif
 #ifndef CH_MAP_PAIR
 #define CH_MAP_PAIR 1        // 1: each XCD handles two of the four channel splits (see the kernel);
-#endif                       //    same time, fabric reads per launch 361 -> 257 MB (tools/pmc_fetch.sh)
+#endif                       //    same time, fabric reads per launch 361 -> 257 MB (tools/pmc_fetch.sh);
+                             //    one split per XCD (a tile's input read by four XCDs) measured 290 MB
 #ifndef CH_VGPR_CAP
 #define CH_VGPR_CAP          // e.g. __attribute__((amdgpu_waves_per_eu(3, 3))) caps the kernel at 168 VGPRs
 #endif

@@ -56,6 +56,14 @@ int main(int argc, char** argv) {
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffffff) / 16777216.f - 0.5f; };
   for (auto& v : w) v = rnd() * 0.04f;
   for (auto& v : b) v = rnd() * 0.1f;
+  // UB_DATA=zero: all-zero operands; UB_DATA=f16: operands exactly representable in f16 (zero low pieces).
+  // Data-dependent timing = the kernel is limited by power, not by instruction issue.
+  const char* ub_data = getenv("UB_DATA");
+  auto shape = [&](std::vector<float>& a) {
+    if (!ub_data) return;
+    for (auto& v : a) v = ub_data[0] == 'z' ? 0.f : (float)(_Float16)v;
+  };
+  shape(w);
   const float scale = conv_weight_scale_f16(w.data(), w.size());
   std::vector<uint16_t> wq = pack_conv_weights_f16(w.data(), scale);
   uint16_t* d_wq; float* d_b;
@@ -69,6 +77,7 @@ int main(int argc, char** argv) {
     const int P = act_pitch(L), tiles = act_tiles(L);
     std::vector<float> x((size_t)128 * L * L);
     for (auto& v : x) v = rnd() * 6.f;
+    shape(x);
     std::vector<uint16_t> xs((size_t)2 * 16 * P * P * 8, 0);
     for (int ch = 0; ch < 128; ++ch)
       for (int y = 0; y < L; ++y)
