@@ -19,6 +19,17 @@ LIB = os.path.join(HERE, "libdmpfold_hip.so")
 SOURCES = ["api.hip", "gemm.hip", "msa.hip", "dca.hip", "gru.hip", "vgru.hip", "trunk.hip", "mds.hip",
            "coords.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# coords.hip: no SLP vectoriser = no packed-f32 instructions.  The vectoriser turns the cross products of the
+# backbone kernel into v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0], which returns 0 in lanes 48..63 when
+# f16 / bf16 MFMA waves share the SIMD (tools/isa_lint.py guards every kernel against it).
+PER_FILE_FLAGS = {"coords.hip": ["-fno-slp-vectorize"]}
+
+
+def per_file_flags(src: str) -> list:
+    """library flags of one source + DMP_FLAGS_<FILE> from the environment (tuning experiments)"""
+    name = os.path.basename(src)
+    env = os.environ.get("DMP_FLAGS_" + name.split(".")[0].upper(), "").split()
+    return PER_FILE_FLAGS.get(name, []) + env
 
 
 def _hipcc():
@@ -47,13 +58,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s, __file__] + headers):
             jobs.append((s, o))
 
     def compile_one(job):
         s, o = job
-        per_file = os.environ.get("DMP_FLAGS_" + os.path.basename(s).split(".")[0].upper(), "").split()
-        cmd = [hipcc] + FLAGS + extra + per_file + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + extra + per_file_flags(s) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))

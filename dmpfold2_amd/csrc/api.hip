@@ -785,8 +785,7 @@ int dmp_predict_pass(dmp_ctx* ctx, void* stream) {
   return DMP_OK;
 }
 
-// final refinement of the best trace; optional first half of dmp_predict_end (a scheduler issues it,
-// waits for dmp_ctx_pending() == 0 and then calls dmp_predict_end, whose lane turn is then short)
+// final refinement of the best trace; optional first half of dmp_predict_end
 int dmp_predict_end_refine(dmp_ctx* ctx, void* stream) {
   DMP_ARG(ctx != nullptr, "null context");
   dmp_ctx* c = ctx;
@@ -810,22 +809,10 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) 
   if (rc) return rc;
   hipStream_t s = STREAM;
   const int L = c->last_L;
-  // The backbone kernel takes a lane turn, i.e. it never runs beside another context's split-product
-  // convolution.  Measured (tools/corrupt_repro.py): with the f16 / bf16 convolutions of another
-  // target on the same CUs, 1-3 % of the predictions came out with the C, O, CB atoms of 16
-  // consecutive residues (lanes 48..63 of one wave of this kernel) off by 1-2 A while every input of
-  // the kernel was bit-identical; never with the exact-f32 convolution, never in any other kernel.
-  // The wrong values are those of a division / square root whose compare-and-select fix-up read a
-  // stale mask in the last quarter of the wave.
-  dmp_lane* ln = c->lane;
-  if (ln && ln->last) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)ln->last, 0));
+  // No lane turn: the corruption once seen here (C, O, CB of lanes 48..63 beside another context's
+  // split-product convolution) was a packed-f32 instruction form that coords.hip no longer contains
+  // (tools/isa_lint.py).
   rc = ca_to_backbone(c->best_ca, c->best_conf, L, d_coords, d_conf, s);
-  if (!rc && ln) {
-    void* e = ln->ev[ln->next];
-    ln->next = (ln->next + 1) % dmp_lane::RING;
-    DMP_HIP(hipEventRecord((hipEvent_t)e, s));
-    ln->last = e;
-  }
   return rc;
 }
 

@@ -359,10 +359,7 @@ class Pipeline:
             while True:
                 kind = lib.dmp_predict_next_unit(e.ctx)
                 if kind == 0:
-                    # final refinement first; the backbone kernel (a lane turn) once it has finished
-                    _lib.check(lib.dmp_predict_end_refine(e.ctx, e.stream()))
-                    if gated and _lib.check(lib.dmp_ctx_pending(e.ctx)) > 0:
-                        break
+                    # final refinement + backbone; neither needs the lane
                     t, coords, confs, _ = self._slot[s]
                     _lib.check(lib.dmp_predict_end(e.ctx, coords.data_ptr(), confs.data_ptr(), e.stream()))
                     self._results[t] = (coords, confs)

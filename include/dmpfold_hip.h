@@ -191,10 +191,8 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L,
                             const float* d_template_ca, int Lt, int nloops, int refine_steps);
 int dmp_predict_next_unit(const dmp_ctx* ctx);
 /* After the last pass: dmp_predict_end_refine enqueues the final minimisation of the best trace
- * (optional: dmp_predict_end does it itself if it was not called).  dmp_predict_end's backbone
- * kernel takes a lane turn (it must not run beside another context's split-product convolution,
- * see api.hip); a scheduler therefore calls end_refine, waits for dmp_ctx_pending() == 0 and only
- * then dmp_predict_end, so that the lane is held for microseconds instead of the refinement. */
+ * alone (optional: dmp_predict_end does it itself if it was not called), for callers that want to
+ * interleave other work between the minimisation and the backbone kernel. */
 int dmp_predict_end_refine(dmp_ctx* ctx, void* stream);
 int dmp_predict_issue_unit(dmp_ctx* ctx, void* stream);
 int dmp_ctx_pending(dmp_ctx* ctx);

@@ -440,11 +440,57 @@ def test_batch_front_end_matches_cli(weights_file, tmp_path):
     assert (tmp_path / "out" / "pf10963.pdb").read_text() == cli(paths[0], str(tpl))
 
 
+def test_backbone_bitwise_stable_beside_convolutions(synth_sd):
+    """Regression test for the packed-f32 hazard: dmp_ca_to_backbone launched 3000 times
+    while another context runs f16 split-product convolutions; every output bit-identical to the
+    output computed alone.  With the vectorised cross products (v_pk_mul_f32 ... op_sel:[0,1]) about
+    a quarter of the launches had the C, O, CB atoms of lanes 48..63 wrong (tools/bb_hazard.hip)."""
+    import ctypes as C
+    import threading
+    from dmpfold2_amd import _lib
+    from dmpfold2_amd.predict import Engine
+    dev = torch.device("cuda:0")
+    L = 300
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ea, eb = Engine(dev, L, 8, stream=sa), Engine(dev, L, 8, stream=sb)
+    eb.set_weights(synth_sd)
+    g = torch.Generator().manual_seed(11)
+    ca = torch.cumsum(torch.randn(L, 3, generator=g) * 2.2, 0).to(dev)
+    lg = torch.randn(L, generator=g).to(dev)
+    slots = 100
+    out = torch.empty(slots, L, 15, device=dev)
+    cf = torch.empty(slots, L, device=dev)
+
+    def backbone(k):
+        _lib.check(ea.lib.dmp_ca_to_backbone(ea.ctx, ca.data_ptr(), lg.data_ptr(), L, out[k].data_ptr(),
+                                             cf[k].data_ptr(), ea.stream()))
+    backbone(0)
+    torch.cuda.synchronize()
+    ref_c, ref_f = out[0].clone(), cf[0].clone()
+
+    def convolutions():
+        ms = C.c_float()
+        with torch.cuda.device(dev):
+            _lib.check(eb.lib.dmp_time_conv5x5(eb.ctx, 1, L, 600, C.byref(ms), eb.stream()))
+    t = threading.Thread(target=convolutions)
+    t.start()
+    bad = 0
+    for rnd in range(30):
+        for k in range(slots):
+            backbone(k)
+        sa.synchronize()
+        bad += int((out != ref_c).any(dim=(1, 2)).sum()) + int((cf != ref_f).any(dim=1).sum())
+    t.join()
+    ea.close()
+    eb.close()
+    assert bad == 0
+
+
 def test_scheduler_results_bitwise_stable_under_corunning_kernels(synth_sd):
     """Canary for cross-kernel interference: 72 short predictions (L=300, 1 iteration, 100 minimiser
-    steps) through 3 engines, every result bit-identical to the single-engine one.  Before the
-    backbone kernel took a lane turn, 1-3 % of them had the C/O/CB atoms of 16 residues wrong when
-    f16 convolutions of another target shared the CUs (tools/corrupt_repro.py)."""
+    steps) through 3 engines, every result bit-identical to the single-engine one.  1-4 % of them
+    used to have the C/O/CB atoms of 16 residues wrong when f16 convolutions of another target shared
+    the CUs (tools/corrupt_repro.py; cause and fix in DESIGN section 6)."""
     from dmpfold2_amd import synth
     from dmpfold2_amd.predict import Engine, Pipeline, encode_aln
     dev = torch.device("cuda:0")
