@@ -19,6 +19,7 @@ import argparse
 import ctypes as C
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -245,6 +246,19 @@ class Engine:
         return out[:n]
 
 
+# DMP_PUMP_TIMING=1: host time of every dmp_predict_issue_unit call by unit kind (developer diagnostic)
+_PUMP_TIMING = {} if os.environ.get("DMP_PUMP_TIMING") else None
+
+
+def pump_timing_report():
+    import numpy as np
+    for kind, v in sorted((_PUMP_TIMING or {}).items()):
+        a = np.array(v) * 1e6
+        print(f"issue_unit kind {kind}: n={len(a)} mean {a.mean():.0f} us  p50 {np.percentile(a, 50):.0f}  "
+              f"p90 {np.percentile(a, 90):.0f}  p99 {np.percentile(a, 99):.0f}  max {a.max():.0f}  total {a.sum() / 1e3:.0f} ms",
+              file=sys.stderr)
+
+
 class Pipeline:
     """Throughput mode on one GPU: `streams` engines (each its own context and HIP stream) share a
     lane, so their machine-filling convolutions take turns while the latency-bound kernels of one
@@ -372,7 +386,12 @@ class Pipeline:
                     busy = _lib.check(lib.dmp_ctx_pending(e.ctx))
                     if busy > (0 if (kind == 2 and n_conv > 1) else 1):
                         break
-                _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
+                if _PUMP_TIMING is not None:
+                    t0 = time.perf_counter()
+                    _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
+                    _PUMP_TIMING.setdefault(kind, []).append(time.perf_counter() - t0)
+                else:
+                    _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
                 progressed = True
                 if kind == 2:
                     self._done[s] += 1
