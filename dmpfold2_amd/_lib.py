@@ -58,6 +58,7 @@ SIGNATURES = {
     "dmp_debug_fetch": (_i64, [_vp, C.c_char_p, _fp, _i64, _vp]),
     "dmp_profile_enable": (_i, [_vp, _i, _i]),
     "dmp_profile_conv_ms": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
+    "dmp_profile_conv_intervals": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "dmp_time_conv5x5": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_float), _vp]),
 }
 

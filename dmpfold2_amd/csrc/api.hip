@@ -892,6 +892,22 @@ int dmp_profile_conv_ms(dmp_ctx* ctx, float* h_avg_ms, int* h_launches) {
   return DMP_OK;
 }
 
+// developer diagnostic (tools/lane_trace.py): start and end of every recorded conv launch in ms after the
+// first recorded launch of `ref`; does not reset the counter
+int dmp_profile_conv_intervals(dmp_ctx* ctx, dmp_ctx* ref, float* h_start_ms, float* h_end_ms, int capacity,
+                               int* h_launches) {
+  DMP_ARG(ctx && ref && h_start_ms && h_end_ms && h_launches, "null argument");
+  DMP_ARG(ref->prof_n >= 2, "the reference context has no recorded launch");
+  const int n = ctx->prof_n / 2 < capacity ? ctx->prof_n / 2 : capacity;
+  hipEvent_t e0 = (hipEvent_t)ref->prof_ev[0];
+  for (int i = 0; i < n; ++i) {
+    DMP_HIP(hipEventElapsedTime(&h_start_ms[i], e0, (hipEvent_t)ctx->prof_ev[2 * i]));
+    DMP_HIP(hipEventElapsedTime(&h_end_ms[i], e0, (hipEvent_t)ctx->prof_ev[2 * i + 1]));
+  }
+  *h_launches = n;
+  return DMP_OK;
+}
+
 int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, void* stream) {
   CHECK_CAP(L, 1);
   CHECK_W();

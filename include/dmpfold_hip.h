@@ -222,6 +222,10 @@ int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t ca
  * must have synchronised the stream) and resets the counter. */
 int dmp_profile_enable(dmp_ctx* ctx, int on, int max_launches);
 int dmp_profile_conv_ms(dmp_ctx* ctx, float* h_avg_ms, int* h_launches);
+/* Developer diagnostic: start / end of every recorded launch of ctx in ms after the first recorded
+ * launch of ref (streams synchronised by the caller); the counter is not reset. */
+int dmp_profile_conv_intervals(dmp_ctx* ctx, dmp_ctx* ref, float* h_start_ms, float* h_end_ms, int capacity,
+                               int* h_launches);
 /* Time the pair-trunk convolution kernel alone with HIP events on `stream`: runs `iters`
  * launches of block `block` at length L on internal buffers, returns average ms per launch. */
 int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, void* stream);
