@@ -1,6 +1,7 @@
 // extern "C" surface of libdmpfold_hip.so (see include/dmpfold_hip.h): context and weight
 // management, host-side residue encoding, stage-level entry points and the fused dmp_predict.
 #include "common.h"
+#include <atomic>
 #include "conv_bf16.h"
 #include "conv_f16.h"
 #include <cstdarg>
@@ -337,6 +338,10 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   dmp_ctx* c = new dmp_ctx();
   c->device = device;
   c->max_L = max_L;
+  {
+    static std::atomic<int> next_xcd{0};             // spread the minimiser clusters of the contexts over the XCDs
+    c->refine_xcd = next_xcd.fetch_add(1) & 7;
+  }
   c->max_N = max_N;
   c->max_passes = 128;
   const int64_t L = max_L, N = max_N, D = NS * L, LL = L * L;
@@ -371,6 +376,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(mat1d, L * WIDTH);
   A_(seq_hx, 2 * 2 * HID2);
   A_(seq_abort, 1);
+  A_(refine_gx, 2 * 3 * L);
   A_(z0, (int64_t)STEM_OUT * LL);
   A_(dmap, LL);
   A_(u, (int64_t)CW * LL);
@@ -418,6 +424,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   const std::string k(name);
   if (k == "conv_f32_exact") { ctx->conv_mode = value ? 1 : 0; return DMP_OK; }
   if (k == "tridiag_single") { ctx->tridiag_single = value ? 1 : 0; return DMP_OK; }
+  if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
   if (k == "conv_mode") {
     DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
     ctx->conv_mode = value;
@@ -433,8 +440,9 @@ int dmp_sync_check(dmp_ctx* ctx, void* stream) {
   int flag = 0;
   DMP_HIP(hipMemcpy(&flag, ctx->seq_abort, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) {
-    set_error("device-side fault (results invalid):%s%s",
+    set_error("device-side fault (results invalid):%s%s%s",
               (flag & 1) ? " sequence-GRU workgroup hand-off timed out;" : "",
+              (flag & 4) ? " minimiser workgroup hand-off timed out;" : "",
               (flag & 2) ? " an activation left the f16 range of the split-product convolution "
                            "(use option conv_f32_exact or conv_mode=2);" : "");
     return DMP_ERR_HIP;
@@ -630,7 +638,8 @@ int dmp_pair_distances(dmp_ctx* ctx, const float* d_ca, int L, int clamp, float*
 
 int dmp_refine_coords(dmp_ctx* ctx, float* d_ca, int L, int steps, void* stream) {
   DMP_ARG(ctx && d_ca && L >= 2 && L <= 1280 && steps >= 0, "bad argument");
-  return refine_coords(d_ca, L, steps, STREAM);
+  DMP_ARG(L >= 2 && L <= ctx->max_L, "L = %d outside 2..max_L", L);
+  return refine_coords(ctx, d_ca, L, steps, STREAM);
 }
 
 int dmp_ca_to_backbone(dmp_ctx* ctx, const float* d_ca, const float* d_conf_logit, int L,
@@ -748,7 +757,7 @@ int dmp_predict_issue_unit(dmp_ctx* ctx, void* stream) {
     rc = trunk_close(c, L, c->conf, c->gram, s);
     if (!rc) rc = eigh_top8(c, c->gram, L, c->mds, s);
     if (!rc) rc = coords_from_mds(c, c->mat1d, c->mds, L, c->ca, s);
-    if (!rc && pass == 0 && c->run_refine > 0) rc = refine_coords(c->ca, L, c->run_refine, s);
+    if (!rc && pass == 0 && c->run_refine > 0) rc = refine_coords(c, c->ca, L, c->run_refine, s);
     if (!rc) rc = select_best(c, c->conf, c->ca, L, pass, c->max_passes, s);
   }
   if (rc) { c->xsplit_current = false; return rc; }
@@ -797,7 +806,7 @@ int dmp_predict_end_refine(dmp_ctx* ctx, void* stream) {
   int rc;
   DMP_HIP(hipMemcpyAsync(c->best_ca_snapshot, c->best_ca, sizeof(float) * 3 * L,
                          hipMemcpyDeviceToDevice, s));
-  if (c->run_refine > 0 && (rc = refine_coords(c->best_ca, L, c->run_refine, s))) return rc;
+  if (c->run_refine > 0 && (rc = refine_coords(c, c->best_ca, L, c->run_refine, s))) return rc;
   c->end_refined = true;
   return record_unit(c, s);
 }

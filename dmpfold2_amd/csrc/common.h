@@ -134,6 +134,7 @@ struct dmp_ctx {
   std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
   std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain
   int tridiag_single = 0;                  // option: 1 = single-workgroup tridiagonalisation
+  int refine_single = 0;                   // option: 1 = single-workgroup minimiser
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions
   float* seq_a = nullptr;   // [L][512]
@@ -142,6 +143,8 @@ struct dmp_ctx {
   float* mat1d = nullptr;   // [512][L]
   unsigned long long* seq_hx = nullptr;  // [2][2][256] hand-off granules of the sequence GRU
   int* seq_abort = nullptr;              // [1] set if a hand-off timed out
+  unsigned long long* refine_gx = nullptr;  // [2][3 max_L] hand-off granules of the minimiser cluster
+  int refine_xcd = 0;                    // XCD the minimiser cluster of this context runs on
   // pair trunk
   float* z0 = nullptr;      // [384][L][L]
   float* dmap = nullptr;    // [L][L]
@@ -244,7 +247,7 @@ int pair_distances(const float* d_ca, int L, int clamp, float* d_dmap, hipStream
 int fill_f32(float* d, int64_t n, float v, hipStream_t s);
 int select_best(dmp_ctx* c, const float* d_conf, const float* d_ca, int L, int pass, int rec_cap,
                 hipStream_t s);
-int refine_coords(float* d_ca, int L, int steps, hipStream_t s);
+int refine_coords(dmp_ctx* c, float* d_ca, int L, int steps, hipStream_t s);
 int ca_to_backbone(const float* d_ca, const float* d_logit, int L, float* d_coords,
                    float* d_conf_out, hipStream_t s);
 }  // namespace dmp

@@ -202,11 +202,137 @@ __global__ __launch_bounds__(1024) void refine_kernel(float* __restrict__ ca, in
   for (int i = threadIdx.x; i < 3 * L; i += 1024) ca[i] = cur[i];
 }
 
-int refine_coords(float* d_ca, int L, int steps, hipStream_t s) {
+// The same iteration on a cluster of RF_G workgroups (one XCD): workgroup g owns the residues
+// [g Lg, (g+1) Lg), keeps a copy of all coordinates in LDS, and per step computes the accelerations of
+// its residues (T threads per residue, each over a contiguous slice of the partners, slices added in
+// order), publishes the new coordinates as 8-byte {epoch, value} granules (agent-scope stores, the
+// data is the flag - the protocol of seq_gru_kernel) and gathers the others' by sweeping the granule
+// array until every tag carries the step's epoch.  Two granule arrays alternate, so a workgroup that
+// is one step ahead never overwrites what a slower one still has to read.
+constexpr int RF_G = 16;          // workgroups of the cluster
+constexpr int RF_THREADS = 512;    // 8 waves of 54 VGPRs: fits beside two convolution workgroups on a CU
+typedef unsigned long long u64;
+struct RefineArgs {
+  float* ca;
+  int L, steps, xcd;
+  u64* gx;             // [2][3L] granules, zeroed before the launch
+  int* abort_flag;     // bit 2 is set if a hand-off ever times out
+};
+
+__host__ __device__ inline int refine_slices(int L) {
+  const int Lg = (L + RF_G - 1) / RF_G;
+  const int t = RF_THREADS / Lg;
+  return t < 1 ? 1 : (t > 32 ? 32 : t);
+}
+
+// grid: 8 * RF_G blocks (only ids with id % 8 == xcd work)   block: RF_THREADS   dynamic LDS: see refine_coords
+__global__ __launch_bounds__(RF_THREADS) void refine_cluster_kernel(RefineArgs a) {
+  extern __shared__ float sm[];          // 3L coordinates + T x 3 Lg partial sums
+  __shared__ int sh_abort;
+  if ((int)(blockIdx.x & 7) != a.xcd) return;
+  const int g = blockIdx.x >> 3, L = a.L, tid = threadIdx.x;
+  const int Lg = (L + RF_G - 1) / RF_G;
+  const int j_lo = g * Lg;
+  const int nj = (j_lo + Lg <= L ? Lg : L - j_lo);
+  if (nj <= 0) return;                   // short chains: the last workgroups own nothing
+  const int T = refine_slices(L);
+  const int chunk = (L + T - 1) / T;
+  float* cur = sm;
+  float* part = sm + 3 * L;
+  for (int i = tid; i < 3 * L; i += RF_THREADS) cur[i] = a.ca[i];
+  if (tid == 0) sh_abort = 0;
+  __syncthreads();
+  for (int step = 0; step < a.steps; ++step) {
+    const unsigned epoch = (unsigned)step + 1u;
+    u64* gx = a.gx + (int64_t)(step & 1) * 3 * L;
+    for (int idx = tid; idx < T * nj; idx += RF_THREADS) {
+      const int jl = idx % nj, sub = idx / nj, j = j_lo + jl;
+      const int i0 = sub * chunk, i1 = (i0 + chunk < L) ? i0 + chunk : L;
+      const float xj = cur[3 * j], yj = cur[3 * j + 1], zj = cur[3 * j + 2];
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      for (int i = i0; i < i1; ++i) {
+        const float dx = xj - cur[3 * i], dy = yj - cur[3 * i + 1], dz = zj - cur[3 * i + 2];
+        float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+        d = fminf(fmaxf(d, 0.01f), 10.0f);
+        const float viol = (d < 3.0f) ? (3.0f - d) : 0.0f;
+        const float f = 100.0f * viol;
+        ax += f * (dx / d);
+        ay += f * (dy / d);
+        az += f * (dz / d);
+      }
+      part[(sub * nj + jl) * 3] = ax;
+      part[(sub * nj + jl) * 3 + 1] = ay;
+      part[(sub * nj + jl) * 3 + 2] = az;
+    }
+    __syncthreads();
+    if (tid < nj) {
+      const int jl = tid, j = j_lo + jl;
+      const float xj = cur[3 * j], yj = cur[3 * j + 1], zj = cur[3 * j + 2];
+      float ax = part[3 * jl], ay = part[3 * jl + 1], az = part[3 * jl + 2];
+      for (int sub = 1; sub < T; ++sub) {
+        ax += part[(sub * nj + jl) * 3];
+        ay += part[(sub * nj + jl) * 3 + 1];
+        az += part[(sub * nj + jl) * 3 + 2];
+      }
+      if (j < L - 1) {   // bond to j+1: accels[:-1] += accels_cov
+        const float dx = cur[3 * j + 3] - xj, dy = cur[3 * j + 4] - yj, dz = cur[3 * j + 5] - zj;
+        const float d = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 0.1f);
+        const float f = 100.0f * fminf(d - 3.78f, 3.0f);
+        ax += f * (dx / d);
+        ay += f * (dy / d);
+        az += f * (dz / d);
+      }
+      if (j > 0) {       // bond from j-1: accels[1:] -= accels_cov
+        const float dx = xj - cur[3 * j - 3], dy = yj - cur[3 * j - 2], dz = zj - cur[3 * j - 1];
+        const float d = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 0.1f);
+        const float f = 100.0f * fminf(d - 3.78f, 3.0f);
+        ax -= f * (dx / d);
+        ay -= f * (dy / d);
+        az -= f * (dz / d);
+      }
+      const float nx = xj + fminf(fmaxf(ax, -100.0f), 100.0f) * 0.001f;
+      const float ny = yj + fminf(fmaxf(ay, -100.0f), 100.0f) * 0.001f;
+      const float nz = zj + fminf(fmaxf(az, -100.0f), 100.0f) * 0.001f;
+      const u64 tag = (u64)epoch << 32;
+      __hip_atomic_store(&gx[3 * j], tag | (u64)__float_as_uint(nx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gx[3 * j + 1], tag | (u64)__float_as_uint(ny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gx[3 * j + 2], tag | (u64)__float_as_uint(nz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                     // every thread has read the old coordinates
+    for (int i = tid; i < 3 * L; i += RF_THREADS) {
+      u64 x = 0;
+      unsigned spins = 0;
+      for (;; ++spins) {
+        x = __hip_atomic_load(&gx[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch) break;
+        if (spins > 4000000u || sh_abort) { sh_abort = 1; atomicOr(a.abort_flag, 4); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      cur[i] = __uint_as_float((unsigned)x);
+    }
+    __syncthreads();                     // cur holds the new coordinates
+    if (sh_abort) break;
+  }
+  for (int i = tid; i < 3 * nj; i += RF_THREADS) a.ca[3 * j_lo + i] = cur[3 * j_lo + i];
+}
+
+int refine_coords(dmp_ctx* c, float* d_ca, int L, int steps, hipStream_t s) {
   if (steps <= 0) return DMP_OK;
-  const int T = L >= 1024 ? 1 : (1024 / L > 8 ? 8 : 1024 / L);
-  hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(1024), sizeof(float) * (6 + 3 * T) * L, s, d_ca, L,
-                     steps);
+  if (c->refine_single || L < 2 * RF_G) {
+    const int T = L >= 1024 ? 1 : (1024 / L > 8 ? 8 : 1024 / L);
+    hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(1024), sizeof(float) * (6 + 3 * T) * L, s, d_ca, L,
+                       steps);
+    DMP_LAUNCH_CHECK();
+    return DMP_OK;
+  }
+  RefineArgs a{};
+  a.ca = d_ca; a.L = L; a.steps = steps; a.xcd = c->refine_xcd;
+  a.gx = (u64*)c->refine_gx;
+  a.abort_flag = c->seq_abort;
+  const int Lg = (L + RF_G - 1) / RF_G;
+  DMP_HIP(hipMemsetAsync(c->refine_gx, 0, sizeof(u64) * 2 * 3 * L, s));
+  hipLaunchKernelGGL(refine_cluster_kernel, dim3(8 * RF_G), dim3(RF_THREADS),
+                     sizeof(float) * (3 * L + 3 * refine_slices(L) * Lg), s, a);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

@@ -61,7 +61,10 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default).
  * "tridiag_single" = 1 runs the Householder tridiagonalisation of the MDS eigensolver in a single
  * workgroup (one launch) instead of one multi-workgroup launch per step; same algorithm, different
- * summation order (results agree to float64 rounding). */
+ * summation order (results agree to float64 rounding).
+ * "refine_single" = 1 runs the minimiser (dmp_refine_coords, dmp_predict*) in one workgroup instead
+ * of a cluster of 16 that hands the coordinates over every step; same iteration, different
+ * partial-sum slices (results agree to float32 rounding). */
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value);
 /* Reset the device-side fault word read by dmp_sync_check (enqueued on `stream`). */
 int dmp_clear_faults(dmp_ctx* ctx, void* stream);

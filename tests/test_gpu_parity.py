@@ -329,6 +329,34 @@ def test_refine_known_answer(st):
     assert np.abs(got - k["refined_noisy_100"]).max() < 1e-3
 
 
+def test_refine_cluster_and_single_workgroup_agree(synth_sd):
+    """Option refine_single: the 16-workgroup minimiser (granule hand-off between the workgroups every
+    step) and the single-workgroup one are the same iteration with different partial-sum slices;
+    well-spread chains, so the iteration is not chaotic.  Also pins the cluster kernel at lengths that
+    leave the last workgroups empty or ragged, and its determinism."""
+    from abi import Stages
+    stg = Stages(synth_sd, max_L=1024, max_N=8)
+    rng = np.random.default_rng(3)
+    try:
+        for L, steps in ((33, 50), (82, 100), (300, 100), (1000, 30)):
+            step = rng.standard_normal((L, 3))
+            step *= 3.8 / np.linalg.norm(step, axis=1, keepdims=True)
+            ca = np.cumsum(step, axis=0).astype(np.float32)
+            a = stg.refine(stg.to(ca), steps).cpu().numpy()
+            a2 = stg.refine(stg.to(ca), steps).cpu().numpy()
+            stg.eng.set_option("refine_single", 1)
+            try:
+                b = stg.refine(stg.to(ca), steps).cpu().numpy()
+            finally:
+                stg.eng.set_option("refine_single", 0)
+            assert np.array_equal(a, a2), L
+            assert np.isfinite(a).all() and np.abs(a - ca).max() > 0
+            assert np.abs(a - b).max() < 2e-4, (L, np.abs(a - b).max())
+        stg.eng.sync_check()
+    finally:
+        stg.eng.close()
+
+
 def test_backbone_known_answer(st):
     k = load_golden("kat_refine_backbone")
     L = k["ca_in"].shape[0]
