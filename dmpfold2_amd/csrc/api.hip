@@ -408,6 +408,13 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
     hipEvent_t e;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
     c->unit_ev[i] = (void*)e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+    c->side_ev[i] = (void*)e;
+  }
+  {
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+    c->side_stream = (void*)st;
   }
   *out = c;
   return DMP_OK;
@@ -457,6 +464,9 @@ void dmp_ctx_destroy(dmp_ctx* c) {
   for (void* e : c->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
   for (void* e : c->unit_ev)
     if (e) (void)hipEventDestroy((hipEvent_t)e);
+  for (void* e : c->side_ev)
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+  if (c->side_stream) (void)hipStreamDestroy((hipStream_t)c->side_stream);
   for (auto& kv : c->vgru_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
   for (auto& kv : c->tri_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
   delete c;
@@ -729,7 +739,26 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
 int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
                       int Lt, int nloops, int refine_steps, void* stream) {
   int rc = dmp_predict_begin_units(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps);
-  while (!rc && ctx->fe_next < ctx->fe_total) rc = issue_front_end_unit(ctx, STREAM);
+  if (rc) return rc;
+  // The covariance features (reweighting, covariance, inverse: f32 matrix cores, serial diagonal blocks)
+  // and the vertical GRU (bound by L1 misses) are independent and use different units of the chip: the
+  // features run on the context's side stream beside the GRU.  (The unit-wise path of a scheduler keeps everything on one stream:
+  // there other targets fill the machine.)
+  dmp_ctx* c = ctx;
+  hipStream_t s = STREAM, side = (hipStream_t)c->side_stream;
+  static const bool no_fork = getenv("DMP_NO_SIDE_STREAM") && getenv("DMP_NO_SIDE_STREAM")[0] == '1';   // A/B timing
+  const bool fork = c->fe_inv > 0 && side != nullptr && !no_fork;
+  while (!rc && c->fe_next < c->fe_total) {
+    const int u = c->fe_next;
+    const bool inv_unit = fork && u <= c->fe_inv;          // reweighting, covariance, inverse, contacts
+    if (fork && u == 0) {
+      DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[0], s));
+      DMP_HIP(hipStreamWaitEvent(side, (hipEvent_t)c->side_ev[0], 0));
+    }
+    if (fork && u == c->fe_total - 1) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->side_ev[1], 0));
+    rc = issue_front_end_unit(c, inv_unit ? side : s);
+    if (!rc && fork && u == c->fe_inv) DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[1], side));
+  }
   return rc;
 }
 

@@ -178,6 +178,8 @@ struct dmp_ctx {
   int unit_next = 0;           // next unit of the current pass (0 open, 1..16 blocks, 17 close + MDS + coordinates)
   float *trunk_cur = nullptr, *trunk_oth = nullptr;   // ping-pong activations of the pass in flight
   void* unit_ev[2] = {nullptr, nullptr};   // hipEvent_t ring: recorded after each unit issued
+  void* side_stream = nullptr;             // hipStream_t: dmp_predict_begin runs the covariance inverse here, beside the vertical GRU
+  void* side_ev[2] = {nullptr, nullptr};   // fork / join events of the side stream
   long unit_seq = 0;           // units issued since the context was created
   int fe_next = 0, fe_total = 0;           // front-end units (features, sequence trunk, static stem)
   int fe_inv = 0, fe_vgru = 0;             // ... of which inverse chunks / vertical-GRU chunks

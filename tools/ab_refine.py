@@ -10,7 +10,7 @@ sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_
 for L, N, it, ms in ((200, 1000, 10, 100), (300, 2000, 10, 100), (500, 3000, 30, 200)):
     e = Engine(dev, L, N); e.set_weights(sd)
     a = encode_aln(synth.synth_msa(L, N, seed=1))
-    for single in (0, 1, 0, 1):
+    for single in (0, 1):
         e.set_option("refine_single", single)
         e.predict(a, None, it, ms); torch.cuda.synchronize()
         t0 = time.perf_counter()
