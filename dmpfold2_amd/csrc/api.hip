@@ -681,23 +681,52 @@ static int record_unit(dmp_ctx* c, hipStream_t s) {
   return DMP_OK;
 }
 
+// The covariance features (reweighting, covariance, Gauss-Jordan inverse, contacts: f32 matrix cores,
+// serial diagonal blocks) and the vertical GRU (bound by L1 misses) are independent and use different
+// units of the chip, so the features run on the context's side stream and their units alternate with
+// the GRU's: one unit of each kind is in flight at a time.  They join before the static stem.
+static bool side_stream_enabled() {
+  static const bool off = getenv("DMP_NO_SIDE_STREAM") && getenv("DMP_NO_SIDE_STREAM")[0] == '1';   // A/B timing
+  return !off;
+}
+
 static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   const int L = c->last_L, N = c->last_N, u = c->fe_next;
   const uint8_t* d_msa = c->run_msa;
+  const bool fork = c->fe_inv > 0 && c->side_stream != nullptr && side_stream_enabled();
+  hipStream_t side = fork ? (hipStream_t)c->side_stream : s;
+  hipStream_t used = s;
   int rc = DMP_OK;
   if (u == 0) {
-    rc = msa_weights(c, d_msa, N, L, c->w, s);
-    if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, s);
-  } else if (u <= c->fe_inv) {
-    rc = spd_inverse_steps(c, c->cov, NS * L, (u - 1) * FE_INV_BLOCKS, u * FE_INV_BLOCKS, s);
-    if (!rc && u == c->fe_inv) rc = dca_contacts(c, c->cov, L, c->contacts, s);
+    if (fork) {
+      DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[0], s));
+      DMP_HIP(hipStreamWaitEvent(side, (hipEvent_t)c->side_ev[0], 0));
+    }
+    used = side;
+    rc = msa_weights(c, d_msa, N, L, c->w, side);
+    if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, side);
   } else if (u <= c->fe_inv + c->fe_vgru) {
-    const int j = u - c->fe_inv - 1;
-    rc = gru_vertical_steps(c, d_msa, N, L, j * FE_VGRU_STEPS, std::min((j + 1) * FE_VGRU_STEPS, N + 1),
-                            c->vout, s);
+    // alternate GRU chunk / inverse chunk while both kinds remain
+    const int k = u - 1, m = std::min(c->fe_inv, c->fe_vgru);
+    bool inv;
+    int j;
+    if (k < 2 * m) { inv = (k & 1) != 0; j = k >> 1; }
+    else { inv = c->fe_inv > m; j = m + (k - 2 * m); }
+    if (inv) {
+      used = side;
+      rc = spd_inverse_steps(c, c->cov, NS * L, j * FE_INV_BLOCKS, (j + 1) * FE_INV_BLOCKS, side);
+      if (!rc && j == c->fe_inv - 1) {
+        rc = dca_contacts(c, c->cov, L, c->contacts, side);
+        if (!rc && fork) DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[1], side));
+      }
+    } else {
+      rc = gru_vertical_steps(c, d_msa, N, L, j * FE_VGRU_STEPS, std::min((j + 1) * FE_VGRU_STEPS, N + 1),
+                              c->vout, s);
+    }
   } else {
     const float* inv = N > 1 ? c->cov : nullptr;
     const float* contacts = N > 1 ? c->contacts : nullptr;
+    if (fork) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->side_ev[1], 0));
     rc = gru_bidir(c, 0, c->vout, L, c->seq_b, s);
     if (!rc) rc = transpose_f32(c->seq_b, L, WIDTH, c->mat1d, s);
     if (!rc) rc = stem_static(c, c->mat1d, inv, contacts, L, c->z0, s);
@@ -708,7 +737,7 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   }
   if (rc) return rc;
   c->fe_next = u + 1;
-  return record_unit(c, s);
+  return record_unit(c, used);
 }
 
 int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
@@ -739,26 +768,7 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
 int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
                       int Lt, int nloops, int refine_steps, void* stream) {
   int rc = dmp_predict_begin_units(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps);
-  if (rc) return rc;
-  // The covariance features (reweighting, covariance, inverse: f32 matrix cores, serial diagonal blocks)
-  // and the vertical GRU (bound by L1 misses) are independent and use different units of the chip: the
-  // features run on the context's side stream beside the GRU.  (The unit-wise path of a scheduler keeps everything on one stream:
-  // there other targets fill the machine.)
-  dmp_ctx* c = ctx;
-  hipStream_t s = STREAM, side = (hipStream_t)c->side_stream;
-  static const bool no_fork = getenv("DMP_NO_SIDE_STREAM") && getenv("DMP_NO_SIDE_STREAM")[0] == '1';   // A/B timing
-  const bool fork = c->fe_inv > 0 && side != nullptr && !no_fork;
-  while (!rc && c->fe_next < c->fe_total) {
-    const int u = c->fe_next;
-    const bool inv_unit = fork && u <= c->fe_inv;          // reweighting, covariance, inverse, contacts
-    if (fork && u == 0) {
-      DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[0], s));
-      DMP_HIP(hipStreamWaitEvent(side, (hipEvent_t)c->side_ev[0], 0));
-    }
-    if (fork && u == c->fe_total - 1) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->side_ev[1], 0));
-    rc = issue_front_end_unit(c, inv_unit ? side : s);
-    if (!rc && fork && u == c->fe_inv) DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[1], side));
-  }
+  while (!rc && ctx->fe_next < ctx->fe_total) rc = issue_front_end_unit(ctx, STREAM);
   return rc;
 }
 
