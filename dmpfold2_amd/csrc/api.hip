@@ -411,11 +411,6 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
     c->side_ev[i] = (void*)e;
   }
-  {
-    hipStream_t st;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
-    c->side_stream = (void*)st;
-  }
   *out = c;
   return DMP_OK;
 }
@@ -693,7 +688,15 @@ static bool side_stream_enabled() {
 static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   const int L = c->last_L, N = c->last_N, u = c->fe_next;
   const uint8_t* d_msa = c->run_msa;
-  const bool fork = c->fe_inv > 0 && c->side_stream != nullptr && side_stream_enabled();
+  // Only the single-target entry (dmp_predict_begin) forks: a scheduler that drives several contexts has
+  // other targets to fill the machine, and a second stream per context would push the process past the
+  // hardware queues (with 4 engines the unused side streams alone cost 10 % of the throughput).
+  const bool fork = c->fe_side && c->fe_inv > 0 && side_stream_enabled();
+  if (fork && !c->side_stream) {
+    hipStream_t st;
+    DMP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->side_stream = (void*)st;
+  }
   hipStream_t side = fork ? (hipStream_t)c->side_stream : s;
   hipStream_t used = s;
   int rc = DMP_OK;
@@ -759,6 +762,7 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->run_msa = d_msa;
   c->run_template = d_template_ca;
   c->fe_next = 0;
+  c->fe_side = false;
   c->fe_inv = N > 1 ? cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
   c->fe_vgru = cdiv(N + 1, FE_VGRU_STEPS);
   c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
@@ -768,6 +772,7 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
 int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
                       int Lt, int nloops, int refine_steps, void* stream) {
   int rc = dmp_predict_begin_units(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps);
+  if (!rc) ctx->fe_side = true;
   while (!rc && ctx->fe_next < ctx->fe_total) rc = issue_front_end_unit(ctx, STREAM);
   return rc;
 }

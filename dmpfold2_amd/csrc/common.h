@@ -180,6 +180,7 @@ struct dmp_ctx {
   void* unit_ev[2] = {nullptr, nullptr};   // hipEvent_t ring: recorded after each unit issued
   void* side_stream = nullptr;             // hipStream_t: dmp_predict_begin runs the covariance inverse here, beside the vertical GRU
   void* side_ev[2] = {nullptr, nullptr};   // fork / join events of the side stream
+  bool fe_side = false;                    // this prediction's front end forks onto the side stream
   long unit_seq = 0;           // units issued since the context was created
   int fe_next = 0, fe_total = 0;           // front-end units (features, sequence trunk, static stem)
   int fe_inv = 0, fe_vgru = 0;             // ... of which inverse chunks / vertical-GRU chunks

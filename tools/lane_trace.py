@@ -26,6 +26,8 @@ dev = torch.device("cuda:0")
 sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_scale=5.0).items()}
 msas = [torch.from_numpy(encode_aln(synth.synth_msa(L, N, seed=i))).to(dev) for i in range(8)]
 pipe = Pipeline(dev, L, N, sd, streams=S)
+for e in pipe.engines:                                   # A/B knob
+    e.set_option("refine_single", int(os.environ.get("LT_REFINE_SINGLE", "0")))
 pipe.run(msas[:S], 10, 100)
 torch.cuda.synchronize()
 lib = pipe.lib
