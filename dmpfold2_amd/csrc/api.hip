@@ -762,7 +762,10 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->run_msa = d_msa;
   c->run_template = d_template_ca;
   c->fe_next = 0;
-  c->fe_side = false;
+  {
+    static const bool side_units = getenv("DMP_SIDE_UNITS") && getenv("DMP_SIDE_UNITS")[0] == '1';   // experiment
+    c->fe_side = side_units;
+  }
   c->fe_inv = N > 1 ? cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
   c->fe_vgru = cdiv(N + 1, FE_VGRU_STEPS);
   c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
