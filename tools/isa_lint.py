@@ -63,14 +63,18 @@ def device_asm(src, flags):
 
 def main():
     from dmpfold2_amd import build as B
-    bad = 0
-    for src in B.SOURCES:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(src):
         path = os.path.join(B.CSRC, src)
-        per_file = B.per_file_flags(src) if hasattr(B, "per_file_flags") else []
-        found = scan_asm(device_asm(path, B.FLAGS + per_file))
-        for sym, ins in found:
-            print("%s: %s: %s" % (src, sym, ins))
-        bad += len(found)
+        return src, scan_asm(device_asm(path, B.FLAGS + B.per_file_flags(src)))
+
+    bad = 0
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for src, found in ex.map(one, B.SOURCES):
+            for sym, ins in found:
+                print("%s: %s: %s" % (src, sym, ins))
+            bad += len(found)
     print("isa_lint: %d hazardous packed instruction(s)" % bad)
     return 1 if bad else 0
 
