@@ -275,7 +275,16 @@ static int trunk_open(dmp_ctx* c, const float* z0, const float* dmap, int L, hip
 
 static int trunk_block(dmp_ctx* c, int k, int L, hipStream_t s) {
   int rc;
-  if (c->lane && c->lane->last) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->lane->last, 0));
+  {
+    // The lane admits two convolutions at a time: a launch waits for the one before the previous one,
+    // so the tail of one launch (1444 workgroups on 512 slots at L = 300, fewer at smaller L) fills with
+    // the head of the next.  Measured (tools/lane_trace.py, structures/s at depth 1 / 2 / 3 / 4):
+    // L = 300: 6.72 / 7.00 / 6.88 / 6.74; L = 200: 12.7 / 13.8-14.1 / 13.8 / 13.4; L = 128: 26.0 / 28.7 / 28.5.
+    // DMP_LANE_DEPTH overrides.
+    static const int depth = getenv("DMP_LANE_DEPTH") ? std::max(1, atoi(getenv("DMP_LANE_DEPTH"))) : 2;
+    if (c->lane && c->lane->count >= depth)
+      DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->lane->ev[(c->lane->count - depth) % dmp_lane::RING], 0));
+  }
   if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
     DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n], s));
   }
@@ -286,6 +295,7 @@ static int trunk_block(dmp_ctx* c, int k, int L, hipStream_t s) {
     ln->next = (ln->next + 1) % dmp_lane::RING;
     DMP_HIP(hipEventRecord((hipEvent_t)e, s));
     ln->last = e;
+    ln->count++;
   }
   if (c->prof_on && c->prof_n + 2 <= (int)c->prof_ev.size()) {
     DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n + 1], s));

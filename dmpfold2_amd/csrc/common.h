@@ -102,6 +102,7 @@ struct dmp_lane {
   std::vector<void*> ev;   // hipEvent_t ring
   int next = 0;
   void* last = nullptr;    // event recorded after the most recent conv launch
+  long long count = 0;     // conv launches recorded so far (event of launch i: ev[i % RING])
 };
 
 struct dmp_ctx {

@@ -21,7 +21,7 @@ from dmpfold2_amd.predict import Pipeline, encode_aln    # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-L, N = 300, 2000
+L, N = int(os.environ.get("LT_L", "300")), int(os.environ.get("LT_N", "2000"))
 dev = torch.device("cuda:0")
 sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_scale=5.0).items()}
 msas = [torch.from_numpy(encode_aln(synth.synth_msa(L, N, seed=i))).to(dev) for i in range(8)]
