@@ -201,9 +201,11 @@ int dmp_predict_issue_unit(dmp_ctx* ctx, void* stream);
 int dmp_ctx_pending(dmp_ctx* ctx);
 
 /* Throughput mode: contexts of ONE process that run on different streams may share a lane.  The
- * machine-filling conv5x5 launches of all contexts on a lane then take turns (cross-stream events)
- * while every other kernel of one target overlaps the convolutions of another.  All contexts of
- * a lane must be driven by the same host thread.  NULL detaches. */
+ * machine-filling conv5x5 launches of all contexts on a lane then take turns (cross-stream events),
+ * two in flight at a time (a launch waits for the one before the previous one, so the tail of one
+ * launch fills with the head of the next), while every other kernel of one target overlaps the
+ * convolutions of another.  All contexts of a lane must be driven by the same host thread.  NULL
+ * detaches. */
 typedef struct dmp_lane dmp_lane;
 int dmp_lane_create(dmp_lane** out);
 void dmp_lane_destroy(dmp_lane* lane);
