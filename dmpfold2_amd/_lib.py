@@ -54,6 +54,7 @@ SIGNATURES = {
     "dmp_lane_create": (_i, [C.POINTER(_vp)]),
     "dmp_lane_destroy": (None, [_vp]),
     "dmp_ctx_set_lane": (_i, [_vp, _vp]),
+    "dmp_sync_faults": (_i, [_vp, _vp, C.POINTER(_i)]),
     "dmp_sync_check": (_i, [_vp, _vp]),
     "dmp_debug_fetch": (_i64, [_vp, C.c_char_p, _fp, _i64, _vp]),
     "dmp_profile_enable": (_i, [_vp, _i, _i]),

@@ -29,6 +29,15 @@ from .predict import (Pipeline, default_iterations, default_minsteps, encode_aln
                       pdb_text, read_a3m, read_aln, read_template_ca)
 
 
+class BatchFailures(RuntimeError):
+    """Some targets of a shard failed; the PDB files of all the others were written."""
+
+    def __init__(self, failed, n_done, elapsed, outputs):
+        self.failed, self.n_done, self.elapsed, self.outputs = failed, n_done, elapsed, outputs
+        super().__init__(f"{len(failed)} targets failed (the {len(outputs)} PDB files of the others "
+                         "were written): " + ", ".join(f"{a} ({type(e).__name__}: {e})" for a, e in failed))
+
+
 def read_target_list(path):
     """[(alignment path, template path or None)] from a text file (blank lines and # comments skipped)."""
     out = []
@@ -46,39 +55,50 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
               weights_file=None, state_dict=None, streams=4, device=None, rank=0, world=1):
     """Predict the targets of this rank's shard; returns (number done, seconds, [output paths])."""
     os.makedirs(out_dir, exist_ok=True)
-    parsed = []
+    parsed, failed = [], []
     for aln_path, tpl_path in targets:
         rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
-        parsed.append((aln_path, tpl_path, encode_aln(rows)))
+        try:
+            parsed.append((aln_path, tpl_path, encode_aln(rows)))
+        except (IndexError, ValueError) as exc:      # unknown residue letter / ragged rows: this target only
+            if rank == 0:
+                failed.append((aln_path, exc))
     costs = [shard.estimate_cost(m.shape[1], m.shape[0], iterations) for _, _, m in parsed]
     mine = shard.partition_targets(costs, world)[rank]
-    if not mine:
+    if not mine and not failed:
         return 0, 0.0, []
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    max_L = max(parsed[i][2].shape[1] for i in mine)
-    max_N = max(parsed[i][2].shape[0] for i in mine)
-    sd = state_dict if state_dict is not None else load_state_dict(weights_file)
-    pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
     t0 = time.perf_counter()
-    tickets = []
+    tickets, results, pipe = [], {}, None
+    if mine:
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        max_L = max(parsed[i][2].shape[1] for i in mine)
+        max_N = max(parsed[i][2].shape[0] for i in mine)
+        sd = state_dict if state_dict is not None else load_state_dict(weights_file)
+        pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
     for i in mine:                                   # longest first: the order partition_targets returns
         aln_path, tpl_path, alnmat = parsed[i]
         tpl = read_template_ca(tpl_path) if tpl_path else None
         d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
         tickets.append((i, pipe.submit(d_msa, iterations, minsteps, template_ca=tpl)))
         pipe.pump()
-    pipe.drain()
-    pipe.sync_check()
+    if pipe is not None:
+        results = pipe.collect([t for _, t in tickets])
     outputs = []
     for i, t in tickets:
-        coords, confs = pipe.result(t)
         aln_path, _, alnmat = parsed[i]
+        if isinstance(results[t], Exception):        # this target only: the others keep their results
+            failed.append((aln_path, results[t]))
+            continue
+        coords, confs = results[t]
         out_path = os.path.join(out_dir, os.path.splitext(os.path.basename(aln_path))[0] + ".pdb")
         with open(out_path, "w") as fh:
             fh.write(pdb_text(coords, confs, alnmat))
         outputs.append(out_path)
     elapsed = time.perf_counter() - t0
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
+    if failed:
+        raise BatchFailures(failed, len(outputs), elapsed, outputs)
     return len(mine), elapsed, outputs
 
 
@@ -103,9 +123,15 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     targets = read_target_list(args.list)
-    n, elapsed, _ = run_batch(targets, args.out_dir, args.iterations, args.minsteps,
-                              weights_file=args.model_weights, streams=args.streams,
-                              device=f"cuda:{local_rank}", rank=rank, world=world)
+    status = 0
+    try:
+        n, elapsed, _ = run_batch(targets, args.out_dir, args.iterations, args.minsteps,
+                                  weights_file=args.model_weights, streams=args.streams,
+                                  device=f"cuda:{local_rank}", rank=rank, world=world)
+    except BatchFailures as bf:                      # keep going: the other ranks wait in job_summary
+        for aln_path, exc in bf.failed:
+            print(f"dmpfold-batch: {aln_path}: {type(exc).__name__}: {exc}", file=sys.stderr)
+        n, elapsed, status = bf.n_done, bf.elapsed, 1
     total, tmax = shard.job_summary(n, elapsed)
     if rank == 0:
         print(json.dumps({"targets": total, "seconds": tmax, "structures_per_s": total / tmax if tmax > 0 else 0.0,
@@ -113,7 +139,7 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
-    return 0
+    return status
 
 
 if __name__ == "__main__":

@@ -330,6 +330,20 @@ static int coords_from_mds(dmp_ctx* c, const float* mat1d, const float* mds, int
   return coord_fc(c, c->seq_a, L, d_ca, s);
 }
 
+// End of a prediction: if a device-side fault was recorded while it ran, its outputs become NaN (an
+// invalid structure can never be mistaken for a result, and a batch can tell WHICH target failed) and
+// the fault bits are latched into the word dmp_sync_faults reports.
+__global__ void fault_latch_kernel(int* __restrict__ words, float* __restrict__ coords,
+                                   float* __restrict__ conf, int L) {
+  const int f = words[0];
+  if (!f) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float nan = __builtin_nanf("");
+  if (i < 15 * L) coords[i] = nan;
+  if (i < L) conf[i] = nan;
+  if (i == 0) atomicOr(&words[1], f);
+}
+
 }  // namespace dmp
 
 using namespace dmp;
@@ -385,7 +399,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(emb, L * (WIDTH + 8));
   A_(mat1d, L * WIDTH);
   A_(seq_hx, 2 * 2 * HID2);
-  A_(seq_abort, 1);
+  A_(seq_abort, 2);      // [0] fault word of the prediction in flight, [1] faults latched by finished ones
   A_(refine_gx, 2 * 3 * L);
   A_(z0, (int64_t)STEM_OUT * LL);
   A_(dmap, LL);
@@ -412,8 +426,9 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(ca_pass, (int64_t)c->max_passes * L * 3);
 #undef A_
   if (rc) { dmp_ctx_destroy(c); return rc; }
-  if (hipMemset(c->seq_abort, 0, sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+  if (hipMemset(c->seq_abort, 0, 2 * sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
   if ((rc = trunk_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
+  if ((rc = mds_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
   for (int i = 0; i < 2; ++i) {
     hipEvent_t e;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
@@ -427,7 +442,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
 
 int dmp_clear_faults(dmp_ctx* ctx, void* stream) {
   DMP_ARG(ctx != nullptr, "null context");
-  DMP_HIP(hipMemsetAsync(ctx->seq_abort, 0, sizeof(int), (hipStream_t)stream));
+  DMP_HIP(hipMemsetAsync(ctx->seq_abort, 0, 2 * sizeof(int), (hipStream_t)stream));
   return DMP_OK;
 }
 
@@ -446,18 +461,33 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   return DMP_ERR_ARG;
 }
 
-int dmp_sync_check(dmp_ctx* ctx, void* stream) {
-  DMP_ARG(ctx != nullptr, "null context");
+int dmp_sync_faults(dmp_ctx* ctx, void* stream, int* h_bits) {
+  DMP_ARG(ctx && h_bits, "null argument");
   DMP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int words[2] = {0, 0};
+  DMP_HIP(hipMemcpy(words, ctx->seq_abort, sizeof(words), hipMemcpyDeviceToHost));
+  *h_bits = words[0] | words[1];
+  // reported once: a fault of one prediction must not poison the checks of the following ones
+  if (*h_bits) DMP_HIP(hipMemset(ctx->seq_abort, 0, sizeof(words)));
+  return DMP_OK;
+}
+
+int dmp_sync_check(dmp_ctx* ctx, void* stream) {
   int flag = 0;
-  DMP_HIP(hipMemcpy(&flag, ctx->seq_abort, sizeof(int), hipMemcpyDeviceToHost));
+  const int rc = dmp_sync_faults(ctx, stream, &flag);
+  if (rc) return rc;
+  if (flag & DMP_FAULT_BAD_CODE) {
+    set_error("index out of range in self: the alignment holds a residue code above 21 "
+              "(a character outside the alignment alphabet)");
+    return DMP_ERR_ARG;
+  }
   if (flag) {
-    set_error("device-side fault (results invalid):%s%s%s",
-              (flag & 1) ? " sequence-GRU workgroup hand-off timed out;" : "",
-              (flag & 4) ? " minimiser workgroup hand-off timed out;" : "",
-              (flag & 2) ? " an activation left the f16 range of the split-product convolution "
-                           "(use option conv_f32_exact or conv_mode=2);" : "");
-    return DMP_ERR_HIP;
+    set_error("device-side fault (results invalid, outputs set to NaN):%s%s%s",
+              (flag & DMP_FAULT_SEQ_HANDOFF) ? " sequence-GRU workgroup hand-off timed out;" : "",
+              (flag & DMP_FAULT_REFINE_HANDOFF) ? " minimiser workgroup hand-off timed out;" : "",
+              (flag & DMP_FAULT_F16_RANGE) ? " an activation left the f16 range of the split-product convolution "
+                                             "(use option conv_f32_exact or conv_mode=2);" : "");
+    return DMP_ERR_FAULT;
   }
   return DMP_OK;
 }
@@ -487,11 +517,12 @@ int dmp_weights_set(dmp_ctx* c, const char* key, const float* h_data, const int6
     int64_t n = 1;
     bool ok = (int)k.shape.size() == ndim;
     for (int i = 0; ok && i < ndim; ++i) { ok = (shape[i] == k.shape[i]); n *= shape[i]; }
-    if (!ok) { set_error("size mismatch for %s", key); return DMP_ERR_WEIGHTS; }
+    if (!ok) { c->W.host.clear(); set_error("size mismatch for %s", key); return DMP_ERR_WEIGHTS; }
     c->W.host[key].assign(h_data, h_data + n);
     c->W.ready = false;
     return DMP_OK;
   }
+  c->W.host.clear();     // a rejected state_dict leaves nothing staged for the next attempt
   set_error("unexpected key %s in state_dict", key);
   return DMP_ERR_WEIGHTS;
 }
@@ -500,7 +531,11 @@ int dmp_weights_finalize(dmp_ctx* c) {
   DMP_ARG(c != nullptr, "null context");
   static const std::vector<KeySpec> spec = weight_spec();
   for (const auto& k : spec)
-    if (!c->W.host.count(k.key)) { set_error("missing key %s in state_dict", k.key.c_str()); return DMP_ERR_WEIGHTS; }
+    if (!c->W.host.count(k.key)) {
+      c->W.host.clear();
+      set_error("missing key %s in state_dict", k.key.c_str());
+      return DMP_ERR_WEIGHTS;
+    }
   DMP_HIP(hipSetDevice(c->device));
   for (void* p : c->W.allocs) { (void)hipFree(p); }
   c->W.allocs.clear();
@@ -711,6 +746,8 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   hipStream_t used = s;
   int rc = DMP_OK;
   if (u == 0) {
+    // the fault word of the previous prediction was latched by its dmp_predict_end
+    DMP_HIP(hipMemsetAsync(c->seq_abort, 0, sizeof(int), s));
     if (fork) {
       DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[0], s));
       DMP_HIP(hipStreamWaitEvent(side, (hipEvent_t)c->side_ev[0], 0));
@@ -879,7 +916,11 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) 
   // split-product convolution) was a packed-f32 instruction form that coords.hip no longer contains
   // (tools/isa_lint.py).
   rc = ca_to_backbone(c->best_ca, c->best_conf, L, d_coords, d_conf, s);
-  return rc;
+  if (rc) return rc;
+  hipLaunchKernelGGL(fault_latch_kernel, dim3(cdiv(15 * L, 256)), dim3(256), 0, s, c->seq_abort, d_coords,
+                     d_conf, L);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
 }
 
 // ---- heavy lane: serialises the conv launches of the contexts that share it -----------------

@@ -143,7 +143,7 @@ struct dmp_ctx {
   float* emb = nullptr;     // [L][520]
   float* mat1d = nullptr;   // [512][L]
   unsigned long long* seq_hx = nullptr;  // [2][2][256] hand-off granules of the sequence GRU
-  int* seq_abort = nullptr;              // [1] set if a hand-off timed out
+  int* seq_abort = nullptr;              // [2] DMP_FAULT_* bits: [0] of the prediction in flight, [1] latched by finished ones
   unsigned long long* refine_gx = nullptr;  // [2][3 max_L] hand-off granules of the minimiser cluster
   int refine_xcd = 0;                    // XCD the minimiser cluster of this context runs on
   // pair trunk
@@ -242,6 +242,7 @@ int act_unpad(const float* d_xpad, int L, float* d_dense, hipStream_t s);
 int act_clear(float* d_xpad, int L, hipStream_t s);
 int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s);
 // mds.hip
+int mds_kernel_attrs(dmp_ctx* c);     // once per device, at context creation
 int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s);
 // coords.hip
 int coord_fc(dmp_ctx* c, const float* d_g, int L, float* d_ca, hipStream_t s);

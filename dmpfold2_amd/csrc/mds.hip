@@ -669,6 +669,18 @@ static int tridiag_graph(dmp_ctx* c, int n, double* A, TriRun* run, double* d, d
   return DMP_OK;
 }
 
+// tri_eig_kernel keeps 11 n doubles in dynamic LDS: 112 640 bytes at the largest order (1280), above the
+// 64 KB a kernel may use without the opt-in.  Set once per device at context creation (see
+// trunk_kernel_attrs for why never between launches).
+int mds_kernel_attrs(dmp_ctx* c) {
+  static bool done[64] = {};
+  if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
+  DMP_HIP(hipFuncSetAttribute((const void*)tri_eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double) * (3 + NEV) * 1280)));
+  if (c->device >= 0 && c->device < 64) done[c->device] = true;
+  return DMP_OK;
+}
+
 int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) {
   const int n = L;
   double* A = c->eig_a;

@@ -10,7 +10,7 @@ namespace dmp {
 // codes clamped to <= 20 and packed 4 per word; tail bytes are 0xFF in every row, so each
 // pair gains exactly (4*Lw - L) spurious matches, removed again in the count kernel.
 __global__ void msa_pack_kernel(const uint8_t* __restrict__ msa, int N, int L, int Lw,
-                                uint32_t* __restrict__ words) {
+                                uint32_t* __restrict__ words, int* __restrict__ fault) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)N * Lw) return;
   const int n = idx / Lw, wd = idx % Lw;
@@ -20,6 +20,8 @@ __global__ void msa_pack_kernel(const uint8_t* __restrict__ msa, int N, int L, i
     uint32_t c = 0xFF;
     if (l < L) {
       c = msa[(int64_t)n * L + l];
+      // the reference's 22-row embedding raises IndexError on such a code (network.py:223)
+      if (c > 21) atomicOr(fault, DMP_FAULT_BAD_CODE);
       c = c > 20 ? 20 : c;
     }
     v |= c << (8 * b);
@@ -98,7 +100,7 @@ int msa_weights(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_w, hipS
   const int Lw = cdiv(L, 4);
   const int64_t nw = (int64_t)N * Lw;
   hipLaunchKernelGGL(msa_pack_kernel, dim3((unsigned)cdiv64(nw, 256)), dim3(256), 0, s, d_msa, N,
-                     L, Lw, c->msa_words);
+                     L, Lw, c->msa_words, c->seq_abort);
   DMP_LAUNCH_CHECK();
   DMP_HIP(hipMemsetAsync(c->nbr_count, 0, sizeof(int) * N, s));
   const float id_min = (float)((double)L * 0.8);

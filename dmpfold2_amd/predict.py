@@ -8,6 +8,9 @@ PyTorch is used only for device memory and the current stream.
 Differences from the reference, all additive or forced by the environment:
   * there is no CPU path: `device` must name a GPU ("cuda", "cuda:1", an int, or a
     torch.device).  The default is "cuda" (the reference defaults to "cpu");
+  * `aln_to_coords` synchronises with the GPU before it returns and checks the engine's device-side
+    fault word: a prediction whose activations left the range of the default split-f16 convolution is
+    re-run with the range-free bf16 split (a note goes to stderr), any other fault raises;
   * packed weights are cached per (device, weights file) instead of being rebuilt on
     every call (the reference constructs and loads a fresh network each time);
   * eigenvector signs of the MDS step follow a fixed rule (see include/dmpfold_hip.h);
@@ -64,7 +67,10 @@ def read_a3m(input_file):
 
 def encode_aln(rows):
     """Residue letters -> uint8 codes (N, L), capped at 3000 rows (predict.py:124-132).
-    Ragged input raises ValueError from the reshape, as in the reference."""
+    Ragged input raises ValueError from the reshape, as in the reference.  A character outside the
+    alignment alphabet (lower-case a3m inserts, digits ...) maps to a code above 21, which the
+    reference's 22-row embedding rejects with IndexError (network.py:223): raised here, for the
+    rows that survive the 3000-row cap, as the reference would."""
     nseqs = len(rows)
     length = len(rows[0])
     text = np.frombuffer("".join(rows).encode("latin-1"), dtype=np.uint8)
@@ -74,6 +80,8 @@ def encode_aln(rows):
     alnmat = codes.reshape(nseqs, length)
     if nseqs > MAX_SEQS:
         alnmat = alnmat[:MAX_SEQS]
+    if alnmat.size and int(alnmat.max()) > 21:
+        raise IndexError("index out of range in self")
     return alnmat
 
 
@@ -113,11 +121,36 @@ def load_state_dict(weights_file=None):
                 f"trained model not found at {parts[0]}; the reference would download it, this "
                 "build does not: place the two FINAL_fullmap_e2e_model_part*.pt files there or "
                 "pass weights_file=/-w")
-        sd = torch.load(parts[0], map_location="cpu")
-        sd.update(torch.load(parts[1], map_location="cpu"))
+        sd = torch.load(parts[0], map_location="cpu", weights_only=True)
+        sd.update(torch.load(parts[1], map_location="cpu", weights_only=True))
     else:
-        sd = torch.load(weights_file, map_location="cpu")
+        # weights_only: a user-supplied -w file is data (a tensor dict), never unpickled code
+        sd = torch.load(weights_file, map_location="cpu", weights_only=True)
     return sd
+
+
+# device-side fault bits (include/dmpfold_hip.h, DMP_FAULT_*)
+FAULT_SEQ_HANDOFF, FAULT_F16_RANGE, FAULT_REFINE_HANDOFF, FAULT_BAD_CODE = 1, 2, 4, 8
+
+
+class DeviceFault(_lib.DmpError):
+    """A device-side fault invalidated a prediction (its outputs are NaN)."""
+
+    def __init__(self, bits):
+        self.bits = int(bits)
+        what = [txt for bit, txt in ((FAULT_SEQ_HANDOFF, "sequence-GRU workgroup hand-off timed out"),
+                                     (FAULT_REFINE_HANDOFF, "minimiser workgroup hand-off timed out"),
+                                     (FAULT_F16_RANGE, "an activation left the f16 range of the "
+                                      "split-product convolution (conv_mode 2 has no range limit)"))
+                if bits & bit]
+        super().__init__("device-side fault (results invalid): " + "; ".join(what))
+
+
+def raise_for_faults(bits):
+    if bits & FAULT_BAD_CODE:
+        raise IndexError("index out of range in self")      # the embedding lookup of network.py:223
+    if bits:
+        raise DeviceFault(bits)
 
 
 # ---------------------------------------------------------------------------
@@ -137,6 +170,7 @@ class Engine:
             _lib.check(self.lib.dmp_ctx_create(self.device.index, self.max_L, self.max_N,
                                                C.byref(self._ctx)))
         self.weights_tag = None
+        self.options = {}
 
     def close(self):
         if self._ctx:
@@ -234,10 +268,50 @@ class Engine:
     def set_option(self, name, value):
         """Additive engine options, e.g. ("conv_f32_exact", 1); see include/dmpfold_hip.h."""
         _lib.check(self.lib.dmp_ctx_set_option(self._ctx, name.encode(), int(value)))
+        if name == "conv_f32_exact":
+            name, value = "conv_mode", 1 if value else 0
+        self.options[name] = int(value)
+
+    def sync_faults(self):
+        """Wait for the queued work; the DMP_FAULT_* bits recorded since the last report (reporting
+        clears them).  Predictions that ran while a bit was raised returned NaN."""
+        bits = C.c_int(0)
+        _lib.check(self.lib.dmp_sync_faults(self._ctx, self.stream(), C.byref(bits)))
+        return bits.value
 
     def sync_check(self):
-        """Wait for the queued work and raise if a device-side fault was recorded."""
-        _lib.check(self.lib.dmp_sync_check(self._ctx, self.stream()))
+        """Wait for the queued work and raise if a device-side fault was recorded: IndexError for a
+        residue code above 21 (as the reference's embedding), DeviceFault otherwise."""
+        raise_for_faults(self.sync_faults())
+
+    def predict_checked(self, alnmat, template_ca=None, iterations=default_iterations,
+                        minsteps=default_minsteps):
+        """`predict`, synchronised and verified.  The default convolution multiplies f16 pieces of its
+        operands and needs |activation| < 6e4; a prediction that leaves that range (never seen with
+        InstanceNorm'd trunks, but the trained weights decide) is repeated with the 3-way bf16 split,
+        which has float32's range, at about half the convolution rate."""
+        alnmat = np.ascontiguousarray(alnmat, dtype=np.uint8)
+        with torch.cuda.device(self.device):
+            d_msa = torch.from_numpy(alnmat).to(self.device)
+        return self.predict_device_checked(d_msa, template_ca, iterations, minsteps)
+
+    def predict_device_checked(self, d_msa, template_ca=None, iterations=default_iterations,
+                               minsteps=default_minsteps):
+        """`predict_checked` for residue codes already resident on the GPU."""
+        coords, confs = self.predict_device(d_msa, template_ca, iterations, minsteps)
+        bits = self.sync_faults()
+        if bits == FAULT_F16_RANGE and self.options.get("conv_mode", 0) == 0:
+            print("dmpfold2_amd: activations left the f16 range of the split-product convolution; "
+                  "re-running this alignment with conv_mode=2 (bf16 split, no range limit)",
+                  file=sys.stderr)
+            self.set_option("conv_mode", 2)
+            try:
+                coords, confs = self.predict_device(d_msa, template_ca, iterations, minsteps)
+                bits = self.sync_faults()
+            finally:
+                self.set_option("conv_mode", 0)
+        raise_for_faults(bits)
+        return coords, confs
 
     def fetch(self, name, numel):
         out = torch.empty((int(numel),), dtype=torch.float32, device=self.device)
@@ -293,7 +367,12 @@ class Pipeline:
         self._total = [0] * S
         self._stagger = bool(stagger)
         self._results = {}
+        self._jobs = {}               # ticket -> job, kept until the result is handed out (retry of faults)
         self._tickets = 0
+        # DMP_PUMP_SLEEP_US: sleep that long whenever a scheduling round found nothing to issue (default:
+        # only yield the core).  One scheduler thread per GPU polls HIP events; with 8 ranks on a node
+        # that is 8 polling threads, which yield to anything else runnable on their cores.
+        self._idle_sleep = float(os.environ.get("DMP_PUMP_SLEEP_US", "0")) * 1e-6
 
     def close(self):
         for e in self.engines:
@@ -328,17 +407,26 @@ class Pipeline:
                                    f"alignment has {L} columns")
         t = self._tickets
         self._tickets += 1
-        self._pending.append((t, d_msa, int(max(iterations, 0)), int(max(minsteps, 0)), d_tpl))
+        job = (t, d_msa, int(max(iterations, 0)), int(max(minsteps, 0)), d_tpl)
+        self._pending.append(job)
+        self._jobs[t] = job
         return t
 
     def _begin(self, s, job):
         t, d_msa, nloops, minsteps, d_tpl = job
         e = self.engines[s]
-        e._stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        e._stream.wait_stream(cur)
         n, L = d_msa.shape
-        with torch.cuda.stream(e._stream):
+        # The outputs belong to the caller's stream (drain() orders it after the engine); inputs and
+        # outputs are used on the engine's stream, which the caching allocator has to know before it
+        # recycles their blocks.
+        with torch.cuda.device(self.device):
             coords = torch.empty((L, 5, 3), dtype=torch.float32, device=self.device)
             confs = torch.empty((L,), dtype=torch.float32, device=self.device)
+        for x in (coords, confs, d_msa, d_tpl):
+            if x is not None:
+                x.record_stream(e._stream)
         _lib.check(self.lib.dmp_predict_begin_units(
             e.ctx, d_msa.data_ptr(), n, L, d_tpl.data_ptr() if d_tpl is not None else None,
             L if d_tpl is not None else 0, nloops, minsteps))
@@ -399,24 +487,59 @@ class Pipeline:
                     break
         return progressed
 
+    def _idle(self):
+        """Nothing could be issued: every engine waits for the GPU.  Give the core away instead of
+        polling flat out."""
+        if self._idle_sleep > 0:
+            time.sleep(self._idle_sleep)
+        else:
+            os.sched_yield()
+
     def pump(self):
         """Schedule until every queued target has been started on an engine."""
         with torch.cuda.device(self.device):          # launches and graph builds need the current device
             while self._pending:
-                self._pump()
+                if not self._pump():
+                    self._idle()
 
     def drain(self):
         """Schedule until every queued target is fully enqueued; the current stream then waits for
         the engines' streams (nothing is synchronised with the host)."""
         with torch.cuda.device(self.device):
             while self._pending or any(x is not None for x in self._slot):
-                self._pump()
+                if not self._pump():
+                    self._idle()
         cur = torch.cuda.current_stream(self.device)
         for e in self.engines:
             cur.wait_stream(e._stream)
 
     def result(self, ticket):
+        self._jobs.pop(ticket, None)
         return self._results.pop(ticket)
+
+    def collect(self, tickets):
+        """drain + synchronise + verify.  Returns {ticket: (coords, confs) or Exception}: a target
+        whose prediction recorded a device-side fault (its outputs are NaN) is repeated alone through
+        `Engine.predict_device_checked` - which falls back to the range-free convolution where that
+        is the cure - and only if that fails too its entry is the exception.  One bad target never
+        costs the others their results."""
+        self.drain()
+        bits = 0
+        for e in self.engines:
+            bits |= e.sync_faults()
+        out = {}
+        for t in tickets:
+            job = self._jobs.get(t)
+            coords, confs = self.result(t)
+            if bits and bool(torch.isnan(confs[0])):
+                _, d_msa, nloops, minsteps, d_tpl = job
+                try:
+                    coords, confs = self.engines[0].predict_device_checked(d_msa, d_tpl, nloops, minsteps)
+                except (IndexError, _lib.DmpError) as exc:
+                    out[t] = exc
+                    continue
+            out[t] = (coords, confs)
+        return out
 
     def run(self, d_msas, iterations=default_iterations, minsteps=default_minsteps):
         """Predict every target (uint8 (N, L) tensors on the GPU).  Returns [(coords, confs)] in
@@ -426,8 +549,12 @@ class Pipeline:
         return [self.result(t) for t in tickets]
 
     def sync_check(self):
+        """Synchronise every engine and raise for the first recorded fault (see `collect` for the
+        per-target form)."""
+        bits = 0
         for e in self.engines:
-            e.sync_check()
+            bits |= e.sync_faults()
+        raise_for_faults(bits)
 
 
 _ENGINES = {}
@@ -469,7 +596,7 @@ def aln_to_coords(input_file, device=default_device, template=None, iterations=d
     alnmat = encode_aln(aln)
     nseqs, length = alnmat.shape
     eng = get_engine(dev, length, nseqs, weights_file=weights_file)
-    coords, confs = eng.predict(alnmat, template_ca, iterations, minsteps)
+    coords, confs = eng.predict_checked(alnmat, template_ca, iterations, minsteps)
     if return_alnmat:
         return coords, confs, alnmat
     return coords, confs

@@ -37,8 +37,17 @@ typedef enum dmp_status {
   DMP_ERR_ARG = -1,     /* bad argument (sizes, NULL, L < 8 ...) */
   DMP_ERR_HIP = -2,     /* a HIP runtime call failed */
   DMP_ERR_WEIGHTS = -3, /* unknown key, wrong shape, or weights incomplete */
-  DMP_ERR_CAPACITY = -4 /* L or N exceeds what the context was created for */
+  DMP_ERR_CAPACITY = -4, /* L or N exceeds what the context was created for */
+  DMP_ERR_FAULT = -5     /* a device-side fault was recorded: results invalid (dmp_sync_check) */
 } dmp_status;
+
+/* Device-side fault bits (dmp_sync_faults).  A prediction during which a bit was raised returns NaN
+ * coordinates and confidences. */
+#define DMP_FAULT_SEQ_HANDOFF 1    /* sequence-GRU workgroup hand-off timed out */
+#define DMP_FAULT_F16_RANGE 2      /* conv_mode 0: an activation reached |x| >= 6e4 (re-run in conv_mode 2) */
+#define DMP_FAULT_REFINE_HANDOFF 4 /* minimiser workgroup hand-off timed out */
+#define DMP_FAULT_BAD_CODE 8       /* residue code > 21: the reference's embedding raises IndexError
+                                      (network.py:223); dmp_sync_check returns DMP_ERR_ARG for it */
 
 int dmp_abi_version(void);
 const char* dmp_last_error(void);
@@ -66,7 +75,7 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * of a cluster of 16 that hands the coordinates over every step; same iteration, different
  * partial-sum slices (results agree to float32 rounding). */
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value);
-/* Reset the device-side fault word read by dmp_sync_check (enqueued on `stream`). */
+/* Reset the device-side fault words read by dmp_sync_faults (enqueued on `stream`). */
 int dmp_clear_faults(dmp_ctx* ctx, void* stream);
 
 /* ---- weights (the reference's state_dict ABI, network.py:182-215) ---------------------
@@ -74,7 +83,8 @@ int dmp_clear_faults(dmp_ctx* ctx, void* stream);
  * float32, contiguous, with its shape (replaces load_state_dict, predict.py:98).
  * dmp_weights_finalize: checks that all 184 tensors arrived and builds the packed device
  * layouts the kernels read (transposed GRU matrices, K-major conv slabs, the cSE gate
- * sigma(W2 relu(W1 beta)) of every block). */
+ * sigma(W2 relu(W1 beta)) of every block).  A rejected tensor (unknown key, wrong shape) or an
+ * incomplete set drops everything staged so far: the next state_dict starts from nothing. */
 int dmp_weights_set(dmp_ctx* ctx, const char* key, const float* h_data, const int64_t* shape,
                     int ndim);
 int dmp_weights_finalize(dmp_ctx* ctx);
@@ -211,8 +221,11 @@ int dmp_lane_create(dmp_lane** out);
 void dmp_lane_destroy(dmp_lane* lane);
 int dmp_ctx_set_lane(dmp_ctx* ctx, dmp_lane* lane);
 
-/* Synchronise `stream` and report device-side faults recorded since the context was created
- * (the bounded spin of the sequence-GRU workgroup hand-off).  0 = all results valid. */
+/* Synchronise `stream` and report the device-side faults recorded since the last report
+ * (DMP_FAULT_* bits in *h_bits; 0 = every result handed out since then is valid).  Reporting clears
+ * them: one failed prediction does not poison the checks of later ones.  dmp_sync_check is the same
+ * as a status: DMP_OK, DMP_ERR_ARG (residue code > 21) or DMP_ERR_FAULT, message in dmp_last_error. */
+int dmp_sync_faults(dmp_ctx* ctx, void* stream, int* h_bits);
 int dmp_sync_check(dmp_ctx* ctx, void* stream);
 
 /* ---- introspection for tests and the benchmark ------------------------------------------- */

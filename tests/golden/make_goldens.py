@@ -127,16 +127,24 @@ def run_oracle(aln_path, wfile, n, m, template=None, sign="canonical", threads=8
 
 
 def capture_case(name, aln_rows, n, m, wfile, wsum, template=None, sign="canonical",
-                 stages=True, report=None, with_cli=False, extra=None):
+                 stages=True, report=None, with_cli=False, extra=None, store_aln=True,
+                 noise_threads=1):
+    """`store_aln=False` keeps only a SHA-256 of the residue codes (large synthetic alignments are
+    regenerated from their seed by the tests); `noise_threads` is the thread count of the second
+    oracle run that measures the noise floor (1 is unaffordable at the north-star size)."""
     aln_path = os.path.join("/tmp", f"golden_{name}.aln")
     synth.write_aln(aln_path, aln_rows)
     coords, confs, alnmat, tap = run_reference(aln_path, wfile, n, m, template, sign)
-    out = {"aln_text": np.frombuffer("\n".join(aln_rows).encode("latin-1"), dtype=np.uint8),
-           "iterations": np.int64(n), "minsteps": np.int64(m),
+    out = {"iterations": np.int64(n), "minsteps": np.int64(m),
            "sign_mode": np.frombuffer(sign.encode(), dtype=np.uint8),
            "weights_sha256": np.frombuffer(wsum.encode(), dtype=np.uint8),
-           "alnmat": alnmat.astype(np.uint8),
+           "alnmat_sha256": np.frombuffer(
+               hashlib.sha256(np.ascontiguousarray(alnmat, dtype=np.uint8).tobytes()).hexdigest().encode(),
+               dtype=np.uint8),
            "coords": coords.numpy(), "confs": confs.numpy()}
+    if store_aln:
+        out["aln_text"] = np.frombuffer("\n".join(aln_rows).encode("latin-1"), dtype=np.uint8)
+        out["alnmat"] = alnmat.astype(np.uint8)
     if extra:
         out.update(extra)
     if "w" in tap:
@@ -173,7 +181,8 @@ def capture_case(name, aln_rows, n, m, wfile, wsum, template=None, sign="canonic
         out["cli_stdout"] = np.frombuffer(buf.getvalue().encode(), dtype=np.uint8)
     # oracle vs reference, and the oracle's own noise floor (8 vs 1 thread)
     oc, of, oa, _ = run_oracle(aln_path, wfile, n, m, template, sign, 8)
-    o1, f1, _, _ = run_oracle(aln_path, wfile, n, m, template, sign, 1)
+    o1, f1, _, _ = run_oracle(aln_path, wfile, n, m, template, sign, noise_threads)
+    out["noise_threads"] = np.int64(noise_threads)
     dev = rmsd(oc[:, 1], coords[:, 1])
     devc = float((of - confs).abs().max())
     nf = rmsd(oc[:, 1], o1[:, 1])
@@ -185,81 +194,148 @@ def capture_case(name, aln_rows, n, m, wfile, wsum, template=None, sign="canonic
     assert (oa == alnmat).all()
     line = (f"{name:24s} L={L:4d} N={alnmat.shape[0]:5d} n={n:3d} m={m:4d} sign={sign:9s} "
             f"passes={npass:3d} oracle-vs-ref CA-RMSD={dev:.2e} dconf={devc:.2e} | "
-            f"noise(8v1 thr) CA-RMSD={nf:.2e} dconf={nfc:.2e}")
+            f"noise(8v{noise_threads} thr) CA-RMSD={nf:.2e} dconf={nfc:.2e}")
     print(line, flush=True)
     if report is not None:
         report.append(line)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
-def chain_a_ca(pdb_path):
-    xyz = []
+def chain_a_ca(pdb_path, with_seq=False):
+    xyz, seq = [], []
     for line in open(pdb_path):
         if line[:4] == "ATOM" and line[12:16] == " CA " and line[21] == "A":
             xyz.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
-    return np.asarray(xyz, dtype=np.float32)
+            seq.append(line[17:20])
+    xyz = np.asarray(xyz, dtype=np.float32)
+    return (xyz, seq) if with_seq else xyz
+
+
+def fit_coord_fc(sd, aln_rows, target_ca, ridge):
+    """coord_fc.weight (3, 512) fitted by ridge regression so that the FIRST-pass CA trace of
+    `aln_rows` under the synthetic weights `sd` approximates `target_ca` (centred): the pass-0
+    coordinate-GRU output G (L, 512) does not depend on coord_fc, so trace_0 = G Wfc^T is linear in
+    it.  With a protein-like first trace the minimiser runs in its regular regime (3.8 A bonds, few
+    clashes) instead of on the collapsed tangle random weights produce, and the end-to-end noise
+    floor at minsteps=100 drops from 0.12 A to a few 1e-4 A."""
+    W = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    alnmat = O.encode_aln(aln_rows)
+    cap = {}
+    with torch.no_grad():
+        O.predict(alnmat, W, None, 0, 0, "canonical", capture=cap)
+        emb = torch.cat((cap["mat1d"].t().unsqueeze(0), cap["p0.mds"].unsqueeze(0)), dim=2)
+        G = O._gru(W, "coord_gru", emb, 520, 256, 3, True, True)[0].double()
+    t = torch.from_numpy(np.asarray(target_ca)).double()
+    t = t - t.mean(0, keepdim=True)
+    A = G @ G.t() + ridge * torch.eye(G.shape[0], dtype=torch.float64)
+    return (G.t() @ torch.linalg.solve(A, t)).t().float().contiguous().numpy()
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma-separated case names (default: all)")
+    only = [x for x in ap.parse_args().only.split(",") if x]
     report = []
     sd = synth.synth_weights(0, coord_scale=5.0)
     wfile = "/tmp/golden_weights_seed0.pt"
     synth.save_state_dict(wfile, sd)
     wsum = synth.weights_checksum(sd)
-    report.append(f"synthetic weights seed=0 coord_scale=5.0 sha256={wsum}")
+    header = f"synthetic weights seed=0 coord_scale=5.0 sha256={wsum}"
 
     pf = O.read_aln(os.path.join(REF, "dmpfold/example/PF10963.aln"))
     with open(os.path.join(HERE, "PF10963.aln"), "w") as fh:      # data file of the reference
         fh.write("\n".join(pf) + "\n")
-
-    capture_case("pf10963_n0_m0_lapack", pf, 0, 0, wfile, wsum, sign="lapack", report=report)
-    capture_case("pf10963_n0_m0", pf, 0, 0, wfile, wsum, report=report)
-    capture_case("pf10963_n3_m0", pf, 3, 0, wfile, wsum, stages=False, report=report)
-    capture_case("pf10963_n2_m5", pf, 2, 5, wfile, wsum, stages=False, report=report)
-    capture_case("pf10963_default_cli", pf, 10, 100, wfile, wsum, stages=False, report=report,
-                 with_cli=True)
-
-    capture_case("synth_L40_N64_n2_m0", synth.synth_msa(40, 64, 1), 2, 0, wfile, wsum,
-                 report=report)
-    capture_case("synth_L24_N3050_n1_m0", synth.synth_msa(24, 3050, 2), 1, 0, wfile, wsum,
-                 stages=False, report=report)
-    capture_case("synth_L30_N1_n1_m3", synth.synth_msa(30, 1, 3), 1, 3, wfile, wsum,
-                 stages=False, report=report)
-    # full alphabet incl. BJOUXZ and both gap characters in rows >= 1
-    rows = synth.synth_msa(16, 12, 4)
-    odd = "BJOUXZ-."
-    rows = [rows[0]] + [r[:i] + odd[i % 8] + r[i + 1:] if i < 16 else r
-                        for i, r in enumerate(rows[1:])]
-    capture_case("alphabet_L16_N12_n0_m0", rows, 0, 0, wfile, wsum, stages=False, report=report)
-
-    # template path: chain A of the reference's example structure as the seed distance map
     ca = chain_a_ca(os.path.join(REF, "dmpfold/example/3FGX.pdb"))
     tpl = "/tmp/golden_template.pdb"
     with open(tpl, "w") as fh:
         for i, (x, y, z) in enumerate(ca):
             fh.write("ATOM  %5d  CA  ALA A%4d    %8.3f%8.3f%8.3f  1.00  0.00\n" % (i + 1, i + 1, x, y, z))
-    capture_case("template_L96_N50_n1_m0", synth.synth_msa(len(ca), 50, 5), 1, 0, wfile, wsum,
-                 template=tpl, stages=False, report=report,
-                 extra={"template_ca": ca})
+
+    def want(name):
+        return not only or name in only
+
+    def case(name, *a, **kw):
+        if want(name):
+            capture_case(name, *a, report=report, **kw)
+
+    case("pf10963_n0_m0_lapack", pf, 0, 0, wfile, wsum, sign="lapack")
+    case("pf10963_n0_m0", pf, 0, 0, wfile, wsum)
+    case("pf10963_n3_m0", pf, 3, 0, wfile, wsum, stages=False)
+    case("pf10963_n2_m5", pf, 2, 5, wfile, wsum, stages=False)
+    case("pf10963_default_cli", pf, 10, 100, wfile, wsum, stages=False, with_cli=True)
+    # the benchmark's recycling depth (11 trunk passes) on the reference's example alignment
+    case("pf10963_n10_m0", pf, 10, 0, wfile, wsum, stages=False)
+
+    case("synth_L40_N64_n2_m0", synth.synth_msa(40, 64, 1), 2, 0, wfile, wsum)
+    case("synth_L24_N3050_n1_m0", synth.synth_msa(24, 3050, 2), 1, 0, wfile, wsum, stages=False)
+    case("synth_L30_N1_n1_m3", synth.synth_msa(30, 1, 3), 1, 3, wfile, wsum, stages=False)
+    # full alphabet incl. BJOUXZ and both gap characters in rows >= 1
+    rows = synth.synth_msa(16, 12, 4)
+    odd = "BJOUXZ-."
+    rows = [rows[0]] + [r[:i] + odd[i % 8] + r[i + 1:] if i < 16 else r
+                        for i, r in enumerate(rows[1:])]
+    case("alphabet_L16_N12_n0_m0", rows, 0, 0, wfile, wsum, stages=False)
+
+    # template path: chain A of the reference's example structure as the seed distance map
+    case("template_L96_N50_n1_m0", synth.synth_msa(len(ca), 50, 5), 1, 0, wfile, wsum,
+         template=tpl, stages=False, extra={"template_ca": ca})
+
+    # the north-star size (bench.py's target 0: L=300, N=2000), two trunk passes, from the reference
+    # itself; the alignment is regenerated from its seed by the tests (only its checksum is stored)
+    case("synth_L300_N2000_n1_m0", synth.synth_msa(300, 2000, 0), 1, 0, wfile, wsum, stages=False,
+         store_aln=False, noise_threads=4, extra={"msa_seed": np.int64(0)})
+
+    # minimiser end to end on protein-like traces: coord_fc fitted so that the first-pass trace of a
+    # synthetic L=96 alignment approximates 3FGX chain A (see fit_coord_fc)
+    rows96 = synth.synth_msa(len(ca), 50, 5)
+    for name, ridge, n, m in (("fit3fgx_L96_N50_n0_m100", 1e-3, 0, 100),
+                              ("fit3fgx_L96_N50_n10_m100", 1e-1, 10, 100)):
+        if not want(name):
+            continue
+        sd2 = dict(sd)
+        sd2["coord_fc.weight"] = fit_coord_fc(sd, rows96, ca, ridge)
+        wf2 = f"/tmp/golden_weights_{name}.pt"
+        synth.save_state_dict(wf2, sd2)
+        capture_case(name, rows96, n, m, wf2, synth.weights_checksum(sd2), stages=False,
+                     report=report, extra={"coord_fc": sd2["coord_fc.weight"], "target_ca": ca,
+                                           "ridge": np.float64(ridge)})
 
     # known-answer vectors for the minimiser and the backbone builder on a real CA trace
-    t = torch.from_numpy(ca)
-    kat = {"ca_in": ca}
-    for steps in (1, 10, 100, 1000):
-        kat[f"refined_{steps}"] = RN.refine_coords(t, steps).numpy()
-    kat["backbone"] = RN.calpha_to_main_chain(t.unsqueeze(0))[0].numpy()
-    noisy = t + 2.0 * torch.from_numpy(
-        np.random.Generator(np.random.Philox(key=7)).random((len(ca), 3)).astype(np.float32) - 0.5)
-    kat["ca_noisy"] = noisy.numpy()
-    kat["refined_noisy_100"] = RN.refine_coords(noisy, 100).numpy()
-    for steps in (100, 1000):
-        d = float((RN.refine_coords(t, steps) - O.refine_coords(t, steps)).abs().max())
-        report.append(f"refine KAT {steps} steps: oracle vs reference max|d|={d:.2e}")
-    np.savez_compressed(os.path.join(HERE, "kat_refine_backbone.npz"), **kat)
+    if want("kat_refine_backbone"):
+        t = torch.from_numpy(ca)
+        three = "ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL".split()
+        seq3 = chain_a_ca(os.path.join(REF, "dmpfold/example/3FGX.pdb"), with_seq=True)[1]
+        seq1 = "".join("ARNDCQEGHILKMFPSTWYV"[three.index(r)] if r in three else "X" for r in seq3)
+        kat = {"ca_in": ca, "seq1": np.frombuffer(seq1.encode(), dtype=np.uint8)}   # one-letter sequence of chain A
+        for steps in (1, 10, 100, 1000):
+            kat[f"refined_{steps}"] = RN.refine_coords(t, steps).numpy()
+        kat["backbone"] = RN.calpha_to_main_chain(t.unsqueeze(0))[0].numpy()
+        noisy = t + 2.0 * torch.from_numpy(
+            np.random.Generator(np.random.Philox(key=7)).random((len(ca), 3)).astype(np.float32) - 0.5)
+        kat["ca_noisy"] = noisy.numpy()
+        kat["refined_noisy_100"] = RN.refine_coords(noisy, 100).numpy()
+        for steps in (100, 1000):
+            d = float((RN.refine_coords(t, steps) - O.refine_coords(t, steps)).abs().max())
+            report.append(f"refine KAT {steps} steps: oracle vs reference max|d|={d:.2e}")
+        np.savez_compressed(os.path.join(HERE, "kat_refine_backbone.npz"), **kat)
 
-    with open(os.path.join(HERE, "REPORT.txt"), "w") as fh:
-        fh.write("\n".join(report) + "\n")
-    print("\n".join(report))
+    # REPORT.txt: one line per case; a partial run replaces only the lines of the cases it made
+    path = os.path.join(HERE, "REPORT.txt")
+    old = open(path).read().splitlines() if (only and os.path.exists(path)) else []
+    def key_of(ln):
+        return " ".join(ln.split()[:3]) if ln.startswith("refine KAT") else ln.split()[0]
+    made = {key_of(ln): ln for ln in report}
+    lines, seen = [header], set()
+    for ln in old[1:]:
+        lines.append(made.get(key_of(ln), ln))
+        seen.add(key_of(ln))
+    for ln in report:
+        if key_of(ln) not in seen:
+            lines.append(ln)
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
 
 
 if __name__ == "__main__":

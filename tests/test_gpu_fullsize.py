@@ -207,3 +207,27 @@ def test_embedding_is_folded_into_the_input_weights(synth_sd, oracle_weights):
     v = O._gru(ow, "vgru", ow["embed.weight"][idx], 22, 512, 2, False, False)[-1].numpy()
     assert np.abs(out - v).max() < 1e-5
     st.eng.close()
+
+
+def test_eigensolver_at_the_largest_order(synth_sd):
+    """max_L = 1280: the bisection / inverse-iteration kernel keeps 11 n doubles in LDS (112 640 bytes,
+    needs the dynamic-LDS opt-in set at context creation).  A distance-geometry Gram matrix of a 3-D
+    random walk plus noise against the float64 solution."""
+    from abi import Stages
+    st = Stages(synth_sd, max_L=1280, max_N=4)
+    try:
+        rng = np.random.default_rng(17)
+        for L in (1280, 1000):
+            P = np.cumsum(rng.standard_normal((L, 3)) * 2.2, axis=0)
+            D = np.linalg.norm(P[:, None] - P[None], axis=2) + np.abs(rng.standard_normal((L, L))) * 0.3
+            D = 0.5 * (D + D.T)
+            M = (0.5 * (D[0:1, :] ** 2 + D[:, 0:1] ** 2 - D ** 2)).astype(np.float32)
+            got = st.eigh_top8(st.to(M)).cpu().numpy().astype(np.float64)
+            st.eng.sync_check()
+            Mu = np.triu(M.astype(np.float64)) + np.triu(M.astype(np.float64), 1).T      # upper triangle is used
+            lam, vec = np.linalg.eigh(Mu)
+            vec = vec[:, -8:] * np.sign(vec[np.abs(vec[:, -8:]).argmax(axis=0), np.arange(L - 8, L)])
+            truth = vec * np.sqrt(np.maximum(lam[-8:], 1e-8))
+            assert np.abs(got - truth).max() <= 2e-5 * np.abs(truth).max(), L
+    finally:
+        st.eng.close()

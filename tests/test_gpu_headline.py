@@ -1,0 +1,377 @@
+"""End-to-end pins of the HEADLINE path against vectors captured from the reference itself
+(tests/golden/make_goldens.py): the benchmark's recycling depth (11 trunk passes), the benchmark's
+size (L=300, N=2000) and the benchmark's minimiser setting (2 x 100 steps) on protein-like traces -
+each in the default split-f16 convolution AND the exact-f32 one - plus the behaviour at the drop-in
+boundary when something goes wrong on the device (range fault -> automatic re-run, unknown residue
+code -> IndexError, bad weight files -> RuntimeError) and the sharded batch front end.
+
+Tolerances: CA-RMSD <= 1e-3 A and |dconf| < 1e-4 at minsteps=0 (BASELINE.json north_star); with the
+minimiser max(1e-3, 3 x the reference's own 8-vs-1-thread deviation stored in the fixture).
+"""
+import contextlib
+import hashlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_rows, ca_rmsd
+
+pytestmark = pytest.mark.gpu
+
+import dmpfold_oracle as O          # noqa: E402  (test infrastructure: the checker)
+
+MODES = {"f16x3": 0, "f32": 1}
+
+
+def _engine(sd, max_L, max_N):
+    from dmpfold2_amd.predict import Engine
+    eng = Engine("cuda:0", max_L, max_N)
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return eng
+
+
+@pytest.fixture(scope="module")
+def small_engine(synth_sd):
+    eng = _engine(synth_sd, 128, 512)
+    yield eng
+    eng.close()
+
+
+def _check_passes(eng, g, P, L, tol):
+    means = eng.fetch("conf_means", P).cpu().numpy()
+    assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
+    ca_pass = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
+    worst = max(ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P))
+    assert worst <= tol, worst
+
+
+# ------------------------------------------------------------------ the benchmark's recycling depth
+@pytest.mark.parametrize("mode", list(MODES))
+def test_pf10963_eleven_passes_vs_reference(small_engine, mode):
+    """-n 10 -m 0 on the reference's example alignment: 11 trunk passes (176 convolutions) deep, every
+    pass's CA trace and confidence mean against the reference's, then the final structure."""
+    g = load_golden("pf10963_n10_m0")
+    eng = small_engine
+    eng.set_option("conv_mode", MODES[mode])
+    try:
+        coords, confs = eng.predict(g["alnmat"], None, 10, 0)
+        eng.sync_check()
+        coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
+        _check_passes(eng, g, 11, 82, 1e-3)
+        assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= 1e-3
+        assert np.abs(confs - g["confs"]).max() < 1e-4
+        assert np.abs(coords - g["coords"]).max() < 2e-2
+    finally:
+        eng.set_option("conv_mode", 0)
+
+
+# ------------------------------------------------------------------ the benchmark's size
+@pytest.fixture(scope="module")
+def ns_engine(synth_sd):
+    eng = _engine(synth_sd, 300, 2000)
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_north_star_size_vs_reference(ns_engine, mode):
+    """bench.py's target 0 (L=300, N=2000, seed 0), iterations=1, minsteps=0, against the output of the
+    reference itself at that size (6 minutes of reference CPU time in the build container)."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import encode_aln
+    g = load_golden("synth_L300_N2000_n1_m0")
+    alnmat = encode_aln(synth.synth_msa(300, 2000, int(g["msa_seed"])))
+    assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+    eng = ns_engine
+    eng.set_option("conv_mode", MODES[mode])
+    try:
+        coords, confs = eng.predict(alnmat, None, 1, 0)
+        eng.sync_check()
+        coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
+        _check_passes(eng, g, 2, 300, 1e-3)
+        assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= 1e-3
+        assert np.abs(confs - g["confs"]).max() < 1e-4
+    finally:
+        eng.set_option("conv_mode", 0)
+
+
+# ------------------------------------------------------------------ the benchmark's minimiser setting
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("name", ["fit3fgx_L96_N50_n0_m100", "fit3fgx_L96_N50_n10_m100"])
+def test_minimiser_end_to_end_on_protein_like_traces(synth_sd, name, mode):
+    """minsteps=100 (the CLI default, 2 x 100 steps) end to end.  With random weights the first trace
+    is a collapsed tangle on which the reference's minimiser is chaotic (0.12 A between its own 8- and
+    1-thread runs); these fixtures use synthetic weights whose coord_fc was fitted so that the first
+    trace approximates 3FGX chain A (make_goldens.fit_coord_fc), where the noise floor is 2-4e-4 A."""
+    g = load_golden(name)
+    sd = dict(synth_sd)
+    sd["coord_fc.weight"] = g["coord_fc"]
+    from dmpfold2_amd import synth
+    assert synth.weights_checksum(sd) == bytes(g["weights_sha256"]).decode()
+    eng = _engine(sd, 96, 64)
+    eng.set_option("conv_mode", MODES[mode])
+    try:
+        n, m = int(g["iterations"]), int(g["minsteps"])
+        coords, confs = eng.predict(g["alnmat"], None, n, m)
+        eng.sync_check()
+        coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
+        tol = max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
+        assert tol <= 1.1e-3                                   # the floor of these fixtures is small
+        assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= tol
+        assert np.abs(confs - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
+        means = eng.fetch("conf_means", n + 1).cpu().numpy()
+        assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
+        # the trace really is protein-like: bonded CA-CA distances near 3.8 A after the minimiser
+        ca = coords[:, 1]
+        bond = np.linalg.norm(ca[1:] - ca[:-1], axis=1)
+        assert 3.5 < bond.min() and bond.max() < 6.0
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------ device faults at the boundary
+def _hot_weights(synth_sd):
+    """Synthetic weights whose block-6 InstanceNorm scales its output by 4e4: the residual stream
+    leaves the f16 range (|x| >= 6e4) from block 7 on.  Everything stays finite in float32."""
+    sd = dict(synth_sd)
+    sd["resnet.6.layer1.norm.weight"] = (sd["resnet.6.layer1.norm.weight"] * 4e4).astype(np.float32)
+    sd["resnet.6.layer1.norm.bias"] = (sd["resnet.6.layer1.norm.bias"] * 4e4).astype(np.float32)
+    return sd
+
+
+def test_f16_range_fault_is_reported_poisoned_and_cured(synth_sd, tmp_path, capsys):
+    from dmpfold2_amd import aln_to_coords, synth
+    from dmpfold2_amd import predict as P
+    sd = _hot_weights(synth_sd)
+    rows = synth.synth_msa(40, 64, 1)
+    alnmat = P.encode_aln(rows)
+    ow = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    ref_c, ref_f = O.predict(alnmat, ow, None, 1, 0, "canonical")
+    eng = _engine(sd, 64, 64)
+    try:
+        # raw call: the fault is recorded, the outputs are NaN, the report clears the word
+        coords, confs = eng.predict(alnmat, None, 1, 0)
+        bits = eng.sync_faults()
+        assert bits == P.FAULT_F16_RANGE
+        assert bool(torch.isnan(coords).all()) and bool(torch.isnan(confs).all())
+        assert eng.sync_faults() == 0
+        with pytest.raises(P.DeviceFault):
+            eng.predict(alnmat, None, 1, 0)
+            eng.sync_check()
+        # the range-free convolutions give the reference's answer
+        for mode in (2, 1):
+            eng.set_option("conv_mode", mode)
+            c, f = eng.predict(alnmat, None, 1, 0)
+            eng.sync_check()
+            assert ca_rmsd(c.cpu().numpy()[:, 1], ref_c.numpy()[:, 1]) <= 1e-3, mode
+            assert np.abs(f.cpu().numpy() - ref_f.numpy()).max() < 1e-4, mode
+        eng.set_option("conv_mode", 0)
+        # the checked entry re-runs by itself and says so
+        capsys.readouterr()
+        c, f = eng.predict_checked(alnmat, None, 1, 0)
+        assert "conv_mode=2" in capsys.readouterr().err
+        assert ca_rmsd(c.cpu().numpy()[:, 1], ref_c.numpy()[:, 1]) <= 1e-3
+        assert eng.options["conv_mode"] == 0
+    finally:
+        eng.close()
+    # the public function: same cure through aln_to_coords, and the engine is healthy afterwards
+    wf, aln = str(tmp_path / "hot.pt"), str(tmp_path / "t.aln")
+    synth.save_state_dict(wf, sd)
+    synth.write_aln(aln, rows)
+    c, f = aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=wf)
+    assert "conv_mode=2" in capsys.readouterr().err
+    assert ca_rmsd(c.cpu().numpy()[:, 1], ref_c.numpy()[:, 1]) <= 1e-3
+    assert np.abs(f.cpu().numpy() - ref_f.numpy()).max() < 1e-4
+
+
+def test_unknown_residue_code_raises_index_error(small_engine, tmp_path, weights_file):
+    """network.py:223: a code above 21 fails in the reference's embedding.  File input: raised by the
+    host parser; device-resident codes: flagged by the first kernel that reads them."""
+    from dmpfold2_amd import aln_to_coords, synth
+    rows = synth.synth_msa(24, 8, 3)
+    rows[5] = rows[5][:7] + "x" + rows[5][8:]
+    aln = tmp_path / "lower.aln"
+    synth.write_aln(str(aln), rows)
+    with pytest.raises(IndexError):
+        aln_to_coords(str(aln), device="cuda:0", iterations=0, minsteps=0, weights_file=weights_file)
+    codes = O.encode_aln(synth.synth_msa(24, 8, 3)).copy()
+    codes[5, 7] = 22
+    eng = small_engine
+    d = torch.from_numpy(codes).to("cuda:0")
+    coords, confs = eng.predict_device(d, None, 0, 0)
+    with pytest.raises(IndexError):
+        eng.sync_check()
+    assert bool(torch.isnan(coords).all())
+    # reported once; the next (valid) prediction is clean
+    codes[5, 7] = 21
+    coords, confs = eng.predict(codes, None, 0, 0)
+    eng.sync_check()
+    assert bool(torch.isfinite(coords).all())
+
+
+def test_scheduler_isolates_a_faulting_target(synth_sd):
+    """Pipeline.collect: the one target with a bad residue code comes back as its exception, the
+    others as the bits the single engine computes."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Pipeline
+    dev = torch.device("cuda:0")
+    msas = [O.encode_aln(synth.synth_msa(L, N, 60 + i)) for i, (L, N) in
+            enumerate([(40, 30), (33, 12), (48, 64), (24, 5)])]
+    bad = msas[1].copy()
+    bad[3, 3] = 30
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()}
+    pipe = Pipeline(dev, 64, 64, sd, streams=3)
+    try:
+        order = [msas[0], bad, msas[2], msas[3], msas[1]]
+        tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 2) for m in order]
+        res = pipe.collect(tickets)
+        assert isinstance(res[tickets[1]], IndexError)
+        single = pipe.engines[0]
+        for t, m in zip(tickets, order):
+            if t == tickets[1]:
+                continue
+            c, f = single.predict(m, None, 1, 2)
+            single.sync_check()
+            assert torch.equal(c, res[t][0]) and torch.equal(f, res[t][1])
+    finally:
+        pipe.close()
+
+
+def test_hot_target_in_a_batch_is_re_run_alone(synth_sd):
+    """A range fault inside the scheduler: that target is repeated through the checked single-engine
+    path (conv_mode 2) and every target of the batch gets a valid result."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Pipeline
+    dev = torch.device("cuda:0")
+    sd = _hot_weights(synth_sd)
+    ow = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    msas = [O.encode_aln(synth.synth_msa(L, N, 70 + i)) for i, (L, N) in enumerate([(40, 30), (32, 16)])]
+    pipe = Pipeline(dev, 64, 64, ow, streams=2)
+    try:
+        tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 0) for m in msas]
+        res = pipe.collect(tickets)
+        for t, m in zip(tickets, msas):
+            rc, rf = O.predict(m, ow, None, 1, 0, "canonical")
+            c, f = res[t]
+            assert ca_rmsd(c.cpu().numpy()[:, 1], rc.numpy()[:, 1]) <= 1e-3
+            assert np.abs(f.cpu().numpy() - rf.numpy()).max() < 1e-4
+    finally:
+        pipe.close()
+
+
+# ------------------------------------------------------------------ weight ABI: strict load
+def test_weight_abi_rejects_unknown_missing_and_misshaped_tensors(synth_sd):
+    """load_state_dict(strict) semantics of predict.py:98: RuntimeError naming the key."""
+    from dmpfold2_amd.predict import Engine
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()}
+    eng = Engine("cuda:0", 32, 8)
+    try:
+        extra = dict(sd)
+        extra["resnet.18.weight"] = torch.zeros(2, 128, 1, 1)
+        with pytest.raises(RuntimeError, match="resnet.18.weight"):
+            eng.set_weights(extra)
+        missing = {k: v for k, v in sd.items() if k != "coord_fc.weight"}
+        with pytest.raises(RuntimeError, match="coord_fc.weight"):
+            eng.set_weights(missing)
+        shaped = dict(sd)
+        shaped["vgru.weight_ih_l0"] = torch.zeros(1536, 21)
+        with pytest.raises(RuntimeError, match="vgru.weight_ih_l0"):
+            eng.set_weights(shaped)
+        flat = dict(sd)
+        flat["resnet.17.weight"] = torch.zeros(2, 128)          # right count, wrong rank
+        with pytest.raises(RuntimeError, match="resnet.17.weight"):
+            eng.set_weights(flat)
+        eng.set_weights(sd)                                       # and the good dict still loads
+        c, f = eng.predict(O.encode_aln(["ACDEFGHIKLMNPQRS"] * 3), None, 0, 0)
+        eng.sync_check()
+        assert bool(torch.isfinite(c).all())
+    finally:
+        eng.close()
+
+
+def test_two_part_default_weights_route(synth_sd, tmp_path, monkeypatch, weights_file):
+    """predict.py:81-92: no -w -> trained_model/FINAL_fullmap_e2e_model_part{1,2}.pt merged.  The two
+    halves of the synthetic state_dict in that layout give the bits of the single-file route."""
+    from dmpfold2_amd import predict as P
+    keys = list(synth_sd)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()}
+    d = tmp_path / "trained_model"
+    d.mkdir()
+    parts = [str(d / f"FINAL_fullmap_e2e_model_part{i}.pt") for i in (1, 2)]
+    torch.save({k: sd[k] for k in keys[:100]}, parts[0])
+    torch.save({k: sd[k] for k in keys[100:]}, parts[1])
+    aln = os.path.join(os.path.dirname(__file__), "golden", "PF10963.aln")
+    c1, f1 = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=3, weights_file=weights_file)
+    monkeypatch.setattr(P, "default_weight_files", lambda: parts)
+    c2, f2 = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=3)
+    assert torch.equal(c1, c2) and torch.equal(f1, f2)
+    monkeypatch.undo()
+    P._ENGINES.clear()
+
+
+# ------------------------------------------------------------------ BASELINE config[3], sharded
+def _parse_pdb(text):
+    ca, conf = [], None
+    for line in text.splitlines():
+        if line.startswith("REMARK  CONF:"):
+            conf = float(line.split()[-1])
+        if line[:4] == "ATOM" and line[12:16] == " CA ":
+            ca.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+    return np.asarray(ca), conf
+
+
+def test_config3_batch_sharded_two_ways(tmp_path, weights_file):
+    """BASELINE configs[3] at reduced count: synthetic targets with L in [100, 300] and N=2000 plus the
+    reference's example alignment, 10 iterations, split over world=2 shards (both run here, one after
+    the other, on the one GPU).  Every PDB equals the text of the single-target CLI, the shards cover
+    every target exactly once, and the example's structure matches the REFERENCE's (-n 10 -m 0 golden)."""
+    from dmpfold2_amd import run_dmpfold, synth
+    from dmpfold2_amd.batch import run_batch
+    rng = np.random.Generator(np.random.Philox(key=256))
+    paths = []
+    for k, L in enumerate(rng.integers(100, 301, size=5)):
+        q = tmp_path / f"t{k}_L{L}.aln"
+        synth.write_aln(str(q), synth.synth_msa(int(L), 2000, seed=300 + k))
+        paths.append(str(q))
+    g = load_golden("pf10963_n10_m0")
+    p = tmp_path / "pf10963.aln"
+    p.write_text("\n".join(golden_rows(g)) + "\n")
+    paths.append(str(p))
+    targets = [(a, None) for a in paths]
+    outs, counts = [], []
+    for rank in (0, 1):
+        n, secs, o = run_batch(targets, str(tmp_path / "out"), 10, 0, weights_file=weights_file,
+                               streams=4, device="cuda:0", rank=rank, world=2)
+        counts.append(n)
+        outs += o
+    assert sum(counts) == 6 and min(counts) >= 1 and len(set(outs)) == 6
+    for a in paths:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            run_dmpfold(["-i", a, "-d", "cuda:0", "-n", "10", "-m", "0", "-w", weights_file])
+        name = os.path.splitext(os.path.basename(a))[0] + ".pdb"
+        assert (tmp_path / "out" / name).read_text() == buf.getvalue(), a
+    ca, conf = _parse_pdb((tmp_path / "out" / "pf10963.pdb").read_text())
+    # %8.3f text: 5e-4 A of rounding per coordinate on top of the 1e-3 A tolerance
+    assert ca_rmsd(ca, g["coords"][:, 1]) <= 1e-3 + 5e-4
+    assert abs(conf - float(g["confs"].mean())) < 1e-4
+
+
+def test_accuracy_harness_runs_when_trained_weights_exist():
+    """TM-score / RMSD of the PF10963 prediction against 3FGX chain A needs the trained
+    weights, which are not in the tree (.MISSING_LARGE_BLOBS); the harness is staged and runs as soon
+    as they are placed in dmpfold2_amd/trained_model/."""
+    from dmpfold2_amd import predict as P
+    if not all(os.path.isfile(f) for f in P.default_weight_files()):
+        pytest.skip("trained weights absent: " + P.default_weight_files()[0])
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("accuracy_3fgx", os.path.join(root, "tools", "accuracy_3fgx.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.evaluate(os.path.join(root, "tests", "golden", "PF10963.aln"),
+                       os.path.join(root, "tests", "golden", "kat_refine_backbone.npz"))
+    assert res["tm_score"] > 0.5, res

@@ -201,3 +201,109 @@ def test_no_hazardous_packed_f32_instruction_in_any_kernel():
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     assert lint.main() == 0
+
+
+# ---------------------------------------------------------------------------- round 2
+def test_unknown_residue_letter_raises_index_error(tmp_path):
+    """A character outside the alignment alphabet maps to a code above 21; the reference fails in its
+    22-row embedding (network.py:223) with IndexError.  Raised on the host before anything runs; rows
+    beyond the 3000-row cap are never looked at, as in the reference."""
+    p = tmp_path / "bad.aln"
+    p.write_text("ACDEFGHIKL\nACDEFgHIKL\n")
+    with pytest.raises(IndexError):
+        predict.encode_aln(predict.read_aln(str(p)))
+    rows = ["ACDEFGHIKL"] * 3000 + ["ACDEF1HIKL"]
+    assert predict.encode_aln(rows).shape == (3000, 10)
+    assert predict.encode_aln(["ACDEFGHIKL", "BJOUXZ-.AC"]).max() == 21
+
+
+def test_fault_bits_map_to_the_reference_exceptions():
+    predict.raise_for_faults(0)
+    with pytest.raises(IndexError):
+        predict.raise_for_faults(predict.FAULT_BAD_CODE | predict.FAULT_F16_RANGE)
+    with pytest.raises(predict.DeviceFault) as ei:
+        predict.raise_for_faults(predict.FAULT_F16_RANGE | predict.FAULT_SEQ_HANDOFF)
+    assert ei.value.bits == 3 and isinstance(ei.value, RuntimeError)
+    header = open(os.path.join(ROOT, "include", "dmpfold_hip.h")).read()
+    for name, bit in (("SEQ_HANDOFF", 1), ("F16_RANGE", 2), ("REFINE_HANDOFF", 4), ("BAD_CODE", 8)):
+        assert re.search(r"#define DMP_FAULT_%s %d\b" % (name, bit), header)
+        assert getattr(predict, "FAULT_" + name) == bit
+
+
+def test_two_part_default_weights_are_merged(tmp_path, monkeypatch, synth_sd):
+    """predict.py:81-96: the default model is two pickled dicts merged with dict.update; a single
+    file through weights_file= gives the same state_dict."""
+    keys = list(synth_sd)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()}
+    d = tmp_path / "trained_model"
+    d.mkdir()
+    parts = [str(d / f"FINAL_fullmap_e2e_model_part{i}.pt") for i in (1, 2)]
+    torch.save({k: sd[k] for k in keys[:90]}, parts[0])
+    torch.save({k: sd[k] for k in keys[90:]}, parts[1])
+    single = str(tmp_path / "one.pt")
+    torch.save(sd, single)
+    monkeypatch.setattr(predict, "default_weight_files", lambda: parts)
+    merged = predict.load_state_dict(None)
+    one = predict.load_state_dict(single)
+    assert list(merged) == keys and list(one) == keys
+    assert all(torch.equal(merged[k], one[k]) for k in keys)
+
+
+def test_weight_files_are_loaded_as_data_only(tmp_path):
+    """A -w file is a tensor dict; anything that needs unpickling code is refused."""
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    p = tmp_path / "evil.pt"
+    torch.save({"embed.weight": Evil()}, str(p))
+    with pytest.raises(pickle.UnpicklingError):
+        predict.load_state_dict(str(p))
+
+
+def test_bench_launches_its_own_ranks_over_gloo():
+    """`python bench.py --gpus 2` outside a launcher starts two ranks itself (the launch, barrier and
+    max-over-ranks code of bench.py with a stand-in workload, gloo backend)."""
+    env = dict(os.environ, DMP_BENCH_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["steps"] == 2
+    # slowest rank sleeps 0.02 * 2 * steps: the reported time is the maximum over the ranks
+    assert out["ms_per_step"] >= 39.0
+    # under a launcher (RANK set) the same command line must not launch again
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "1"], 29555)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "1"]
+
+
+def test_north_star_golden_input_is_reproducible():
+    """The L=300, N=2000 golden stores only a checksum of its alignment: the generator must give the
+    same bytes here and on the GPU box."""
+    import hashlib
+    g = load_golden("synth_L300_N2000_n1_m0")
+    alnmat = predict.encode_aln(synth.synth_msa(300, 2000, int(g["msa_seed"])))
+    assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+    assert g["coords"].shape == (300, 5, 3) and g["ca_pass"].shape == (2, 300, 3)
+    assert float(g["oracle_vs_ref_ca_rmsd"]) <= 1e-3 and float(g["oracle_vs_ref_conf"]) < 1e-4
+
+
+def test_batch_reports_bad_targets_without_losing_the_others(tmp_path):
+    """Host half of the per-target failure path: an alignment with an unknown letter is reported as
+    that target's failure (BatchFailures), before any GPU is needed."""
+    from dmpfold2_amd.batch import BatchFailures, run_batch
+    bad = tmp_path / "bad.aln"
+    bad.write_text("ACDEFGHIKL\nACDEFgHIKL\n")
+    with pytest.raises(BatchFailures) as ei:
+        run_batch([(str(bad), None)], str(tmp_path / "out"), 0, 0, state_dict={})
+    assert len(ei.value.failed) == 1 and isinstance(ei.value.failed[0][1], IndexError)
+    assert ei.value.outputs == []

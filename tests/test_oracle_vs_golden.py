@@ -10,7 +10,8 @@ from dmpfold2_amd import synth
 
 E2E = ["pf10963_n0_m0_lapack", "pf10963_n0_m0", "pf10963_n3_m0", "pf10963_n2_m5",
        "synth_L40_N64_n2_m0", "synth_L24_N3050_n1_m0", "synth_L30_N1_n1_m3",
-       "alphabet_L16_N12_n0_m0", "template_L96_N50_n1_m0"]
+       "alphabet_L16_N12_n0_m0", "template_L96_N50_n1_m0", "pf10963_n10_m0",
+       "fit3fgx_L96_N50_n0_m100", "fit3fgx_L96_N50_n10_m100"]
 
 
 def test_synthetic_weights_are_the_ones_the_goldens_used(synth_sd):
@@ -25,6 +26,11 @@ def test_end_to_end_matches_reference(name, oracle_weights):
     alnmat = O.encode_aln(golden_rows(g))
     assert alnmat.dtype == np.uint8 and np.array_equal(alnmat, g["alnmat"])      # bit exact
     tpl = torch.from_numpy(g["template_ca"]) if "template_ca" in g else None
+    if "coord_fc" in g:          # protein-like fixtures: synthetic weights with a fitted coord_fc
+        oracle_weights = dict(oracle_weights)
+        oracle_weights["coord_fc.weight"] = torch.from_numpy(g["coord_fc"])
+        sd = {k: v.numpy() for k, v in oracle_weights.items()}
+        assert synth.weights_checksum(sd) == bytes(g["weights_sha256"]).decode()
     cap = {}
     coords, confs = O.predict(alnmat, oracle_weights, tpl, int(g["iterations"]),
                               int(g["minsteps"]), sign, cap)

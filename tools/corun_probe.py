@@ -5,7 +5,7 @@ Times `stage A alone`, `the f16x3 convolution alone` and both together on two st
 contexts).  If the stages share the CUs the joint time approaches the larger of the two, if one
 excludes the other it approaches their sum.
 
-    python tools/corun_test.py [gru_vertical|spd_inverse|eigh|trunk_norm]
+    python tools/corun_probe.py [gru_vertical|spd_inverse|eigh|trunk_norm]
 """
 import ctypes as C
 import os

@@ -54,7 +54,8 @@ def scan_asm(text):
 
 
 def device_asm(src, flags):
-    cmd = ["hipcc"] + [f for f in flags if f not in ("-fPIC", "-c")] + ["-S", "--cuda-device-only", src, "-o", "-"]
+    from dmpfold2_amd import build as B
+    cmd = [B._hipcc()] + [f for f in flags if f not in ("-fPIC", "-c")] + ["-S", "--cuda-device-only", src, "-o", "-"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
@@ -67,7 +68,9 @@ def main():
 
     def one(src):
         path = os.path.join(B.CSRC, src)
-        return src, scan_asm(device_asm(path, B.FLAGS + B.per_file_flags(src)))
+        # exactly the flags of the shipped objects, tuning extras included (build.py)
+        extra = os.environ.get("DMP_EXTRA_HIPCC_FLAGS", "").split()
+        return src, scan_asm(device_asm(path, B.FLAGS + extra + B.per_file_flags(src)))
 
     bad = 0
     with ThreadPoolExecutor(max_workers=4) as ex:
