@@ -77,7 +77,7 @@ def _cpu_threads():
     return int(os.environ.get("DMP_CPU_THREADS", min(os.cpu_count() or 1, 16)))
 
 
-def cpu_baseline_full(budget_s=300.0):
+def cpu_baseline_full(budget_s=150.0):
     """ONE complete prediction of the north-star workload by the CPU oracle (bench target 0: all 2000
     rows, 11 trunk passes, 2 x 100 minimiser steps), timed per stage.  Before it starts, a probe
     (vertical GRU on 64 rows, one residual block) estimates the total; if that exceeds `budget_s`

@@ -264,6 +264,7 @@ static int trunk_open(dmp_ctx* c, const float* z0, const float* dmap, int L, hip
   c->trunk_cur = c->xa;
   c->trunk_oth = c->xb;
   c->xsplit_current = false;
+  c->ab_current = false;
   if ((rc = stem_update_padded(c, z0, dmap, L, c->trunk_cur, s))) return rc;
   if (c->conv_mode != 1) {
     // f16 / bf16 pieces of the stem output; every block's norm kernel then emits those of its output
@@ -301,7 +302,7 @@ static int trunk_block(dmp_ctx* c, int k, int L, hipStream_t s) {
     DMP_HIP(hipEventRecord((hipEvent_t)c->prof_ev[c->prof_n + 1], s));
     c->prof_n += 2;
   }
-  if ((rc = conv5x5_reduce_stats(c, L, c->stats, s))) return rc;
+  if ((rc = conv5x5_reduce_stats(c, L, c->stats, s, k))) return rc;
   if ((rc = norm_scse_residual_padded(c, k, c->u, c->stats, c->trunk_cur, L, c->trunk_oth, s))) return rc;
   std::swap(c->trunk_cur, c->trunk_oth);
   return DMP_OK;

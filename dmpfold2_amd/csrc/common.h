@@ -156,7 +156,7 @@ struct dmp_ctx {
   uint16_t* xsplit = nullptr;  // [3][16][P][P][8] bf16 pieces of the current activations
   int conv_mode = 0;           // 0: f16x3 split products (default), 1: exact f32 MFMA, 2: bf16x6 split
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
-  int conv_lds = 0;            // dynamic LDS bytes requested for the f16x3 convolution
+  bool ab_current = false;     // the statistics reduction already wrote this block's InstanceNorm coefficients
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm
@@ -232,7 +232,7 @@ int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L
                        hipStream_t s);
 int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
                           double* d_stats, hipStream_t s, bool reduce);
-int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s);
+int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s, int block = 0);
 int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
                               const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s);
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,

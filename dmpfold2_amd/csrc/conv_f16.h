@@ -15,10 +15,27 @@
 // O(1)..O(100)).  Low pieces of |x| < 0.125 are f16 subnormals: their absolute error <= 3e-8 is far
 // below the float32 accumulation error of the sums they enter.
 //
-// Layouts and workgroup structure are those of conv_bf16.h with 2 pieces instead of 3:
-//   activations  xs[piece 2][c/8 16][P][P][8] f16;   weights wq[split 4][cgrp 8][tap 25][wave 4][piece 2][cg 2][m 32][8] f16
-//   workgroup = 4 waves x 32 conv channels x one 16x16 pixel tile; 8 input stages of 16 channels;
-//   per-wave private weight ring (4 slots of 2 KB, LDS-DMA two taps ahead, counted vmcnt).
+// Workgroup = 4 waves x 32 conv channels x one 16x16 pixel tile (one of 4 channel splits); 8 input stages
+// of 16 channels, whose 20x20 halo tile (both pieces, 30 KB) is brought in by LDS-DMA.
+//
+// Row reuse.  The 32 pixels of the MFMA N axis are 2 rows x 16 columns, so accumulator q (rows 2q, 2q+1
+// of the tile) at tap (dy, dx) reads the B fragment "row pair r = 2q + dy at column offset dx": one
+// fragment serves every (q, dy) with 2q + dy = r.  For a tap column dx the wave therefore loads 19
+// row-pair fragments (x 2 pieces) instead of 8 x 5 = 40, and keeps the column's weight fragments in
+// registers.  Even r only meets even dy and odd r odd dy, so a column is two passes - taps dy = 0, 2, 4
+// against r = 0, 2, .., 18 and taps dy = 1, 3 against r = 1, 3, .., 17 - with 24 and 16 weight registers
+// and a 6 KB weight buffer per wave (3 tap slots, refilled by LDS-DMA for the next pass as soon as the
+// fragments are in registers).  240 LDS reads per stage and wave instead of 450 for the same 600 MFMAs:
+// Sustained (tools/ubench_conv_sustained.hip; the chip sits at its power cap, 1340 W at 1.83 GHz, so a
+// 35 ms burst flatters any change): 0.655-0.660 ms per launch at L = 300 against 0.676 for the tap-by-tap
+// kernel it replaces, 0.628 against 0.648 with two launches in flight.
+//
+// Layouts (one 16-byte load = one MFMA operand):
+//   activations  xs[piece 2][c/8 16][P][P][8] f16
+//   weights      wq[split 4][cgrp 8][dx 5][wave 4][dy: 0 2 4 1 3][piece 2][cg 2][m 32][8] f16
+// Lane -> pixel of a fragment follows the lane groups ds_read_b128 is served in ({0-3,12-15,20-27} and
+// {4-11,16-19,28-31} per half wave): each group reads the 16 consecutive slots of one row = every LDS
+// bank once, whatever the row pitch.
 #pragma once
 #include "common.h"
 #include <cmath>
@@ -32,28 +49,13 @@ typedef _Float16 ch_f16x8 __attribute__((ext_vector_type(8)));
 constexpr int CH_HALO = 20, CH_PITCH = 24;
 constexpr int CH_IN_SLOTS = 2 * 2 * CH_HALO * CH_PITCH;               // 1920 16-byte slots
 constexpr int CH_IN_BYTES = CH_IN_SLOTS * 16;                         // 30720
-constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slots per wave and tap
-#ifndef CH_RING_SLOTS
-#define CH_RING_SLOTS 4      // per-wave weight ring: 4 slots = DMA two taps ahead, 2 slots = one tap
-#endif
-#ifndef CH_OCC
-#define CH_OCC 2             // workgroups per CU the register budget is compiled for
-#endif
-#ifndef CH_MAP_PAIR
-#define CH_MAP_PAIR 1        // 1: each XCD handles two of the four channel splits (see the kernel);
-#endif                       //    same time, fabric reads per launch 361 -> 257 MB (tools/pmc_fetch.sh);
-                             //    one split per XCD (a tile's input read by four XCDs) measured 290 MB
-#ifndef CH_VGPR_CAP
-#define CH_VGPR_CAP          // e.g. __attribute__((amdgpu_waves_per_eu(3, 3))) caps the kernel at 168 VGPRs
-#endif
-// number of workgroups to launch for tiles x tiles pixel tiles
-inline int conv_f16_grid(int tiles) {
-  const int ntiles = tiles * tiles;
-  return CH_MAP_PAIR ? 8 * 2 * ((ntiles + 3) / 4) : (ntiles * 4 + 7) / 8 * 8;
-}
-constexpr int CH_RING = CH_RING_SLOTS;
-constexpr int CH_DIST = CH_RING >= 4 ? 2 : 1;
-constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_RING * CH_WSLOT * 16;   // 63488 (ring 4) / 47104 (ring 2)
+constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slots = 2 KB per wave and tap
+constexpr int CH_WCOL = 5 * CH_WSLOT;                                 // one tap column of one wave in the packed weights
+constexpr int CH_WBUF = 3 * CH_WSLOT;                                 // per-wave LDS weight buffer: 3 tap slots
+constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_WBUF * 16;       // 55296
+// number of workgroups to launch for tiles x tiles pixel tiles: XCD x (block b runs on XCD b % 8) works
+// on the channel splits {0,1} (x even) or {2,3} (x odd) of a contiguous quarter of the tiles
+inline int conv_f16_grid(int tiles) { return 8 * 2 * ((tiles * tiles + 3) / 4); }
 
 __host__ __device__ inline uint16_t ch_f16_bits(float f) {
   const _Float16 h = (_Float16)f;                                     // round to nearest even
@@ -78,22 +80,24 @@ inline float conv_weight_scale_f16(const float* w, size_t n) {
   return std::ldexp(1.0f, 10 - e);      // m * scale in [512, 1024)
 }
 
-// w: [512][128][5][5] float32 -> packed f16 pieces of scale * w
+// w: [512][128][5][5] float32 -> packed f16 pieces of scale * w (layout above)
 inline std::vector<uint16_t> pack_conv_weights_f16(const float* w, float scale) {
+  const int tap_row[5] = {0, 2, 4, 1, 3};              // slot order inside a column: even pass, then odd pass
   std::vector<uint16_t> q((size_t)4 * 8 * 25 * 4 * 2 * 2 * 32 * 8);
   for (int split = 0; split < 4; ++split)
     for (int g = 0; g < 8; ++g)
-      for (int tap = 0; tap < 25; ++tap)
+      for (int dx = 0; dx < 5; ++dx)
         for (int wave = 0; wave < 4; ++wave)
-          for (int cg = 0; cg < 2; ++cg)
-            for (int m = 0; m < 32; ++m)
-              for (int e = 0; e < 8; ++e) {
-                const int oc = split * 128 + wave * 32 + m, ic = g * 16 + cg * 8 + e;
-                uint16_t p2[2];
-                split2_f16(scale * w[((size_t)oc * 128 + ic) * 25 + tap], p2);
-                for (int p = 0; p < 2; ++p)
-                  q[((((((((size_t)split * 8 + g) * 25 + tap) * 4 + wave) * 2 + p) * 2 + cg) * 32 + m) * 8) + e] = p2[p];
-              }
+          for (int sl = 0; sl < 5; ++sl)
+            for (int cg = 0; cg < 2; ++cg)
+              for (int m = 0; m < 32; ++m)
+                for (int e = 0; e < 8; ++e) {
+                  const int oc = split * 128 + wave * 32 + m, ic = g * 16 + cg * 8 + e;
+                  uint16_t p2[2];
+                  split2_f16(scale * w[((size_t)oc * 128 + ic) * 25 + tap_row[sl] * 5 + dx], p2);
+                  for (int p = 0; p < 2; ++p)
+                    q[(((((((((size_t)split * 8 + g) * 5 + dx) * 4 + wave) * 5 + sl) * 2 + p) * 2 + cg) * 32 + m) * 8) + e] = p2[p];
+                }
   return q;
 }
 
@@ -110,16 +114,60 @@ __device__ __forceinline__ ch_f32x16 ch_mfma(uint4 a, uint4 b, ch_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ch_f16x8, a),
                                                 __builtin_bit_cast(ch_f16x8, b), c, 0, 0, 0);
 }
+// lane (0..31 of a half wave) -> (row, column) of the 2 x 16 pixel fragment
+__device__ __forceinline__ void ch_lane_pixel(int li, int& row, int& x) {
+  const bool a = li < 4 || (li >= 12 && li < 16) || (li >= 20 && li < 28);
+  row = a ? 0 : 1;
+  if (a) x = li < 4 ? li : (li < 16 ? li - 8 : li - 12);
+  else x = li < 12 ? li - 4 : (li < 20 ? li - 8 : li - 16);
+}
 
+// One pass of a tap column: NT taps (rows dy = PAR, PAR + 2, ..) whose weight fragments a[t][piece] sit in
+// registers, against the row pairs r = PAR, PAR + 2, .. < 19 read from the halo tile at `il`.
+// Per fragment the small products go first (w0 x1, w1 x0), then w0 x0.
+template <int NT, int PAR>
+__device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const uint4* il, ch_f32x16 (&acc)[8]) {
+  constexpr int PIECE = 2 * CH_HALO * CH_PITCH;
+  uint4 bn0 = il[PAR * CH_PITCH], bn1 = il[PAR * CH_PITCH + PIECE];
+#pragma unroll
+  for (int r = PAR; r < 19; r += 2) {
+    const uint4 b0 = bn0, b1 = bn1;
+    if (r + 2 < 19) {
+      bn0 = il[(r + 2) * CH_PITCH];
+      bn1 = il[(r + 2) * CH_PITCH + PIECE];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int q = (r - PAR - 2 * t) / 2;
+      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b1, acc[q]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int q = (r - PAR - 2 * t) / 2;
+      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][1], b0, acc[q]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int q = (r - PAR - 2 * t) / 2;
+      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b0, acc[q]);
+    }
+  }
+}
+
+// Footprint: the register budget is capped at 168 VGPRs (3 waves per SIMD; the compiler parks the input-tile
+// DMA plan and a few epilogue constants in 68 bytes of scratch, none of it touched inside the tap loops),
+// and 54 KB of LDS let exactly two workgroups share a CU (a third does not fit).  Two of them leave 176
+// registers per SIMD lane and 52 KB of LDS to the kernels of other targets that run beside the convolutions in
+// throughput mode (vertical GRU step 156 registers / 32 KB, norm 108, Gauss-Jordan update 92); uncapped
+// (194 registers) the same kernel cost the scheduler 6 % although it is faster alone.
 // grid: conv_f16_grid(tiles) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
-__global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
                                                                const uint16_t* __restrict__ wq,
                                                                const float* __restrict__ bias, float inv_scale,
                                                                int L, int P, int tiles, int nwork,
                                                                float* __restrict__ u, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
   const int id = blockIdx.x;
-#if CH_MAP_PAIR
   // XCD x works on the channel splits {0,1} (x even) or {2,3} (x odd) only: its share of the weight
   // pieces is 3.3 MB, which fits the 4 MB L2; a tile's input is then read by two XCDs
   const int xcd = id & 7, slot = id >> 3;
@@ -127,12 +175,6 @@ __global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(
   const int tile = (xcd >> 1) * tper + (slot >> 1);
   const int split = 2 * (xcd & 1) + (slot & 1);
   if ((slot >> 1) >= tper || tile >= ntiles) return;
-#else
-  const int per = gridDim.x >> 3;
-  const int work = (id & 7) * per + (id >> 3);
-  if (work >= nwork) return;
-  const int tile = work >> 2, split = work & 3;
-#endif
   const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,9 +182,9 @@ __global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(
   const int64_t PP = (int64_t)P * P;
 
   const uint4* in_l = reinterpret_cast<const uint4*>(ch_smem);
-  const uint4* w_l = reinterpret_cast<const uint4*>(ch_smem + CH_IN_BYTES) + wave * (CH_RING * CH_WSLOT);
+  const uint4* w_l = reinterpret_cast<const uint4*>(ch_smem + CH_IN_BYTES) + wave * CH_WBUF;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ch_smem;
-  const unsigned w_lds_addr = lds_base + CH_IN_BYTES + wave * (CH_RING * CH_WSLOT * 16);
+  const unsigned w_lds_addr = lds_base + CH_IN_BYTES + wave * (CH_WBUF * 16);
 
   // input-tile DMA plan: slot s = e*256 + tid, e = 0..7 (1920 slots = 7.5 x 256)
   const uint4* xs4 = reinterpret_cast<const uint4*>(xs);
@@ -156,25 +198,13 @@ __global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(
     const int yy = r2 / CH_PITCH;
     int xx = r2 % CH_PITCH;
     xx = xx < CH_HALO ? xx : 0;                     // pad slots re-read a valid pixel
-#ifdef CH_EXP_SAMETILE      // traffic experiment only: every workgroup reads the first tile's halo
-    in_src[e] = (int)(((int64_t)(p * 16 + cg) * P + yy) * P + xx);
-#else
     in_src[e] = (int)(((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx);
-#endif
   }
-#ifdef CH_EXP_SAMEW         // traffic experiment only: every workgroup streams the first split's weights
-  const uint4* wq4 = reinterpret_cast<const uint4*>(wq) +
-#else
-  const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 25 * 4 * CH_WSLOT +
-#endif
-                     (int64_t)wave * CH_WSLOT + lane;
-
-  int b_off[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int y = (q >> 1) * 4 + (li >> 3), x = (q & 1) * 8 + (li & 7);
-    b_off[q] = (kk * CH_HALO + y) * CH_PITCH + x;
-  }
+  const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 5 * 4 * CH_WCOL +
+                     (int64_t)wave * CH_WCOL + lane;
+  int prow, px;
+  ch_lane_pixel(li, prow, px);
+  const int b_base = (kk * CH_HALO + prow) * CH_PITCH + px;      // + r * CH_PITCH + dx (+ piece stride)
   const int a_off = kk * 32 + li;
 
   ch_f32x16 acc[8];
@@ -183,13 +213,19 @@ __global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-  auto wdma = [&](int g, int tap) {
-    const uint4* src = wq4 + ((int64_t)g * 25 + tap) * 4 * CH_WSLOT;
-    const unsigned dst = w_lds_addr + (tap & (CH_RING - 1)) * (CH_WSLOT * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier LDS reads of the slot are complete
-    ch_dma16(src, dst);
-    ch_dma16(src + 64, dst + 1024);
+  // pass h = 2 * (g * 5 + dx) + odd: stream its 3 (even) or 2 (odd) tap slots into this wave's buffer
+  auto wdma = [&](int h) {
+    const int odd = h & 1;
+    const uint4* src = wq4 + (int64_t)(h >> 1) * 4 * CH_WCOL + odd * 3 * CH_WSLOT;
+    if (odd) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ch_dma16(src + 64 * i, w_lds_addr + 1024 * i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ch_dma16(src + 64 * i, w_lds_addr + 1024 * i);
+    }
   };
+  wdma(0);
 
   for (int g = 0; g < 8; ++g) {
     __syncthreads();                                   // every wave is done with the previous tile
@@ -200,37 +236,35 @@ __global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(
       for (int e = 0; e < 7; ++e) ch_dma16(src + in_src[e], dst + e * 4096);
       if (wave < 2) ch_dma16(src + in_src[7], dst + 7 * 4096);
     }
-    wdma(g, 0);
-    if (CH_DIST == 2) wdma(g, 1);
     ch_wait_vm<0>();
     __syncthreads();                                   // the tile of every wave has landed
 #pragma unroll 1
-    for (int dy = 0; dy < 5; ++dy) {
+    for (int dx = 0; dx < 5; ++dx) {
+      const uint4* il = in_l + b_base + dx;
+      const int h0 = 2 * (g * 5 + dx);
+      {
+        ch_wait_vm<0>();                               // this pass's weights (issued one pass ago)
+        uint4 a[3][2];
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        const int tap = dy * 5 + dx;
-        // weights two taps ahead; this tap's two pieces must have landed (2 instructions per tap)
-        if (tap + CH_DIST < 25) { wdma(g, tap + CH_DIST); ch_wait_vm<2 * CH_DIST>(); }
-        else if (CH_DIST == 2 && tap + 1 < 25) ch_wait_vm<2>();
-        else ch_wait_vm<0>();
-        const uint4* wl = w_l + (tap & (CH_RING - 1)) * CH_WSLOT + a_off;
-        const uint4 a0 = wl[0], a1 = wl[64];
-        const uint4* il = in_l + dy * CH_PITCH + dx;
-#pragma unroll
-        for (int qp = 0; qp < 4; ++qp) {
-          uint4 b[2][2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) b[h][p] = il[p * (2 * CH_HALO * CH_PITCH) + b_off[2 * qp + h]];
-          // small terms first; the two accumulators alternate
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = ch_mfma(a0, b[h][1], acc[2 * qp + h]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = ch_mfma(a1, b[h][0], acc[2 * qp + h]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = ch_mfma(a0, b[h][0], acc[2 * qp + h]);
+        for (int t = 0; t < 3; ++t) {
+          a[t][0] = w_l[t * CH_WSLOT + a_off];
+          a[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wdma(h0 + 1);                                  // the buffer is free: stream the next pass
+        ch_column_pass<3, 0>(a, il, acc);
+      }
+      {
+        ch_wait_vm<0>();
+        uint4 a[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[t][0] = w_l[t * CH_WSLOT + a_off];
+          a[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h0 + 2 < 80) wdma(h0 + 2);
+        ch_column_pass<2, 1>(a, il, acc);
       }
     }
   }
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(256, CH_OCC) CH_VGPR_CAP void conv5x5_f16x3_kernel(
       v = fmaxf(v, acc[q][4 * g4 + 1] * inv_scale + b1);
       v = fmaxf(v, acc[q][4 * g4 + 2] * inv_scale + b2);
       v = fmaxf(v, acc[q][4 * g4 + 3] * inv_scale + b3);
-      const int y = ty0 + (q >> 1) * 4 + (li >> 3), x = tx0 + (q & 1) * 8 + (li & 7);
+      const int y = ty0 + 2 * q + prow, x = tx0 + px;
       if (y < L && x < L) {
         u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
         s1 += v;

@@ -232,10 +232,14 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
   }
 }
 
-// stats[c] = sum over partials, in a fixed order
+// stats[c] = sum over partials, in a fixed order; with `ab` also the InstanceNorm coefficients of the
+// channel (the arithmetic of norm_coeff_kernel below), which saves the trunk a dependent launch per block
 // grid: 128 channels, block: 64 (one wave); lane l sums partials l, l+64, ... then a fixed tree
 __global__ __launch_bounds__(64) void stats_reduce_kernel(const double* __restrict__ part, int nparts,
-                                                          double* __restrict__ stats) {
+                                                          double* __restrict__ stats, double count,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ ab) {
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int t = threadIdx.x; t < nparts; t += 64) {
@@ -249,6 +253,15 @@ __global__ __launch_bounds__(64) void stats_reduce_kernel(const double* __restri
   if (threadIdx.x == 0) {
     stats[c * 2 + 0] = s1;
     stats[c * 2 + 1] = s2;
+    if (ab) {
+      const double mean = s1 / count;
+      double var = s2 / count - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      const float invstd = (float)(1.0 / sqrt(var + 1e-5));
+      const float alpha = invstd * gamma[c];
+      ab[c * 2 + 0] = alpha;
+      ab[c * 2 + 1] = beta[c] - (float)mean * alpha;
+    }
   }
 }
 
@@ -287,9 +300,7 @@ int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L
   hipLaunchKernelGGL(channel_stats_kernel, dim3(CW, STAT_SLICES), dim3(256), 0, s, c->u, LL,
                      c->part);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, STAT_SLICES, c->stats);
-  DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, c->stats, (double)LL,
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, STAT_SLICES, c->stats, (double)LL,
                      W.stem_gamma, W.stem_beta, c->ab);
   DMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(stem_norm_kernel, dim3(cdiv(L, 256), L, CW), dim3(256), 0, s, c->u, c->ab, L,
@@ -315,19 +326,13 @@ constexpr int IN_PITCH = 24;              // row pitch in LDS: 4 rows x 8 column
 constexpr int NTAP = 25;
 constexpr int MCH = 128;                  // conv channels per workgroup
 constexpr int NCHUNK = CW / CONV_CC;      // 64
-// Measured at L = 300 (tools/ubench_conv.hip, ms per launch): 0: 2.50, 1: 2.36, 65: 2.26,
-// 193: 2.25; tap-ahead / group-barrier / b128-fragment variants were neutral or slower.  Floors:
-// no staging 2.18, MFMA only 2.09.
-#ifndef CONV_VARIANT
-#define CONV_VARIANT 65
-#endif
+// 2.26 ms per launch at L = 300 (floors: no staging 2.18, MFMA only 2.09).  The scheduling variants that
+// were measured against this one (branchy / register-staged weight prefetch 2.50 / 2.36, LDS-DMA input
+// image 2.25, tap-ahead fragment reads, sched_group_barrier pinning, b128 weight fragments: neutral or
+// slower) live in the history of this file and in tools/ubench_conv.hip.
 constexpr int W_STAGE = NTAP * CONV_CC * MCH;          // 6400 floats
 constexpr int IN_STAGE = CONV_CC * HALO * IN_PITCH;    // 960 floats
 
-// V: scheduling variant bits (tools/ubench_conv.hip measures them): 1 = branch-free prefetch,
-// 2 = LDS fragments of tap t+1 read before the MFMAs of tap t, 4 = pin that order with
-// sched_group_barrier.
-template <int V>
 __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __restrict__ xpad,
                                                                 const float* __restrict__ wpack,
                                                                 const float* __restrict__ bias, int L,
@@ -338,8 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
   __shared__ __attribute__((aligned(16))) float smem[2 * W_STAGE + 2 * IN_STAGE];
   float (*w_lds)[W_STAGE] = reinterpret_cast<float (*)[W_STAGE]>(smem);
   float (*in_lds)[IN_STAGE] = reinterpret_cast<float (*)[IN_STAGE]>(smem + 2 * W_STAGE);
-  // LDS row pitch of the input tile: 24 (bank-conflict free) or 20 (linear image for LDS-DMA)
-  constexpr int IP = (V & 128) ? HALO : IN_PITCH;
+  constexpr int IP = IN_PITCH;       // LDS row pitch of the input tile (bank-conflict free)
   // XCD-aware remap: block b runs on XCD b % 8; give each XCD a contiguous range of work items
   // so the 4 channel splits of a tile and neighbouring tiles share one L2.
   const int id = blockIdx.x;
@@ -369,63 +373,27 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
     in_off[e] = (int)(cc * PP + (int64_t)(ty0 + yy) * P + tx0 + xx);
     in_dst[e] = cc * HALO * IP + yy * IP + xx;
   }
-  const int w_last = (tid + 6 * 256 < W_STAGE / 4) ? tid + 6 * 256 : W_STAGE / 4 - 1;
-  float4 wreg[7];
   float ireg[4];
+  // weight slab of the next stage by LDS-DMA (25 wave-instructions of 1 KB, lane-linear destination); the
+  // input halo tile through registers
   auto prefetch = [&](int chunk) {
     const float4* ws = wsrc + (int64_t)chunk * (W_STAGE / 4);
     const float* xs = xpad + (int64_t)chunk * CONV_CC * PP;
-    if constexpr (V & 64) {
-      // weight slab by LDS-DMA: 25 wave-instructions of 1 KB (lane-linear destination)
-      typedef __attribute__((address_space(1))) const void* gptr_t;
-      typedef __attribute__((address_space(3))) void* lptr_t;
-      float* dst = w_lds[(chunk & 1)] + (size_t)wave * 256;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    float* dst = w_lds[(chunk & 1)] + (size_t)wave * 256;
 #pragma unroll
-      for (int e = 0; e < 6; ++e)
-        __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + e * 256), (lptr_t)(dst + e * 1024), 16, 0, 0);
-      if (wave == 0)
-        __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + 6 * 256), (lptr_t)(dst + 6 * 1024), 16, 0, 0);
-      if constexpr (V & 128) {
-        // input halo tile as a linear [2][20][20] image: 12.5 wave-instructions of 256 B
-        float* idst = in_lds[(chunk & 1)] + wave * 64;
+    for (int e = 0; e < 6; ++e)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + e * 256), (lptr_t)(dst + e * 1024), 16, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + 6 * 256), (lptr_t)(dst + 6 * 1024), 16, 0, 0);
 #pragma unroll
-        for (int e = 0; e < 3; ++e)
-          __builtin_amdgcn_global_load_lds((gptr_t)(xs + in_off[e]), (lptr_t)(idst + e * 256), 4, 0, 0);
-        if (wave == 0)
-          __builtin_amdgcn_global_load_lds((gptr_t)(xs + in_off[3]), (lptr_t)(idst + 768), 4, 0, 0);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ireg[e] = xs[in_off[e]];
-      }
-    } else if constexpr (V & 1) {
-#pragma unroll
-      for (int e = 0; e < 6; ++e) wreg[e] = ws[tid + e * 256];
-      wreg[6] = ws[w_last];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ireg[e] = xs[in_off[e]];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 7; ++e) {
-        const int idx = tid + e * 256;
-        if (idx < W_STAGE / 4) wreg[e] = ws[idx];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (in_ok[e]) ireg[e] = xs[in_off[e]];
-    }
+    for (int e = 0; e < 4; ++e) ireg[e] = xs[in_off[e]];
   };
   auto commit = [&](int buf) {
-    if constexpr (!(V & 64)) {
-      float4* wd = reinterpret_cast<float4*>(w_lds[buf]);
 #pragma unroll
-      for (int e = 0; e < 6; ++e) wd[tid + e * 256] = wreg[e];
-      if (tid + 6 * 256 < W_STAGE / 4) wd[tid + 6 * 256] = wreg[6];
-    }
-    if constexpr (!(V & 128)) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (in_ok[e]) in_lds[buf][in_dst[e]] = ireg[e];
-    }
+    for (int e = 0; e < 4; ++e)
+      if (in_ok[e]) in_lds[buf][in_dst[e]] = ireg[e];
   };
 
   // fragment addresses
@@ -451,73 +419,25 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
   __syncthreads();
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
     const int buf = chunk & 1;
-    if (!(V & 32) && chunk + 1 < NCHUNK) prefetch(chunk + 1);
+    if (chunk + 1 < NCHUNK) prefetch(chunk + 1);
     const float* wl = w_lds[buf] + a_off;
     const float* il = in_lds[buf];
-    // Fragments of tap t+1 are read from LDS before the 8 MFMAs of tap t are issued (hipcc on its
-    // own waits lgkmcnt(0) in front of every MFMA group and exposes the LDS latency 25 times per
-    // stage); the group barriers pin "6 LDS reads, then 8 MFMAs" per tap.
-    if constexpr (V & 2) {
-      float a[2][4], b[2][2];
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) a[0][mb] = wl[mb * 32];
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int dy = tap / 5, dx = tap % 5;
+      float a[4], b[2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) b[0][q] = il[b_off[q]];
+      for (int mb = 0; mb < 4; ++mb) a[mb] = wl[tap * CONV_CC * MCH + mb * 32];
 #pragma unroll
-      for (int tap = 0; tap < NTAP; ++tap) {
-        const int cur = tap & 1, nxt = cur ^ 1;
-        if (tap + 1 < NTAP) {
-          const int dy = (tap + 1) / 5, dx = (tap + 1) % 5;
+      for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * IP + dx];
 #pragma unroll
-          for (int mb = 0; mb < 4; ++mb) a[nxt][mb] = wl[(tap + 1) * CONV_CC * MCH + mb * 32];
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-          for (int q = 0; q < 2; ++q) b[nxt][q] = il[b_off[q] + dy * IP + dx];
-        }
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mb], b[cur][q], acc[mb][q], 0, 0, 0);
-        if constexpr (V & 4) {
-          if (tap + 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // DS reads of tap+1
-          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                       // MFMAs of tap
-        }
-      }
-    } else if constexpr (V & 8) {
-      // weights packed so a lane's four channel-block operands are one 16-byte LDS read
-      const float* wl4 = w_lds[buf] + kk * MCH + li * 4;
-#pragma unroll
-      for (int tap = 0; tap < NTAP; ++tap) {
-        const int dy = tap / 5, dx = tap % 5;
-        const float4 av = *reinterpret_cast<const float4*>(wl4 + tap * CONV_CC * MCH);
-        const float a[4] = {av.x, av.y, av.z, av.w};
-        float b[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * IP + dx];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int tap = 0; tap < NTAP; ++tap) {
-        const int dy = tap / 5, dx = tap % 5;
-        float a[4], b[2];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) a[mb] = wl[tap * CONV_CC * MCH + mb * 32];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * IP + dx];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
-      }
+        for (int q = 0; q < 2; ++q)
+          acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
     }
-    if (!(V & 32) && chunk + 1 < NCHUNK) commit(buf ^ 1);
-    if (!(V & 16)) __syncthreads();
+    if (chunk + 1 < NCHUNK) commit(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- epilogue: bias, 4-way max, store, per-channel partial sums
@@ -566,9 +486,19 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
   }
 }
 
-int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s) {
+// block = 0: statistics only (stage-level API); block = k: also block k's InstanceNorm coefficients into
+// c->ab, which norm_scse_residual_padded then finds ready (c->ab_current)
+int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s, int block) {
   const int tiles = act_tiles(L);
-  hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, tiles * tiles, d_stats);
+  if (block > 0) {
+    const BlockW& B = c->W.blk[block - 1];
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, tiles * tiles, d_stats,
+                       (double)L * (double)L, B.gamma, B.beta, c->ab);
+    c->ab_current = true;
+  } else {
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, tiles * tiles, d_stats, 1.0,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  }
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
@@ -604,16 +534,12 @@ int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s) {
 // launches of the same kernel in flight corrupted those launches (first target of a fresh scheduler,
 // about one run in three).
 int trunk_kernel_attrs(dmp_ctx* c) {
-  // tuning experiment: DMP_CONV_LDS=<bytes> requests more LDS than the kernel uses (> 80 KB leaves
-  // one convolution workgroup per CU and room for other kernels beside it)
-  const char* env = getenv("DMP_CONV_LDS");
-  c->conv_lds = env ? std::max(atoi(env), (int)CONVH_LDS_BYTES) : (int)CONVH_LDS_BYTES;
   static bool done[64] = {};
   if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
   DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               CONVQ_LDS_BYTES));
   DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              c->conv_lds));
+                              CONVH_LDS_BYTES));
   if (c->device >= 0 && c->device < 64) done[c->device] = true;
   return DMP_OK;
 }
@@ -634,12 +560,12 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
       hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(grid), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
                          B.bias, L, P, tiles, nwork, d_u, c->part);
     else
-      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), c->conv_lds, s, c->xsplit, B.wh,
+      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,
                          B.bias, B.wh_inv_scale, L, P, tiles, nwork, d_u, c->part);
     DMP_LAUNCH_CHECK();
     return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
   }
-  hipLaunchKernelGGL(conv5x5_maxout_kernel<CONV_VARIANT>, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
+  hipLaunchKernelGGL(conv5x5_maxout_kernel, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
                      P, tiles, nwork, d_u, c->part);
   DMP_LAUNCH_CHECK();
   return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
@@ -708,9 +634,12 @@ int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const dou
                               const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s) {
   const BlockW& B = c->W.blk[block - 1];
   const int P = act_pitch(L);
-  hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, d_stats, (double)L * (double)L,
-                     B.gamma, B.beta, c->ab);
-  DMP_LAUNCH_CHECK();
+  if (!c->ab_current) {
+    hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, d_stats, (double)L * (double)L,
+                       B.gamma, B.beta, c->ab);
+    DMP_LAUNCH_CHECK();
+  }
+  c->ab_current = false;
   // inside a trunk pass the kernel also emits the pieces the next convolution reads
   const int split = (c->conv_mode != 1 && c->xsplit_current) ? c->conv_mode : -1;
   dim3 grid(cdiv(L, 128), L);

@@ -41,11 +41,17 @@ def small_engine(synth_sd):
 
 
 def _check_passes(eng, g, P, L, tol):
+    """Every pass's confidence mean and CA trace.  Recycling is expansive over its first passes before
+    it settles: the reference's own 8-vs-1-thread runs differ by up to 7e-4 A at pass 5 of the example
+    although the final structure (the best pass, usually an early one) agrees to 2e-4.  Bound per pass:
+    max(tol, 3 x that pass's floor stored in the fixture), SURVEY 8c(vi)."""
     means = eng.fetch("conf_means", P).cpu().numpy()
     assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
     ca_pass = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
-    worst = max(ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P))
-    assert worst <= tol, worst
+    floor = g["noise_ca_pass"] if "noise_ca_pass" in g else np.full(P, float(g["noise_ca_rmsd"]))
+    dev = np.array([ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P)])
+    assert (dev <= np.maximum(tol, 3.0 * floor)).all(), (dev, floor)
+    return dev
 
 
 # ------------------------------------------------------------------ the benchmark's recycling depth
@@ -105,7 +111,8 @@ def test_minimiser_end_to_end_on_protein_like_traces(synth_sd, name, mode):
     """minsteps=100 (the CLI default, 2 x 100 steps) end to end.  With random weights the first trace
     is a collapsed tangle on which the reference's minimiser is chaotic (0.12 A between its own 8- and
     1-thread runs); these fixtures use synthetic weights whose coord_fc was fitted so that the first
-    trace approximates 3FGX chain A (make_goldens.fit_coord_fc), where the noise floor is 2-4e-4 A."""
+    trace approximates 3FGX chain A (make_goldens.fit_coord_fc), where the reference's spread over 1, 2,
+    3, 5 and 8 threads is 2.9e-4 A (n=0) and 4.8e-4 A (n=10): 250 times tighter."""
     g = load_golden(name)
     sd = dict(synth_sd)
     sd["coord_fc.weight"] = g["coord_fc"]
@@ -119,7 +126,7 @@ def test_minimiser_end_to_end_on_protein_like_traces(synth_sd, name, mode):
         eng.sync_check()
         coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
         tol = max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
-        assert tol <= 1.1e-3                                   # the floor of these fixtures is small
+        assert tol <= 1.5e-3                                   # the floor of these fixtures is small
         assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= tol
         assert np.abs(confs - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
         means = eng.fetch("conf_means", n + 1).cpu().numpy()
@@ -135,10 +142,13 @@ def test_minimiser_end_to_end_on_protein_like_traces(synth_sd, name, mode):
 # ------------------------------------------------------------------ device faults at the boundary
 def _hot_weights(synth_sd):
     """Synthetic weights whose block-6 InstanceNorm scales its output by 4e4: the residual stream
-    leaves the f16 range (|x| >= 6e4) from block 7 on.  Everything stays finite in float32."""
+    leaves the f16 range (|x| up to 4e5) from block 7 on.  The head weights are scaled back by the same
+    factor, so the distance map stays O(10) and the problem well conditioned (without that the
+    REFERENCE differs from itself by 0.4-36 A between 8 and 1 threads; with it by 1e-5..8e-5 A)."""
     sd = dict(synth_sd)
     sd["resnet.6.layer1.norm.weight"] = (sd["resnet.6.layer1.norm.weight"] * 4e4).astype(np.float32)
     sd["resnet.6.layer1.norm.bias"] = (sd["resnet.6.layer1.norm.bias"] * 4e4).astype(np.float32)
+    sd["resnet.17.weight"] = (sd["resnet.17.weight"] / 4e4).astype(np.float32)
     return sd
 
 
