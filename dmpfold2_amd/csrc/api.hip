@@ -170,11 +170,25 @@ static int pack_weights(dmp_ctx* c) {
         GruDirW& g = dst[l][d];
         g.nin = nin;
         int r;
-        if ((r = upload(pool, bytes, &g.wihT, transposed(H[p + ".weight_ih_l" + sfx], 768, nin)))) return r;
         if ((r = upload(pool, bytes, &g.whh, H[p + ".weight_hh_l" + sfx]))) return r;
-        if ((r = upload(pool, bytes, &g.bih, H[p + ".bias_ih_l" + sfx]))) return r;
         if ((r = upload(pool, bytes, &g.bhh, H[p + ".bias_hh_l" + sfx]))) return r;
       }
+    for (int l = 0; l < layers; ++l) {
+      const int nin = l == 0 ? nin0 : 512;
+      const std::string a = p + ".weight_ih_l" + std::to_string(l), b = p + ".bias_ih_l" + std::to_string(l);
+      const auto& wf = H[a];
+      const auto& wr = H[a + "_reverse"];
+      std::vector<float> both((size_t)nin * 1536), bias(1536);
+      for (int k = 0; k < nin; ++k)
+        for (int j = 0; j < 768; ++j) {
+          both[(size_t)k * 1536 + j] = wf[(size_t)j * nin + k];
+          both[(size_t)k * 1536 + 768 + j] = wr[(size_t)j * nin + k];
+        }
+      for (int j = 0; j < 768; ++j) { bias[j] = H[b][j]; bias[768 + j] = H[b + "_reverse"][j]; }
+      int r;
+      if ((r = upload(pool, bytes, &dst[l][0].wihT_both, both))) return r;
+      if ((r = upload(pool, bytes, &dst[l][0].bih_both, bias))) return r;
+    }
     return DMP_OK;
   };
   if ((rc = seq("hgru", 2, 512, W.hgru))) return rc;
@@ -280,8 +294,8 @@ static int trunk_block(dmp_ctx* c, int k, int L, hipStream_t s) {
     // The lane admits two convolutions at a time: a launch waits for the one before the previous one,
     // so the tail of one launch (1444 workgroups on 512 slots at L = 300, fewer at smaller L) fills with
     // the head of the next.  Measured (tools/lane_trace.py, structures/s at depth 1 / 2 / 3 / 4):
-    // L = 300: 6.72 / 7.00 / 6.88 / 6.74; L = 200: 12.7 / 13.8-14.1 / 13.8 / 13.4; L = 128: 26.0 / 28.7 / 28.5.
-    // DMP_LANE_DEPTH overrides.
+    // L = 300: 6.72 / 7.00 / 6.88 / 6.74; L = 200: 12.7 / 13.8-14.1 / 13.8 / 13.4; L = 128: 26.0 / 28.7 / 28.5
+    // (round 2, row-reuse convolution: 6.66 / 6.93 / 6.79 at L = 300).  DMP_LANE_DEPTH overrides (tools/lane_trace.py).
     static const int depth = getenv("DMP_LANE_DEPTH") ? std::max(1, atoi(getenv("DMP_LANE_DEPTH"))) : 2;
     if (c->lane && c->lane->count >= depth)
       DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->lane->ev[(c->lane->count - depth) % dmp_lane::RING], 0));

@@ -51,11 +51,13 @@ inline int act_tiles(int L) { return cdiv(L, CONV_TILE); }
 inline int act_pitch(int L) { return act_tiles(L) * CONV_TILE + 4; }
 
 struct GruDirW {          // one direction of one layer of a sequence GRU
-  float* wihT = nullptr;  // [nin][3H]  (transposed, gate-major columns r|z|n)
   float* whh = nullptr;   // [3H][H]    row-major as in the state_dict
-  float* bih = nullptr;   // [3H]
   float* bhh = nullptr;   // [3H]
   int nin = 0;
+  // forward direction only: both directions' input weights side by side, [nin][2 x 3H] and [2 x 3H], so
+  // that one GEMM launch (twice the workgroups) projects the inputs of both
+  float* wihT_both = nullptr;
+  float* bih_both = nullptr;
 };
 
 struct BlockW {

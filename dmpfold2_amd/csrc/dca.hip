@@ -204,31 +204,15 @@ typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
 // 224 us for the two updates this replaces).  Knobs that measured the same or worse: deeper source-level
 // prefetch (the compiler schedules the loads itself; pinning them with scheduling barriers: 150-240
 // us), register budgets for 3-5 waves per SIMD (165 us), reading the tile before the MFMA chain
-// (GJT_PRELOAD: 168 us).  A CU pulls 64 KB of panel per wave and tile from L2; sharing the panels
+// (168 us).  A CU pulls 64 KB of panel per wave and tile from L2; sharing the panels
 // through LDS is the next step.
-#ifndef GJT_PF
-#define GJT_PF 1        // k octets of operand loads in flight ahead of the MFMAs
-#endif
-#ifndef GJT_OCC
-#define GJT_OCC 2       // waves per SIMD the register budget is compiled for
-#endif
-#ifndef GJT_SCHED
-#define GJT_SCHED 0     // 1: pin the load / MFMA order with scheduling barriers
-#endif
-#ifndef GJT_SYM
-#define GJT_SYM 1       // 1: only tiles on / below the diagonal, mirrored as signed transposes
-#endif
-#ifndef GJT_PRELOAD
-#define GJT_PRELOAD 0   // 1: accumulators start at -A (tile read before the MFMA chain), 0: read-modify-write after it
-#endif
 // grid: (Dp/128)^2 blocks, row-block major   block: 256
-__global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __restrict__ A, int D, int Dp, int k0,
+__global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__ A, int D, int Dp, int k0,
                                                                    const float4* __restrict__ CT,
                                                                    const float4* __restrict__ RT) {
   const int nt = Dp >> 7;
   const int tm = blockIdx.x / nt, tn = blockIdx.x % nt, kb = k0 >> 7;
   if (tm == kb) return;
-#if GJT_SYM
   // Gauss-Jordan on a symmetric matrix keeps M_ij = t_i t_j M_ji^T with t = -1 for processed blocks
   // (including this step's) and +1 otherwise, so outside block row / column k only the tiles on and
   // below the diagonal are computed and each is also stored as its signed transpose.
@@ -236,14 +220,13 @@ __global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __rest
   const bool mirror = (tn != kb && tn < tm);
   const float msign = ((tm < kb) != (tn < kb)) ? -1.f : 1.f;
   __shared__ float tr[4][32][33];
-#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 5, li = lane & 31;
   const int m0 = tm * 128 + (wave >> 1) * 64, n0 = tn * 128 + (wave & 1) * 64;
   const bool blockcol = (tn == kb);
   const float4* cp = CT + (int64_t)kk * Dp + m0 + li;
   const float4* rp = RT + (int64_t)kk * Dp + n0 + li;
-  constexpr int PF = GJT_PF;
+  constexpr int PF = 1;      // k octets of operand loads in flight ahead of the MFMAs
   float4 av[2][PF][2], bv[2][PF][2];
   auto load = [&](int buf, int c) {
 #pragma unroll
@@ -259,20 +242,12 @@ __global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __rest
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + 32 * ni + li;
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
-        acc[mi][ni][r] = (GJT_PRELOAD && !blockcol && row < D && col < D) ? -A[(int64_t)row * D + col] : 0.f;
-      }
-    }
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 #pragma unroll
   for (int c = 0; c < 16 / PF; ++c) {
     if (c + 1 < 16 / PF) load((c + 1) & 1, c + 1);
-#if GJT_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int u = 0; u < PF; ++u)
 #pragma unroll
@@ -288,9 +263,6 @@ __global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __rest
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[mi][ni], 0, 0, 0);
         }
       }
-#if GJT_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -303,14 +275,11 @@ __global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __rest
         float v = 0.f;
         if (row < D && col < D) {
           float* p = A + (int64_t)row * D + col;
-          v = GJT_PRELOAD ? -acc[mi][ni][r] : (blockcol ? 0.f : *p) - acc[mi][ni][r];
+          v = (blockcol ? 0.f : *p) - acc[mi][ni][r];
           *p = v;
         }
-#if GJT_SYM
         if (mirror) tr[wave][li][8 * (r >> 2) + 4 * kk + (r & 3)] = msign * v;     // [column][row]
-#endif
       }
-#if GJT_SYM
       if (mirror) {
         // the wave's 32 x 32 block, transposed through LDS: lanes run along the new rows' columns
         __builtin_amdgcn_wave_barrier();
@@ -323,7 +292,6 @@ __global__ __launch_bounds__(256, GJT_OCC) void gj_trailing_kernel(float* __rest
         }
         __builtin_amdgcn_wave_barrier();
       }
-#endif
     }
 }
 

@@ -139,13 +139,14 @@ int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hip
   const float* in = d_in;
   for (int l = 0; l < layers; ++l) {
     const GruDirW* w = which == 0 ? c->W.hgru[l] : c->W.cgru[l];
-    for (int dir = 0; dir < 2; ++dir) {
+    {
+      // input projections of both directions in one launch: G[t][dir 2][3H] = in[t] W_ih^T + b_ih
       GemmArgs g{};
-      g.A = in; g.sam = w[dir].nin; g.sak = 1;
-      g.B = w[dir].wihT; g.sbk = 768; g.sbn = 1;
-      g.C = c->seq_g + dir * 768; g.ldc = 1536;
-      g.M = T; g.N = 768; g.K = w[dir].nin;
-      g.alpha = 1.f; g.beta = 0.f; g.bias_n = w[dir].bih;
+      g.A = in; g.sam = w[0].nin; g.sak = 1;
+      g.B = w[0].wihT_both; g.sbk = 1536; g.sbn = 1;
+      g.C = c->seq_g; g.ldc = 1536;
+      g.M = T; g.N = 1536; g.K = w[0].nin;
+      g.alpha = 1.f; g.beta = 0.f; g.bias_n = w[0].bih_both;
       int rc = gemm_f32(g, s);
       if (rc) return rc;
     }

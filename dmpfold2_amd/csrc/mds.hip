@@ -481,7 +481,6 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   if (wave == 0) {
     for (int iter = 0; iter < 5; ++iter) {
       if (lane < NEV) {
-        const double tiny = eps * fmax(tnorm, 1e-300);
         // forward substitution with the recorded interchanges.  The factors live in global memory
         // (L2): they are fetched eight steps at a time ahead of the recurrence, which only touches LDS.
         double yk = x[lane];

@@ -31,13 +31,6 @@
 
 namespace dmp {
 
-#ifndef VG_CH
-#define VG_CH 1      // MFMA steps per load chunk (double-buffered)
-#endif
-#ifndef VG_OCC
-#define VG_OCC 4     // waves per SIMD the register budget is compiled for (4 = 128 VGPRs: two step
-                     // workgroups per CU, or one beside a convolution workgroup)
-#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 vg_f16x8 __attribute__((ext_vector_type(8)));
 
@@ -65,11 +58,7 @@ struct VRun {
 };
 
 
-#ifndef VG_NSUB_N
-#define VG_NSUB_N 1
-#endif
-constexpr int VG_NSUB = VG_NSUB_N;     // 32-column subtiles per wave: the weight operands are reused VG_NSUB times
-constexpr int VG_TB = 32 * VG_NSUB;    // columns per tile
+constexpr int VG_TB = 32;              // columns per tile
 
 
 // One wave's quarter of a K = 512 contraction: MFMA steps s = w, w+4, ..., w+28 (16 k each), three
@@ -78,9 +67,11 @@ constexpr int VG_TB = 32 * VG_NSUB;    // columns per tile
 // Measured at L = 300 (240 workgroups, 12.3 us per step): the same kernel without MFMAs takes as
 // long; with all loads redirected to one cache line 7.6 us.  A CU sustains about 50 GB/s of L1
 // misses here whatever the request pattern (rotating the k order per workgroup changes nothing), so
-// the step time follows the bytes one CU has to pull: 64-column tiles (VG_NSUB_N = 2: weights
-// reused from registers, 0.6x the total L2 traffic, but half as many workgroups pulling 1.25x the
-// bytes each) run 18 us per step.
+// the step time follows the bytes one CU has to pull.  64-column tiles (weight operands used for two
+// column subtiles from registers: 0.6x the total L2 traffic, half as many workgroups pulling 1.25x the
+// bytes each, 246 VGPRs) were built and measured in round 2, bit-identical and slower everywhere: alone
+// 31.9 against 26.3 ms at L = 300, N = 2000, two targets side by side 43.5 against 34.5 ms, four 119
+// against 115 ms, and 3 % less throughput in the scheduler.
 __device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const uint4* __restrict__ xp, int Lb,
                                            int w, int kk, f32x16& ar, f32x16& az, f32x16& at) {
   // Two operand sets (6 weight + 2 state loads of 16 bytes each) alternate: the loads of step c+1

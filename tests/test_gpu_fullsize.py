@@ -217,7 +217,7 @@ def test_eigensolver_at_the_largest_order(synth_sd):
     st = Stages(synth_sd, max_L=1280, max_N=4)
     try:
         rng = np.random.default_rng(17)
-        for L in (1280, 1000):
+        for L in (1280, 1000, 640, 513):      # 640 and 513: the cluster tridiagonalisation with its largest LDS image
             P = np.cumsum(rng.standard_normal((L, 3)) * 2.2, axis=0)
             D = np.linalg.norm(P[:, None] - P[None], axis=2) + np.abs(rng.standard_normal((L, L))) * 0.3
             D = 0.5 * (D + D.T)
