@@ -154,8 +154,9 @@ __device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const ui
   }
 }
 
-// Footprint: the register budget is capped at 168 VGPRs (3 waves per SIMD; the compiler parks the input-tile
-// DMA plan and a few epilogue constants in 68 bytes of scratch, none of it touched inside the tap loops),
+// Footprint: the register budget is capped at 168 VGPRs (3 waves per SIMD; the input-tile DMA plan is
+// recomputed per stage instead of living in registers - kept there, the cap parked it and some epilogue
+// constants in 68 bytes of scratch per lane, 25 MB of extra writes per launch in WRITE_SIZE; 8 bytes remain),
 // and 54 KB of LDS let exactly two workgroups share a CU (a third does not fit).  Two of them leave 176
 // registers per SIMD lane and 52 KB of LDS to the kernels of other targets that run beside the convolutions in
 // throughput mode (vertical GRU step 156 registers / 32 KB, norm 108, Gauss-Jordan update 92); uncapped
@@ -186,20 +187,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ch_smem;
   const unsigned w_lds_addr = lds_base + CH_IN_BYTES + wave * (CH_WBUF * 16);
 
-  // input-tile DMA plan: slot s = e*256 + tid, e = 0..7 (1920 slots = 7.5 x 256)
+  // input-tile DMA plan: slot s = e*256 + tid, e = 0..7 (1920 slots = 7.5 x 256); recomputed at every stage
+  // (a few dozen integer operations, 8 times per workgroup) rather than kept in registers across the tap loops
   const uint4* xs4 = reinterpret_cast<const uint4*>(xs);
-  int in_src[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int s = e * 256 + tid;
+  auto in_src = [&](int e, int t) {
+    const int s = e * 256 + t;
     const int sc = s < CH_IN_SLOTS ? s : 0;
     const int p = sc / 960, r = sc % 960;
     const int cg = r / 480, r2 = r % 480;
     const int yy = r2 / CH_PITCH;
     int xx = r2 % CH_PITCH;
     xx = xx < CH_HALO ? xx : 0;                     // pad slots re-read a valid pixel
-    in_src[e] = (int)(((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx);
-  }
+    return (int)(((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx);
+  };
   const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 5 * 4 * CH_WCOL +
                      (int64_t)wave * CH_WCOL + lane;
   int prow, px;
@@ -232,9 +232,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     {
       const uint4* src = xs4 + (int64_t)g * 2 * PP;
       const unsigned dst = lds_base + (wave * 64) * 16;
+      int t = tid;
+      asm volatile("" : "+v"(t));                    // opaque per stage: the plan is not hoisted out of the loop
 #pragma unroll
-      for (int e = 0; e < 7; ++e) ch_dma16(src + in_src[e], dst + e * 4096);
-      if (wave < 2) ch_dma16(src + in_src[7], dst + 7 * 4096);
+      for (int e = 0; e < 7; ++e) ch_dma16(src + in_src(e, t), dst + e * 4096);
+      if (wave < 2) ch_dma16(src + in_src(7, t), dst + 7 * 4096);
     }
     ch_wait_vm<0>();
     __syncthreads();                                   // the tile of every wave has landed
