@@ -4,8 +4,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         -m dmpfold2_amd.batch -l targets.txt -o out_dir
 
+    python -m dmpfold2_amd.batch -i msa_dir more.aln other.a3m -o out_dir --format ca
+
 `targets.txt` holds one alignment path per line (.aln, or .a3m converted as the reference's README
-describes), optionally followed by a template PDB path.  The
+describes), optionally followed by a template PDB path; `-i` takes alignment files and directories
+(every *.aln / *.a3m inside, sorted).  `--format`: `pdb` (default) = the text of the single-target CLI
+(N, CA, C, O, CB records, confidence in the B-factor column and the REMARK line, predict.py:195-208),
+`ca` = the same records for the CA atoms only, `npz` = coords (L,5,3), confs (L,), alnmat as arrays.  The
 reference has no batch mode (its CLI takes one alignment, predict.py:160-208); this is the
 "independent alignments shard embarrassingly" axis of SURVEY.md section 8e: every rank (one process
 per GPU) takes the targets `shard.partition_targets` assigns to it (longest first), runs them through
@@ -51,9 +56,49 @@ def read_target_list(path):
     return out
 
 
+def expand_inputs(inputs):
+    """Files and directories -> [(alignment path, None)]; a directory contributes its *.aln and *.a3m
+    files in sorted order."""
+    out = []
+    for item in inputs:
+        if os.path.isdir(item):
+            out += [(os.path.join(item, f), None) for f in sorted(os.listdir(item))
+                    if f.endswith((".aln", ".a3m"))]
+        else:
+            out.append((item, None))
+    return out
+
+
+def ca_only_text(coords, confs, alnmat):
+    """The CLI's PDB text reduced to its CA records (atom serial numbers renumbered 1..L)."""
+    keep = [ln for ln in pdb_text(coords, confs, alnmat).split("\n") if not ln.startswith("ATOM") or ln[12:16] == " CA "]
+    out, k = [], 0
+    for ln in keep:
+        if ln.startswith("ATOM"):
+            k += 1
+            ln = "ATOM   %4d" % k + ln[11:]
+        out.append(ln)
+    return "\n".join(out)
+
+
+def write_result(out_dir, aln_path, coords, confs, alnmat, fmt="pdb"):
+    stem = os.path.join(out_dir, os.path.splitext(os.path.basename(aln_path))[0])
+    if fmt == "npz":
+        path = stem + ".npz"
+        np.savez_compressed(path, coords=coords.detach().cpu().numpy(), confs=confs.detach().cpu().numpy(),
+                            alnmat=alnmat)
+        return path
+    path = stem + ".pdb"
+    with open(path, "w") as fh:
+        fh.write(pdb_text(coords, confs, alnmat) if fmt == "pdb" else ca_only_text(coords, confs, alnmat))
+    return path
+
+
 def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_minsteps,
-              weights_file=None, state_dict=None, streams=4, device=None, rank=0, world=1):
+              weights_file=None, state_dict=None, streams=4, device=None, rank=0, world=1, fmt="pdb"):
     """Predict the targets of this rank's shard; returns (number done, seconds, [output paths])."""
+    if fmt not in ("pdb", "ca", "npz"):
+        raise ValueError(f"unknown output format {fmt!r} (pdb, ca, npz)")
     os.makedirs(out_dir, exist_ok=True)
     parsed, failed = [], []
     for aln_path, tpl_path in targets:
@@ -90,10 +135,7 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             failed.append((aln_path, results[t]))
             continue
         coords, confs = results[t]
-        out_path = os.path.join(out_dir, os.path.splitext(os.path.basename(aln_path))[0] + ".pdb")
-        with open(out_path, "w") as fh:
-            fh.write(pdb_text(coords, confs, alnmat))
-        outputs.append(out_path)
+        outputs.append(write_result(out_dir, aln_path, coords, confs, alnmat, fmt))
     elapsed = time.perf_counter() - t0
     if pipe is not None:
         pipe.close()
@@ -104,13 +146,19 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description="DMPfold2 batch prediction on AMD MI355X (one process per GPU)")
-    ap.add_argument("-l", "--list", required=True, help="text file: one alignment path (+ optional template) per line")
+    ap.add_argument("-l", "--list", default=None, help="text file: one alignment path (+ optional template) per line")
+    ap.add_argument("-i", "--input", nargs="*", default=[],
+                    help="alignment files (.aln / .a3m) and directories of them")
     ap.add_argument("-o", "--out_dir", required=True)
+    ap.add_argument("--format", choices=("pdb", "ca", "npz"), default="pdb",
+                    help="pdb: the single-target CLI's text; ca: its CA records only; npz: arrays")
     ap.add_argument("-n", "--iterations", type=int, default=default_iterations)
     ap.add_argument("-m", "--minsteps", type=int, default=default_minsteps)
     ap.add_argument("-w", "--model_weights", type=str, default=None)
     ap.add_argument("--streams", type=int, default=4, help="targets in flight per GPU")
     args = ap.parse_args(argv)
+    if not args.list and not args.input:
+        ap.error("give -l targets.txt and / or -i alignments ...")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,12 +170,12 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
-    targets = read_target_list(args.list)
+    targets = (read_target_list(args.list) if args.list else []) + expand_inputs(args.input)
     status = 0
     try:
         n, elapsed, _ = run_batch(targets, args.out_dir, args.iterations, args.minsteps,
                                   weights_file=args.model_weights, streams=args.streams,
-                                  device=f"cuda:{local_rank}", rank=rank, world=world)
+                                  device=f"cuda:{local_rank}", rank=rank, world=world, fmt=args.format)
     except BatchFailures as bf:                      # keep going: the other ranks wait in job_summary
         for aln_path, exc in bf.failed:
             print(f"dmpfold-batch: {aln_path}: {type(exc).__name__}: {exc}", file=sys.stderr)

@@ -385,3 +385,36 @@ def test_accuracy_harness_runs_when_trained_weights_exist():
     res = mod.evaluate(os.path.join(root, "tests", "golden", "PF10963.aln"),
                        os.path.join(root, "tests", "golden", "kat_refine_backbone.npz"))
     assert res["tm_score"] > 0.5, res
+
+
+# ------------------------------------------------------------------ the reference's LAPACK sign flavour
+def test_lapack_sign_flavour_given_its_signs(synth_sd):
+    """Eigenvector signs of `symeig` are implementation-defined; the HIP solver fixes them by rule
+    (largest-magnitude component positive) and is compared with the goldens of that flavour.  The other
+    captured flavour - MKL's signs as `torch.linalg.eigh` returns them - differs from it ONLY in those sign
+    bits: flipping the MDS columns whose recorded LAPACK sign is negative and running the rest of the path
+    (coordinate GRU, coord_fc, backbone) through the stage API reproduces the LAPACK-flavour golden."""
+    from abi import Stages
+    g = load_golden("pf10963_n0_m0_lapack")
+    assert bytes(g["sign_mode"]).decode() == "lapack"
+    signs = g["mds_sign_ref"][0]                                   # sign of each eigenvector's largest component
+    assert (signs < 0).any() and (signs > 0).any()                 # the two flavours really differ here
+    st = Stages(synth_sd, max_L=128, max_N=512)
+    try:
+        L = 82
+        coords, confs = st.eng.predict(g["alnmat"], None, 0, 0)
+        st.eng.sync_check()
+        assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) > 0.05     # canonical signs: another trace
+        mds = st.eng.fetch("mds", L * 8).reshape(L, 8).clone()
+        mat1d = st.eng.fetch("mat1d", 512 * L).reshape(512, L).clone()
+        flipped = (mds * torch.from_numpy(signs).to(mds.device)).contiguous()
+        ca = st.coords_from_mds(mat1d, flipped)
+        logit = torch.zeros(L, device=ca.device)
+        bb, _ = st.backbone(ca, logit)
+        st.eng.sync_check()
+        assert ca_rmsd(ca.cpu().numpy(), g["ca_pass"][0]) <= 1e-3
+        assert ca_rmsd(bb.cpu().numpy()[:, 1], g["coords"][:, 1]) <= 1e-3
+        assert np.abs(bb.cpu().numpy() - g["coords"]).max() < 2e-2
+        assert np.abs(confs.cpu().numpy() - g["confs"]).max() < 1e-4               # confidences do not depend on signs
+    finally:
+        st.eng.close()

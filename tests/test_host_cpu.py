@@ -307,3 +307,37 @@ def test_batch_reports_bad_targets_without_losing_the_others(tmp_path):
         run_batch([(str(bad), None)], str(tmp_path / "out"), 0, 0, state_dict={})
     assert len(ei.value.failed) == 1 and isinstance(ei.value.failed[0][1], IndexError)
     assert ei.value.outputs == []
+
+
+def test_batch_inputs_and_output_variants(tmp_path):
+    """Batch front end, host side: directories expand to their alignments in sorted order; the `ca` variant is
+    the CLI's text reduced to its CA records; `npz` round-trips the arrays."""
+    from dmpfold2_amd.batch import ca_only_text, expand_inputs, write_result
+    d = tmp_path / "msas"
+    d.mkdir()
+    for name in ("b.aln", "a.a3m", "notes.txt", "c.aln"):
+        (d / name).write_text("ACDEFGHIKL\n")
+    lone = tmp_path / "x.aln"
+    lone.write_text("ACDEFGHIKL\n")
+    got = expand_inputs([str(d), str(lone)])
+    assert [os.path.basename(a) for a, _ in got] == ["a.a3m", "b.aln", "c.aln", "x.aln"] and all(t is None for _, t in got)
+    g = load_golden("pf10963_default_cli")
+    coords, confs = torch.from_numpy(g["coords"]), torch.from_numpy(g["confs"])
+    full = bytes(g["cli_stdout"]).decode()
+    ca = ca_only_text(coords, confs, g["alnmat"])
+    lines = ca.split("\n")
+    atoms = [ln for ln in lines if ln.startswith("ATOM")]
+    assert len(atoms) == 82 and all(ln[12:16] == " CA " for ln in atoms)
+    assert lines[0] == full.split("\n")[0] and lines[-2] == "END"
+    ref_ca = [ln for ln in full.split("\n") if ln.startswith("ATOM") and ln[12:16] == " CA "]
+    assert [ln[11:] for ln in atoms] == [ln[11:] for ln in ref_ca]            # same records, renumbered
+    assert [int(ln[6:11]) for ln in atoms] == list(range(1, 83))
+    out = tmp_path / "out"
+    out.mkdir()
+    assert open(write_result(str(out), "t/pf.aln", coords, confs, g["alnmat"], "pdb")).read() == full
+    z = np.load(write_result(str(out), "t/pf.aln", coords, confs, g["alnmat"], "npz"))
+    assert np.array_equal(z["coords"], g["coords"]) and np.array_equal(z["confs"], g["confs"])
+    assert np.array_equal(z["alnmat"], g["alnmat"])
+    from dmpfold2_amd.batch import run_batch
+    with pytest.raises(ValueError):
+        run_batch([], str(out), fmt="cif")
