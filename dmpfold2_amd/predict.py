@@ -256,6 +256,13 @@ class Engine:
                 if lt != L:
                     raise RuntimeError(f"Sizes of tensors must match: template has {lt} CA atoms, "
                                        f"alignment has {L} columns")
+            if self._stream is not None:
+                # an engine with its own stream: order it after the producer of the inputs and tell the
+                # caching allocator that these blocks are in use there
+                self._stream.wait_stream(torch.cuda.current_stream(self.device))
+                for x in (coords, confs, d_msa, d_tpl):
+                    if x is not None:
+                        x.record_stream(self._stream)
             _lib.check(self.lib.dmp_predict(
                 self._ctx, d_msa.data_ptr(), n, L,
                 d_tpl.data_ptr() if d_tpl is not None else None, lt,
