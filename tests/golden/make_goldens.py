@@ -295,6 +295,10 @@ def main():
     case("synth_L300_N2000_n1_m0", synth.synth_msa(300, 2000, 0), 1, 0, wfile, wsum, stages=False,
          store_aln=False, noise_threads=4, extra={"msa_seed": np.int64(0)})
 
+    # the same target at the benchmark's full recycling depth (11 trunk passes, 176 convolutions at L=300)
+    case("synth_L300_N2000_n10_m0", synth.synth_msa(300, 2000, 0), 10, 0, wfile, wsum, stages=False,
+         store_aln=False, noise_threads=(4,), extra={"msa_seed": np.int64(0)})
+
     # minimiser end to end on protein-like traces: coord_fc fitted so that the first-pass trace of a
     # synthetic L=96 alignment approximates 3FGX chain A (see fit_coord_fc)
     rows96 = synth.synth_msa(len(ca), 50, 5)

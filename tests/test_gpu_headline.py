@@ -104,6 +104,28 @@ def test_north_star_size_vs_reference(ns_engine, mode):
         eng.set_option("conv_mode", 0)
 
 
+@pytest.mark.parametrize("mode", list(MODES))
+def test_north_star_size_and_depth_vs_reference(ns_engine, mode):
+    """The benchmark's workload itself minus the minimiser: bench target 0 (L=300, N=2000), iterations=10
+    (11 trunk passes = 176 convolutions at L=300), minsteps=0, every pass against the reference's run."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import encode_aln
+    g = load_golden("synth_L300_N2000_n10_m0")
+    alnmat = encode_aln(synth.synth_msa(300, 2000, int(g["msa_seed"])))
+    assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+    eng = ns_engine
+    eng.set_option("conv_mode", MODES[mode])
+    try:
+        coords, confs = eng.predict(alnmat, None, 10, 0)
+        eng.sync_check()
+        coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
+        _check_passes(eng, g, 11, 300, 1e-3)
+        assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
+        assert np.abs(confs - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
+    finally:
+        eng.set_option("conv_mode", 0)
+
+
 # ------------------------------------------------------------------ the benchmark's minimiser setting
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", ["fit3fgx_L96_N50_n0_m100", "fit3fgx_L96_N50_n10_m100"])

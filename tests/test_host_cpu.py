@@ -295,6 +295,10 @@ def test_north_star_golden_input_is_reproducible():
     assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
     assert g["coords"].shape == (300, 5, 3) and g["ca_pass"].shape == (2, 300, 3)
     assert float(g["oracle_vs_ref_ca_rmsd"]) <= 1e-3 and float(g["oracle_vs_ref_conf"]) < 1e-4
+    g10 = load_golden("synth_L300_N2000_n10_m0")
+    assert bytes(g10["alnmat_sha256"]) == bytes(g["alnmat_sha256"]) and g10["ca_pass"].shape == (11, 300, 3)
+    assert float(g10["oracle_vs_ref_ca_rmsd"]) <= 1e-3 and float(g10["oracle_vs_ref_conf"]) < 1e-4
+    assert np.abs(g10["ca_pass"][:2] - g["ca_pass"]).max() == 0.0      # the same first two passes
 
 
 def test_batch_reports_bad_targets_without_losing_the_others(tmp_path):

@@ -24,13 +24,18 @@ for name in sys.argv[1:] or ["pf10963_n10_m0"]:
         sd["coord_fc.weight"] = g["coord_fc"]
     n, m = int(g["iterations"]), int(g["minsteps"])
     L = g["coords"].shape[0]
-    eng = Engine("cuda:0", max(L, 64), 3000)
+    if "alnmat" in g.files:
+        alnmat = g["alnmat"]
+    else:                                   # large synthetic alignments are regenerated from their seed
+        from dmpfold2_amd.predict import encode_aln
+        alnmat = encode_aln(synth.synth_msa(L, 2000, int(g["msa_seed"])))
+    eng = Engine("cuda:0", max(L, 64), 3000 if L <= 128 else 2000)
     eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     P = n + 1
     print(name, "floor", ["%.1e" % x for x in (g["noise_ca_pass"] if "noise_ca_pass" in g.files else [])])
     for mode in (0, 1, 2):
         eng.set_option("conv_mode", mode)
-        c, f = eng.predict(g["alnmat"], None, n, m)
+        c, f = eng.predict(alnmat, None, n, m)
         eng.sync_check()
         ca = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
         means = eng.fetch("conf_means", P).cpu().numpy()
