@@ -299,6 +299,14 @@ def main():
     case("synth_L300_N2000_n10_m0", synth.synth_msa(300, 2000, 0), 10, 0, wfile, wsum, stages=False,
          store_aln=False, noise_threads=(4,), extra={"msa_seed": np.int64(0)})
 
+    # the other single-target configurations of BASELINE.json at their own sizes (minimiser off: random weights)
+    case("synth_L200_N1000_n10_m0", synth.synth_msa(200, 1000, 11), 10, 0, wfile, wsum, stages=False,
+         store_aln=False, noise_threads=(4,), extra={"msa_seed": np.int64(11), "msa_rows": np.int64(1000)})
+    case("synth_L500_N5000_n1_m0", synth.synth_msa(500, 5000, 5), 1, 0, wfile, wsum, stages=False,
+         store_aln=False, noise_threads=(4,), extra={"msa_seed": np.int64(5), "msa_rows": np.int64(5000)})
+    case("synth_L1000_N2000_n0_m0", synth.synth_msa(1000, 2000, 3), 0, 0, wfile, wsum, stages=False,
+         store_aln=False, noise_threads=(4,), extra={"msa_seed": np.int64(3), "msa_rows": np.int64(2000)})
+
     # minimiser end to end on protein-like traces: coord_fc fitted so that the first-pass trace of a
     # synthetic L=96 alignment approximates 3FGX chain A (see fit_coord_fc)
     rows96 = synth.synth_msa(len(ca), 50, 5)

@@ -231,3 +231,40 @@ def test_eigensolver_at_the_largest_order(synth_sd):
             assert np.abs(got - truth).max() <= 2e-5 * np.abs(truth).max(), L
     finally:
         st.eng.close()
+
+
+@pytest.mark.parametrize("name", ["synth_L200_N1000_n10_m0", "synth_L500_N5000_n1_m0", "synth_L1000_N2000_n0_m0"])
+def test_baseline_config_sizes_vs_reference(synth_sd, name):
+    """The single-target configurations of BASELINE.json at their own sizes against outputs of the reference
+    itself (tests/golden/make_goldens.py; minimiser off - it is chaotic on random weights): configs[1]
+    L=200, N=1000, 10 iterations; configs[2] L=500, N=5000 (cut to 3000 rows), 1 iteration; configs[4]
+    L=1000, N=2000, first pass.  The alignments are regenerated from their seeds (SHA-256 in the fixture).
+    A fixture that has not been generated yet is skipped."""
+    import hashlib
+    import os
+    from conftest import GOLDEN, load_golden
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated: " + name)
+    g = load_golden(name)
+    L = g["coords"].shape[0]
+    alnmat = encode_aln(synth.synth_msa(L, int(g["msa_rows"]), int(g["msa_seed"])))
+    assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+    n = int(g["iterations"])
+    eng = Engine("cuda:0", L, alnmat.shape[0])
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+    try:
+        coords, confs = eng.predict(alnmat, None, n, 0)
+        eng.sync_check()
+        P = n + 1
+        ca_pass = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
+        floor = g["noise_ca_pass"]
+        dev = np.array([ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P)])
+        assert (dev <= np.maximum(1e-3, 3.0 * floor)).all(), (dev, floor)
+        means = eng.fetch("conf_means", P).cpu().numpy()
+        assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
+        assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
+        assert np.abs(confs.cpu().numpy() - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
+    finally:
+        eng.close()

@@ -345,3 +345,14 @@ def test_batch_inputs_and_output_variants(tmp_path):
     from dmpfold2_amd.batch import run_batch
     with pytest.raises(ValueError):
         run_batch([], str(out), fmt="cif")
+
+
+def test_empty_alignment_raises_index_error(tmp_path):
+    """predict.py:124: `len(aln[0])` on an alignment without sequence lines (empty file, headers only)."""
+    for text in ("", ">only a header\n"):
+        p = tmp_path / "e.aln"
+        p.write_text(text)
+        with pytest.raises(IndexError):
+            predict.encode_aln(predict.read_aln(str(p)))
+        with pytest.raises(IndexError):
+            O.encode_aln(O.read_aln(str(p)))
