@@ -126,6 +126,20 @@ def run_oracle(aln_path, wfile, n, m, template=None, sign="canonical", threads=8
     return coords, confs, alnmat, cap
 
 
+def eig_precision_floor(cap, weights):
+    """CA-RMSD between the first-pass trace computed from the float32 eigenvectors the reference's
+    `symeig` returns (LAPACK ssyevd) and from the float64 eigenvectors of the SAME Gram matrix.  The MDS
+    spectrum is clustered (at L=1000 two of the top eight eigenvalues differ by 3e-4 relative), so float32
+    LAPACK itself is only this close to the exact eigenvectors - a floor no exact solver can get under."""
+    M, mat1d = cap["p0.M"], cap["mat1d"]
+    lam, vec = torch.linalg.eigh(M.double(), UPLO="U")
+    vec = O.canonical_signs(vec)
+    mds64 = (vec * lam.clamp(min=1e-8).sqrt())[:, -8:].float().unsqueeze(0)
+    mds32 = O.mds_top8(M.unsqueeze(0), "canonical")
+    with torch.no_grad():
+        return rmsd(O.coords_from_mds(weights, mat1d, mds32)[0], O.coords_from_mds(weights, mat1d, mds64)[0])
+
+
 def capture_case(name, aln_rows, n, m, wfile, wsum, template=None, sign="canonical",
                  stages=True, report=None, with_cli=False, extra=None, store_aln=True,
                  noise_threads=1):
@@ -195,6 +209,8 @@ def capture_case(name, aln_rows, n, m, wfile, wsum, template=None, sign="canonic
         # settles, so intermediate traces wobble more than the final structure (the best pass is often an early one)
         nfp = np.maximum(nfp, [rmsd(cap8[f"p{p}.ca"], cap1[f"p{p}.ca"]) for p in range(npass)])
     out["noise_ca_pass"] = nfp.astype(np.float64)
+    if sign == "canonical":
+        out["noise_eig_ca_rmsd"] = np.float64(eig_precision_floor(cap8, O.load_weights(wfile)))
     out["noise_threads"] = np.array(counts, dtype=np.int64)
     out["oracle_vs_ref_ca_rmsd"] = np.float64(dev)
     out["oracle_vs_ref_conf"] = np.float64(devc)

@@ -259,12 +259,16 @@ def test_baseline_config_sizes_vs_reference(synth_sd, name):
         eng.sync_check()
         P = n + 1
         ca_pass = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
-        floor = g["noise_ca_pass"]
+        # floors of the reference itself: thread-count noise per pass, and how far its float32 LAPACK
+        # eigenvectors are from the exact ones of its own Gram matrix (1.8e-3 A at L=1000, where two of the
+        # top eight eigenvalues are 3e-4 apart; the HIP solver works in float64)
+        eig = float(g["noise_eig_ca_rmsd"]) if "noise_eig_ca_rmsd" in g else 0.0
+        floor = np.maximum(g["noise_ca_pass"], eig)
         dev = np.array([ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P)])
         assert (dev <= np.maximum(1e-3, 3.0 * floor)).all(), (dev, floor)
         means = eng.fetch("conf_means", P).cpu().numpy()
         assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
-        assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
+        assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= max(1e-3, 3.0 * max(float(g["noise_ca_rmsd"]), eig))
         assert np.abs(confs.cpu().numpy() - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
     finally:
         eng.close()
