@@ -276,16 +276,25 @@ def main(argv=None):
     import torch
     # DMP_FORCE_DIST=1 exercises the RCCL barrier / reduction path with a single rank (1-GPU boxes)
     distributed = world > 1 or (os.environ.get("DMP_FORCE_DIST") == "1" and "RANK" in os.environ)
+    # DMP_BENCH_SHARE_GPU=1 (test of the N > 1 flow on a one-GPU box): every rank works on cuda:0 and the
+    # barrier / reductions go over gloo (RCCL refuses two ranks on one device); the throughput is meaningless
+    share_gpu = os.environ.get("DMP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     ranks_seen = 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
         ranks_seen = dist.get_world_size()
     device = torch.device("cuda", local_rank)
+    red_device = torch.device("cpu") if share_gpu else device          # where the reduced scalars live
 
     from dmpfold2_amd import synth, _lib
     from dmpfold2_amd.predict import Pipeline, encode_aln
@@ -413,11 +422,11 @@ def main(argv=None):
 
     if distributed:
         vals = [elapsed, exact if exact is not None else 0.0]
-        t = torch.tensor(vals, dtype=torch.float64, device=device)
+        t = torch.tensor(vals, dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, el1 = float(t[0].item()), float(t[1].item())
         exact = el1 if exact is not None else None
-        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        flag = torch.tensor([1.0 if ok else 0.0], device=red_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() > 0.5)
 

@@ -440,3 +440,29 @@ def test_lapack_sign_flavour_given_its_signs(synth_sd):
         assert np.abs(confs.cpu().numpy() - g["confs"]).max() < 1e-4               # confidences do not depend on signs
     finally:
         st.eng.close()
+
+
+# ------------------------------------------------------------------ bench.py with more than one rank
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """`python bench.py --gpus 2` outside a launcher: it starts two ranks itself, each runs its own scheduler
+    and targets, rank 0 prints one line with n_gpus = ranks = 2 and the whole-job rate.  On this one-GPU box
+    both ranks share cuda:0 (DMP_BENCH_SHARE_GPU=1: gloo instead of RCCL for the barrier / reductions), so
+    only the flow and the verification are checked, not the rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMP_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--streams", "2", "--cpu-baseline", "none", "--no-exact-f32"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["verify"]["ok"] and d["verify"]["reference_golden_L300_N2000_n1_m0"]["ok"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] + 1e-9
+    assert "cpu_baseline" not in d                       # rank 0 times the CPU oracle at N = 1 only
