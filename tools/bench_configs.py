@@ -42,6 +42,7 @@ def single(eng, msa, n, m, reps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c4", type=int, default=256)
+    ap.add_argument("--scheduler-only", action="store_true", help="skip the single-target latencies")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_scale=5.0).items()}
@@ -50,6 +51,8 @@ def main():
         print(json.dumps({"config": name, **kw}), flush=True)
 
     pf = os.path.join(ROOT, "tests", "golden", "PF10963.aln")
+    if args.scheduler_only:
+        return scheduler_configs(args, dev, sd, report)
     eng = Engine(dev, 1000, 3000)
     eng.set_weights(sd)
     t = single(eng, encode_aln(read_aln(pf)), 0, 0, reps=5)
@@ -62,7 +65,10 @@ def main():
         t = single(eng, msa, n, m, reps=reps)
         report(name, seconds_per_structure=t, structures_per_s_single_stream=1.0 / t)
     eng.close()
+    return scheduler_configs(args, dev, sd, report)
 
+
+def scheduler_configs(args, dev, sd, report):
     pipe = Pipeline(dev, 300, 2000, sd, streams=4)
     tg = [torch.from_numpy(encode_aln(synth.synth_msa(200, 1000, seed=10 + i))).to(dev) for i in range(12)]
     pipe.run(tg[:3], 10, 100)
