@@ -366,14 +366,17 @@ def main(argv=None):
         verify["timed_target_bitwise_equals_single_engine"] = bool(
             torch.equal(c1, timed_outs[0][0]) and torch.equal(f1, timed_outs[0][1]))
         ok = ok and verify["timed_target_bitwise_equals_single_engine"]
-        # (2) digest of that target's outputs against the stored one (profiles/bench_digest.json, made by
-        #     DMP_WRITE_DIGEST=1; the results are bit-reproducible, so a change means the arithmetic changed)
+        # (2) digest of bench target 0 (seed 0, the full 10 + 100 prediction, alone on one engine - the same
+        #     bits the scheduler delivers, by (1)) against the stored one (profiles/bench_digest.json, written
+        #     by DMP_WRITE_DIGEST=1); the results are bit-reproducible, so a change means the arithmetic changed.
+        #     The key does not depend on --steps / --warmup.
         if rank == 0:
-            digest = hashlib.sha256(timed_outs[0][0].cpu().numpy().tobytes()
-                                    + timed_outs[0][1].cpu().numpy().tobytes()).hexdigest()
+            c0, f0 = e0.predict_device(targets[0], None, ITERS, MINSTEPS)
+            e0.sync_check()
+            digest = hashlib.sha256(c0.cpu().numpy().tobytes() + f0.cpu().numpy().tobytes()).hexdigest()
             verify["digest"] = digest
             dpath = os.path.join(ROOT, "profiles", "bench_digest.json")
-            key = f"L{L_NS}_N{N_NS}_n{ITERS}_m{MINSTEPS}_seed{first}"
+            key = f"L{L_NS}_N{N_NS}_n{ITERS}_m{MINSTEPS}_seed0"
             stored = {}
             if os.path.exists(dpath):
                 try:
@@ -381,7 +384,7 @@ def main(argv=None):
                 except Exception:
                     stored = {}
             if os.environ.get("DMP_WRITE_DIGEST") == "1":
-                stored[key] = digest
+                stored = {key: digest}
                 json.dump(stored, open(dpath, "w"), indent=1, sort_keys=True)
             verify["digest_expected"] = stored.get(key)
             verify["digest_match"] = (stored.get(key) == digest) if key in stored else None
