@@ -46,7 +46,13 @@ namespace dmp {
 typedef float ch_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 ch_f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int CH_HALO = 20, CH_PITCH = 24;
+#ifndef CH_PITCH_N
+#define CH_PITCH_N 24        // row pitch of the halo tile in LDS (16-byte slots); any value >= 20 is conflict free.
+                             // 24 -> 54 KB per workgroup: two per CU and room for other targets' kernels.  20 -> 50 KB
+                             // lets a third workgroup in (3 waves per SIMD): sustained 0.665 against 0.667 ms - at
+                             // the power cap more occupancy buys nothing, and the room beside the two is worth more
+#endif
+constexpr int CH_HALO = 20, CH_PITCH = CH_PITCH_N;
 constexpr int CH_IN_SLOTS = 2 * 2 * CH_HALO * CH_PITCH;               // 1920 16-byte slots
 constexpr int CH_IN_BYTES = CH_IN_SLOTS * 16;                         // 30720
 constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slots = 2 KB per wave and tap
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   auto in_src = [&](int e, int t) {
     const int s = e * 256 + t;
     const int sc = s < CH_IN_SLOTS ? s : 0;
-    const int p = sc / 960, r = sc % 960;
-    const int cg = r / 480, r2 = r % 480;
+    const int p = sc / (2 * CH_HALO * CH_PITCH), r = sc % (2 * CH_HALO * CH_PITCH);
+    const int cg = r / (CH_HALO * CH_PITCH), r2 = r % (CH_HALO * CH_PITCH);
     const int yy = r2 / CH_PITCH;
     int xx = r2 % CH_PITCH;
     xx = xx < CH_HALO ? xx : 0;                     // pad slots re-read a valid pixel
@@ -235,8 +241,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       int t = tid;
       asm volatile("" : "+v"(t));                    // opaque per stage: the plan is not hoisted out of the loop
 #pragma unroll
-      for (int e = 0; e < 7; ++e) ch_dma16(src + in_src(e, t), dst + e * 4096);
-      if (wave < 2) ch_dma16(src + in_src(7, t), dst + 7 * 4096);
+      for (int e = 0; e < CH_IN_SLOTS / 256; ++e) ch_dma16(src + in_src(e, t), dst + e * 4096);
+      if (wave * 64 < CH_IN_SLOTS % 256) ch_dma16(src + in_src(CH_IN_SLOTS / 256, t), dst + (CH_IN_SLOTS / 256) * 4096);
     }
     ch_wait_vm<0>();
     __syncthreads();                                   // the tile of every wave has landed
