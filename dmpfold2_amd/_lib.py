@@ -21,6 +21,7 @@ SIGNATURES = {
     "dmp_ctx_destroy": (None, [_vp]),
     "dmp_ctx_device_bytes": (_i64, [_vp]),
     "dmp_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "dmp_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "dmp_clear_faults": (_i, [_vp, _vp]),
     "dmp_weights_set": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
     "dmp_weights_finalize": (_i, [_vp]),
@@ -29,6 +30,7 @@ SIGNATURES = {
     "dmp_cov_build": (_i, [_vp, _fp, _fp, _i, _i, _fp, _vp]),
     "dmp_spd_inverse": (_i, [_vp, _fp, _i, _vp]),
     "dmp_dca_contacts": (_i, [_vp, _fp, _i, _fp, _vp]),
+    "dmp_dca_features": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "dmp_gru_vertical": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "dmp_gru_bidir": (_i, [_vp, _i, _fp, _i, _fp, _vp]),
     "dmp_stem_static": (_i, [_vp, _fp, _fp, _fp, _i, _fp, _vp]),
@@ -63,6 +65,8 @@ SIGNATURES = {
     "dmp_time_conv5x5": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_float), _vp]),
 }
 
+ABI_VERSION = 2      # include/dmpfold_hip.h DMP_ABI_VERSION
+
 _lib = None
 
 
@@ -84,8 +88,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.dmp_abi_version() != 1:
-        raise ImportError("libdmpfold_hip.so ABI version mismatch")
+    if lib.dmp_abi_version() != ABI_VERSION:
+        raise ImportError(f"libdmpfold_hip.so ABI version {lib.dmp_abi_version()} != {ABI_VERSION} "
+                          "(stale library: rebuild with `python -m dmpfold2_amd.build`)")
     _lib = lib
     return lib
 

@@ -58,15 +58,58 @@ def read_target_list(path):
 
 def expand_inputs(inputs):
     """Files and directories -> [(alignment path, None)]; a directory contributes its *.aln and *.a3m
-    files in sorted order."""
+    files in sorted order.  The reference README's workflow converts x.a3m to x.aln in the same
+    directory: where a directory holds both, only x.aln is taken (both would be written to x.pdb)."""
     out = []
     for item in inputs:
         if os.path.isdir(item):
-            out += [(os.path.join(item, f), None) for f in sorted(os.listdir(item))
-                    if f.endswith((".aln", ".a3m"))]
+            names = sorted(f for f in os.listdir(item) if f.endswith((".aln", ".a3m")))
+            have_aln = {f[:-4] for f in names if f.endswith(".aln")}
+            out += [(os.path.join(item, f), None) for f in names
+                    if f.endswith(".aln") or f[:-4] not in have_aln]
         else:
             out.append((item, None))
     return out
+
+
+def check_output_stems(targets):
+    """Two targets with the same basename would be written to the same <out_dir>/<stem> file (and, sharded,
+    by two ranks at once): refuse the job before anything is predicted."""
+    seen = {}
+    for aln_path, _ in targets:
+        stem = os.path.splitext(os.path.basename(aln_path))[0]
+        if stem in seen and seen[stem] != aln_path:
+            raise ValueError(f"targets {seen[stem]} and {aln_path} would both be written to {stem}.*: "
+                             "rename one of them or run them into different output directories")
+        seen[stem] = aln_path
+
+
+def scan_target(aln_path):
+    """(L, N) estimate of an alignment WITHOUT parsing it: the length of its first sequence line and the file
+    size divided by that line length.  Every rank scans every target (a stat and one line each) so that all
+    ranks compute the same partition; only the owner of a target reads and encodes it.  An unreadable file
+    scans as (0, 0): its owner reports the error when it reads it."""
+    try:
+        size = os.path.getsize(aln_path)
+        a3m = aln_path.endswith(".a3m")
+        with open(aln_path, "rb") as fh:
+            for raw in fh:
+                if raw.startswith(b">"):
+                    continue
+                line = raw.rstrip()
+                L = sum(1 for ch in line if not (a3m and 97 <= ch <= 122))
+                per_row = len(raw) + (16 if a3m else 0)      # a3m: a header line per sequence
+                return L, max(1, size // max(per_row, 1))
+    except OSError:
+        pass
+    return 0, 0
+
+
+def plan_shard(targets, iterations, rank, world):
+    """Indices of the targets rank `rank` of `world` owns, longest first.  Deterministic and identical on every
+    rank (it depends only on the header scans), every target exactly once over the ranks."""
+    costs = [shard.estimate_cost(L, N, iterations) for L, N in (scan_target(a) for a, _ in targets)]
+    return shard.partition_targets(costs, world)[rank]
 
 
 def ca_only_text(coords, confs, alnmat):
@@ -99,17 +142,22 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     """Predict the targets of this rank's shard; returns (number done, seconds, [output paths])."""
     if fmt not in ("pdb", "ca", "npz"):
         raise ValueError(f"unknown output format {fmt!r} (pdb, ca, npz)")
+    check_output_stems(targets)
     os.makedirs(out_dir, exist_ok=True)
-    parsed, failed = [], []
-    for aln_path, tpl_path in targets:
-        rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
+    # shard first, parse afterwards: the partition needs only (L, N) estimates from a header scan, so a rank
+    # reads and encodes its own targets and nobody else's
+    owned = plan_shard(targets, iterations, rank, world)
+    parsed, failed, mine = {}, [], []
+    for i in owned:                                  # longest first: the order partition_targets returns
+        aln_path, tpl_path = targets[i]
         try:
-            parsed.append((aln_path, tpl_path, encode_aln(rows)))
-        except (IndexError, ValueError) as exc:      # unknown residue letter / ragged rows: this target only
-            if rank == 0:
-                failed.append((aln_path, exc))
-    costs = [shard.estimate_cost(m.shape[1], m.shape[0], iterations) for _, _, m in parsed]
-    mine = shard.partition_targets(costs, world)[rank]
+            rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
+            tpl = read_template_ca(tpl_path) if tpl_path else None
+            parsed[i] = (aln_path, tpl, encode_aln(rows))
+            mine.append(i)
+        except (IndexError, ValueError, OSError, UnicodeDecodeError) as exc:
+            # unknown residue letter / ragged rows / unreadable file: this target only
+            failed.append((aln_path, exc))
     if not mine and not failed:
         return 0, 0.0, []
     t0 = time.perf_counter()
@@ -120,9 +168,8 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
         max_N = max(parsed[i][2].shape[0] for i in mine)
         sd = state_dict if state_dict is not None else load_state_dict(weights_file)
         pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
-    for i in mine:                                   # longest first: the order partition_targets returns
-        aln_path, tpl_path, alnmat = parsed[i]
-        tpl = read_template_ca(tpl_path) if tpl_path else None
+    for i in mine:
+        aln_path, tpl, alnmat = parsed[i]
         d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
         tickets.append((i, pipe.submit(d_msa, iterations, minsteps, template_ca=tpl)))
         pipe.pump()

@@ -476,6 +476,17 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   return DMP_ERR_ARG;
 }
 
+int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
+  DMP_ARG(ctx && name && h_value, "null argument");
+  const std::string k(name);
+  if (k == "conv_mode") { *h_value = ctx->conv_mode; return DMP_OK; }
+  if (k == "conv_f32_exact") { *h_value = ctx->conv_mode == 1; return DMP_OK; }
+  if (k == "tridiag_single") { *h_value = ctx->tridiag_single; return DMP_OK; }
+  if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
+  set_error("unknown option %s", name);
+  return DMP_ERR_ARG;
+}
+
 int dmp_sync_faults(dmp_ctx* ctx, void* stream, int* h_bits) {
   DMP_ARG(ctx && h_bits, "null argument");
   DMP_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -603,6 +614,21 @@ int dmp_dca_contacts(dmp_ctx* ctx, const float* d_inv, int L, float* d_contacts,
   CHECK_CAP(L, 1);
   DMP_ARG(d_inv && d_contacts, "null argument");
   return dca_contacts(ctx, d_inv, L, d_contacts, STREAM);
+}
+
+int dmp_dca_features(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_out, void* stream) {
+  CHECK_CAP(L, N);
+  DMP_ARG(d_msa && d_out && N >= 1 && L >= 1, "bad argument");
+  if (N == 1) {                                   // predict.py:139: a single sequence has zero features
+    DMP_HIP(hipMemsetAsync(d_out, 0, sizeof(float) * (size_t)L * L * NUM_DCA, STREAM));
+    return DMP_OK;
+  }
+  int rc;
+  if ((rc = msa_weights(ctx, d_msa, N, L, ctx->w, STREAM))) return rc;
+  if ((rc = cov_build(ctx, d_msa, ctx->w, N, L, ctx->cov, STREAM))) return rc;
+  if ((rc = spd_inverse(ctx, ctx->cov, NS * L, STREAM))) return rc;
+  if ((rc = dca_contacts(ctx, ctx->cov, L, ctx->contacts, STREAM))) return rc;
+  return dca_features(ctx->cov, ctx->contacts, L, d_out, STREAM);
 }
 
 int dmp_gru_vertical(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_out, void* stream) {

@@ -20,6 +20,7 @@ constexpr int NBLOCK = 16;
 constexpr int STEM_OUT = 384;  // 128 * pool 3
 constexpr int STEM_IN = 955;
 constexpr int NS = 21;         // one-hot classes of the DCA features
+constexpr int NUM_DCA = NS * NS + 1;   // channels of fast_dca's return value (network.py:10)
 constexpr int GJ_NB = 128;     // Gauss-Jordan block size
 constexpr int CONV_TILE = 16;  // conv output tile edge
 constexpr int CONV_CC = 2;     // input channels per K stage
@@ -220,6 +221,7 @@ int spd_inverse(dmp_ctx* c, float* d_A, int D, hipStream_t s);
 // block steps [blk_lo, blk_hi) of the in-place inverse (GJ_NB columns each); all of them = spd_inverse
 int spd_inverse_steps(dmp_ctx* c, float* d_A, int D, int blk_lo, int blk_hi, hipStream_t s);
 int dca_contacts(dmp_ctx* c, const float* d_inv, int L, float* d_contacts, hipStream_t s);
+int dca_features(const float* d_inv, const float* d_contacts, int L, float* d_out, hipStream_t s);
 // gru.hip
 int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s);
 // launches t in [t_lo, t_hi) of the N + 1 per-row launches (t_lo = 0 clears the state, t_hi = N + 1

@@ -405,6 +405,37 @@ __global__ __launch_bounds__(256) void apc_apply_kernel(const float* __restrict_
   contacts[(int64_t)i * L + j] = (i == j) ? 0.f : (x3[(int64_t)i * L + j] - apc);
 }
 
+// fast_dca's return value as the reference lays it out (predict.py:54-61): out[i][j][21a+b] = inv[21i+a][21j+b],
+// out[i][j][441] = contacts[i][j].  One thread per output float: the writes are contiguous, the reads are runs
+// of 21 floats.  (The prediction path never builds this tensor - the stem reads `inv` in place; this is the
+// training-side consumer's layout, train.py:175-190.)
+__global__ __launch_bounds__(256) void dca_features_kernel(const float* __restrict__ inv,
+                                                           const float* __restrict__ contacts, int L,
+                                                           float* __restrict__ out) {
+  const int64_t total = (int64_t)L * L * NUM_DCA;
+  const int64_t D = (int64_t)L * NS;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t pair = e / NUM_DCA;
+    const int ch = (int)(e - pair * NUM_DCA);
+    const int i = (int)(pair / L), j = (int)(pair - (int64_t)i * L);
+    float v;
+    if (ch == NUM_DCA - 1) v = contacts[pair];
+    else {
+      const int a = ch / NS, b = ch - a * NS;
+      v = inv[((int64_t)i * NS + a) * D + (int64_t)j * NS + b];
+    }
+    out[e] = v;
+  }
+}
+
+int dca_features(const float* d_inv, const float* d_contacts, int L, float* d_out, hipStream_t s) {
+  const int64_t total = (int64_t)L * L * NUM_DCA;
+  const int grid = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 32);
+  hipLaunchKernelGGL(dca_features_kernel, dim3(grid), dim3(256), 0, s, d_inv, d_contacts, L, d_out);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
 int dca_contacts(dmp_ctx* c, const float* d_inv, int L, float* d_contacts, hipStream_t s) {
   dim3 grid(cdiv(L, 256), L);
   hipLaunchKernelGGL(contact_norm_kernel, grid, dim3(256), 0, s, d_inv, L, c->x3);

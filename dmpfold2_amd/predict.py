@@ -170,7 +170,7 @@ class Engine:
             _lib.check(self.lib.dmp_ctx_create(self.device.index, self.max_L, self.max_N,
                                                C.byref(self._ctx)))
         self.weights_tag = None
-        self.options = {}
+        self.last_fallback = False     # the last predict_*_checked call fell back to conv_mode 2
 
     def close(self):
         if self._ctx:
@@ -275,9 +275,13 @@ class Engine:
     def set_option(self, name, value):
         """Additive engine options, e.g. ("conv_f32_exact", 1); see include/dmpfold_hip.h."""
         _lib.check(self.lib.dmp_ctx_set_option(self._ctx, name.encode(), int(value)))
-        if name == "conv_f32_exact":
-            name, value = "conv_mode", 1 if value else 0
-        self.options[name] = int(value)
+
+    def get_option(self, name):
+        """The option's current value, read back from the context (not from a Python-side mirror: the
+        C API may have been used directly)."""
+        v = C.c_int(0)
+        _lib.check(self.lib.dmp_ctx_get_option(self._ctx, name.encode(), C.byref(v)))
+        return v.value
 
     def sync_faults(self):
         """Wait for the queued work; the DMP_FAULT_* bits recorded since the last report (reporting
@@ -307,10 +311,12 @@ class Engine:
         """`predict_checked` for residue codes already resident on the GPU."""
         coords, confs = self.predict_device(d_msa, template_ca, iterations, minsteps)
         bits = self.sync_faults()
-        if bits == FAULT_F16_RANGE and self.options.get("conv_mode", 0) == 0:
+        self.last_fallback = False
+        if bits == FAULT_F16_RANGE and self.get_option("conv_mode") == 0:
             print("dmpfold2_amd: activations left the f16 range of the split-product convolution; "
                   "re-running this alignment with conv_mode=2 (bf16 split, no range limit)",
                   file=sys.stderr)
+            self.last_fallback = True
             self.set_option("conv_mode", 2)
             try:
                 coords, confs = self.predict_device(d_msa, template_ca, iterations, minsteps)
@@ -546,23 +552,32 @@ class Pipeline:
         whose prediction recorded a device-side fault (its outputs are NaN) is repeated alone through
         `Engine.predict_device_checked` - which falls back to the range-free convolution where that
         is the cure - and only if that fails too its entry is the exception.  One bad target never
-        costs the others their results."""
+        costs the others their results.  Once one repeat needed the range-free convolution the
+        remaining repeats run in it directly (the weights, not the alignment, put a trunk outside the
+        f16 range: the others would only fault again first), with one note on stderr for all of them."""
         self.drain()
         bits = 0
         for e in self.engines:
             bits |= e.sync_faults()
         out = {}
-        for t in tickets:
-            job = self._jobs.get(t)
-            coords, confs = self.result(t)
-            if bits and bool(torch.isnan(confs[0])):
-                _, d_msa, nloops, minsteps, d_tpl = job
-                try:
-                    coords, confs = self.engines[0].predict_device_checked(d_msa, d_tpl, nloops, minsteps)
-                except (IndexError, _lib.DmpError) as exc:
-                    out[t] = exc
-                    continue
-            out[t] = (coords, confs)
+        eng = self.engines[0]
+        mode0 = eng.get_option("conv_mode")
+        try:
+            for t in tickets:
+                job = self._jobs.get(t)
+                coords, confs = self.result(t)
+                if bits and bool(torch.isnan(confs[0])):
+                    _, d_msa, nloops, minsteps, d_tpl = job
+                    try:
+                        coords, confs = eng.predict_device_checked(d_msa, d_tpl, nloops, minsteps)
+                        if eng.last_fallback:
+                            eng.set_option("conv_mode", 2)
+                    except (IndexError, _lib.DmpError) as exc:
+                        out[t] = exc
+                        continue
+                out[t] = (coords, confs)
+        finally:
+            eng.set_option("conv_mode", mode0)
         return out
 
     def run(self, d_msas, iterations=default_iterations, minsteps=default_minsteps):

@@ -71,7 +71,7 @@ def _uniform(rng, shape, bound):
     return ((2.0 * u - 1.0) * bound).astype(np.float32)
 
 
-def synth_weights(seed: int = 0, coord_scale: float = 1.0):
+def synth_weights(seed: int = 0, coord_scale: float = 1.0, act_scale: float = 1.0):
     """Synthetic ``state_dict`` (name -> float32 ndarray).
 
     Scale rules follow the reference's initialisers so activations stay in a
@@ -79,7 +79,10 @@ def synth_weights(seed: int = 0, coord_scale: float = 1.0):
     per-block gain 1/sqrt(block) of network.py:20-23; InstanceNorm gamma
     1+-0.2 and beta +-0.5 (non-trivial, so the cSE gate is exercised).
     ``coord_fc`` is scaled so C-alpha traces span tens of Angstroms rather
-    than collapsing onto a point.
+    than collapsing onto a point.  ``act_scale`` multiplies every InstanceNorm
+    gamma and beta (1.0 leaves the bytes of the default set unchanged): the
+    residual stream of the pair trunk grows by about that factor per block, a
+    second activation regime for the parity fixtures.
     """
     rng = np.random.Generator(np.random.Philox(key=int(seed) + 0x5EED))
     sd = {}
@@ -90,9 +93,9 @@ def synth_weights(seed: int = 0, coord_scale: float = 1.0):
             hid = shape[0] // 3
             w = _uniform(rng, shape, 1.0 / sqrt(hid))
         elif name.endswith("norm.weight"):
-            w = 1.0 + _uniform(rng, shape, 0.2)
+            w = np.float32(act_scale) * (1.0 + _uniform(rng, shape, 0.2))
         elif name.endswith("norm.bias"):
-            w = _uniform(rng, shape, 0.5)
+            w = np.float32(act_scale) * _uniform(rng, shape, 0.5)
         elif name.endswith("lin.weight"):
             cout, cin, kh, kw = shape
             block = int(name.split(".")[1])

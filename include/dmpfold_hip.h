@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define DMP_ABI_VERSION 1
+/* 2: dmp_sync_check returns DMP_ERR_FAULT / DMP_ERR_ARG (was DMP_ERR_HIP), dmp_sync_faults clears what it
+ *    reports, dmp_ctx_get_option and dmp_dca_features added. */
+#define DMP_ABI_VERSION 2
 #define DMP_MAX_SEQS 3000 /* predict.py:130-132: deeper MSAs are truncated */
 
 typedef struct dmp_ctx dmp_ctx;
@@ -75,6 +77,8 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * of a cluster of 16 that hands the coordinates over every step; same iteration, different
  * partial-sum slices (results agree to float32 rounding). */
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value);
+/* Current value of an option of dmp_ctx_set_option ("conv_f32_exact" reads as conv_mode == 1). */
+int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value);
 /* Reset the device-side fault words read by dmp_sync_faults (enqueued on `stream`). */
 int dmp_clear_faults(dmp_ctx* ctx, void* stream);
 
@@ -107,6 +111,14 @@ int dmp_spd_inverse(dmp_ctx* ctx, float* d_A, int D, void* stream);
 /* predict.py:58-60: APC-corrected contact channel (L x L) from the inverse covariance.
  * The 441 coupling channels are never materialised: the stem reads d_inv in place. */
 int dmp_dca_contacts(dmp_ctx* ctx, const float* d_inv, int L, float* d_contacts, void* stream);
+
+/* reweight() + fast_dca() in one call, with fast_dca's return value laid out as the reference returns it
+ * (predict.py:41-61; train.py:175-190 computes the same tensor in its data loader): d_out (L x L x 442),
+ * d_out[i][j][21a+b] = inv_cov[21i+a][21j+b], d_out[i][j][441] = APC-corrected contacts.  N = 1 gives zeros
+ * (the glue of predict.py:139).  The prediction path itself never builds this tensor (the stem reads the
+ * inverse in place); this export is for consumers that want the features themselves.  Uses the context's
+ * covariance workspace: not to be interleaved with a prediction on the same context. */
+int dmp_dca_features(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_out, void* stream);
 
 /* ---- sequence trunk ------------------------------------------------------------------- */
 /* embed + vgru, network.py:223-224: 2-layer GRU down the alignment (time = N, batch = L);

@@ -61,6 +61,13 @@ class Stages:
         self.call("dmp_dca_contacts", inv, L, out)
         return out
 
+    def dca_features(self, alnmat):
+        m = self.to(alnmat, torch.uint8)
+        n, L = m.shape
+        out = self.f32(L, L, 442)
+        self.call("dmp_dca_features", m, n, L, out)
+        return out
+
     def gru_vertical(self, alnmat):
         m = self.to(alnmat, torch.uint8)
         n, L = m.shape

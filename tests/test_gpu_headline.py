@@ -206,7 +206,7 @@ def test_f16_range_fault_is_reported_poisoned_and_cured(synth_sd, tmp_path, caps
         c, f = eng.predict_checked(alnmat, None, 1, 0)
         assert "conv_mode=2" in capsys.readouterr().err
         assert ca_rmsd(c.cpu().numpy()[:, 1], ref_c.numpy()[:, 1]) <= 1e-3
-        assert eng.options["conv_mode"] == 0
+        assert eng.get_option("conv_mode") == 0
     finally:
         eng.close()
     # the public function: same cure through aln_to_coords, and the engine is healthy afterwards

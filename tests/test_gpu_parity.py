@@ -93,6 +93,34 @@ def test_covariance_inverse_contacts(st, pf, ocap):
     assert np.abs(con - pf["contacts"]).max() <= scale_tol(cref, 1e-5)     # golden from the reference
 
 
+@pytest.mark.parametrize("name", ["pf10963_n0_m0", "synth_L40_N64_n2_m0"])
+def test_dca_features_layout_vs_reference(st, name):
+    """dmp_dca_features = fast_dca's return value (L, L, 442) in the reference's own layout
+    (predict.py:54-61), against the samples / checksums the goldens hold of the tensor the REFERENCE
+    returned: all 441 coupling channels and the contact channel, by flat index."""
+    g = load_golden(name)
+    f = st.dca_features(g["alnmat"]).cpu().numpy()
+    L = g["alnmat"].shape[1]
+    assert f.shape == (L, L, 442)
+    flat = f.ravel()
+    ref = g["f2d.val"]
+    assert np.abs(flat[g["f2d.idx"]] - ref).max() <= scale_tol(ref, 1e-5)
+    assert abs(flat.astype(np.float64).sum() - float(g["f2d.sum"])) <= 1e-5 * max(1.0, np.abs(flat).sum())
+    assert abs((flat.astype(np.float64) ** 2).sum() - float(g["f2d.sumsq"])) <= 2e-5 * float(g["f2d.sumsq"])
+    assert np.abs(f[:, :, 441] - g["contacts"]).max() <= scale_tol(g["contacts"], 1e-5)
+    # the layout itself: channel 21a+b of pair (i, j) is inv_cov[21i+a, 21j+b]
+    st.eng.predict(g["alnmat"], None, 0, 0)
+    st.eng.sync_check()
+    inv = st.eng.fetch("inv_cov", (21 * L) ** 2).cpu().numpy().reshape(L, 21, L, 21)
+    assert np.array_equal(f[:, :, :441].reshape(L, L, 21, 21), inv.transpose(0, 2, 1, 3))
+
+
+def test_dca_features_single_sequence_is_zero(st):
+    """predict.py:139: no covariance features for a one-row alignment."""
+    a = np.random.default_rng(0).integers(0, 20, size=(1, 17)).astype(np.uint8)
+    assert not st.dca_features(a).cpu().numpy().any()
+
+
 def test_spd_inverse_identity_property(st):
     rng = np.random.default_rng(3)
     for D in (21 * 9, 21 * 13 + 0, 300):

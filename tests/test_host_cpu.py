@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # the ctypes binding covers the same set
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().dmp_abi_version() == 1
+    assert _lib.load().dmp_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_residue_encoding_all_bytes():
@@ -325,6 +325,13 @@ def test_batch_inputs_and_output_variants(tmp_path):
     lone.write_text("ACDEFGHIKL\n")
     got = expand_inputs([str(d), str(lone)])
     assert [os.path.basename(a) for a, _ in got] == ["a.a3m", "b.aln", "c.aln", "x.aln"] and all(t is None for _, t in got)
+    # the README workflow leaves x.a3m beside its x.aln: only the .aln is a target (both would be written to x.pdb)
+    (d / "a.aln").write_text("ACDEFGHIKL\n")
+    assert [os.path.basename(a) for a, _ in expand_inputs([str(d)])] == ["a.aln", "b.aln", "c.aln"]
+    from dmpfold2_amd.batch import check_output_stems
+    check_output_stems(expand_inputs([str(d), str(lone)]))
+    with pytest.raises(ValueError, match="both be written"):
+        check_output_stems([(str(d / "b.aln"), None), (str(tmp_path / "other" / "b.a3m"), None)])
     g = load_golden("pf10963_default_cli")
     coords, confs = torch.from_numpy(g["coords"]), torch.from_numpy(g["confs"])
     full = bytes(g["cli_stdout"]).decode()
@@ -356,3 +363,124 @@ def test_empty_alignment_raises_index_error(tmp_path):
             predict.encode_aln(predict.read_aln(str(p)))
         with pytest.raises(IndexError):
             O.encode_aln(O.read_aln(str(p)))
+
+
+# ---------------------------------------------------------------------------- round 3
+class _FakePipeline:
+    """Stands in for the GPU scheduler in the host-logic tests of run_batch: the 'prediction' of a target is
+    a function of its alignment only, so results can be compared across shardings."""
+    made = 0
+
+    def __init__(self, device, max_L, max_N, state_dict, streams=2, stagger=False):
+        _FakePipeline.made += 1
+        self.jobs, self.max_L, self.max_N = [], max_L, max_N
+
+    def submit(self, d_msa, iterations, minsteps, template_ca=None):
+        assert d_msa.shape[1] <= self.max_L and d_msa.shape[0] <= self.max_N
+        self.jobs.append(d_msa)
+        return len(self.jobs) - 1
+
+    def pump(self):
+        pass
+
+    def collect(self, tickets):
+        out = {}
+        for t in tickets:
+            m = self.jobs[t]
+            L = m.shape[1]
+            base = m.float().mean() + torch.arange(L * 15, dtype=torch.float32).reshape(L, 5, 3) * 0.01
+            out[t] = (base, torch.full((L,), float(m.shape[0]) / 1000.0))
+        return out
+
+    def close(self):
+        pass
+
+
+def _write_synth_targets(folder, count, seed=0):
+    rng = np.random.default_rng(seed)
+    paths = []
+    for i in range(count):
+        L, N = int(rng.integers(20, 61)), int(rng.integers(2, 40))
+        p = folder / f"t{i:03d}.aln"
+        synth.write_aln(str(p), synth.synth_msa(L, N, seed=1000 + i))
+        paths.append((str(p), None))
+    return paths
+
+
+def test_run_batch_256_targets_world_8_each_exactly_once(tmp_path, monkeypatch):
+    """BASELINE configs[3] at its own count on the host side: 256 targets, 8 ranks (run one after the other
+    here).  Every target is written exactly once, by the rank that owns it; a rank reads and encodes ONLY its
+    own targets (the partition comes from a header scan); results do not depend on the sharding."""
+    from dmpfold2_amd import batch
+    monkeypatch.setattr(batch, "Pipeline", _FakePipeline)
+    d = tmp_path / "msas"
+    d.mkdir()
+    targets = _write_synth_targets(d, 256)
+    reads = []
+    real_read = batch.read_aln
+    monkeypatch.setattr(batch, "read_aln", lambda p: (reads.append(p), real_read(p))[1])
+    outs, owners = {}, {}
+    for rank in range(8):
+        before = len(reads)
+        n, _, written = batch.run_batch(targets, str(tmp_path / f"out8"), 1, 0, state_dict={}, device="cpu",
+                                        rank=rank, world=8)
+        mine = batch.plan_shard(targets, 1, rank, 8)
+        assert n == len(mine) == len(written) == len(reads) - before      # parsed its own shard, nothing else
+        assert sorted(reads[before:]) == sorted(targets[i][0] for i in mine)
+        for path in written:
+            assert path not in outs
+            outs[path] = open(path).read()
+            owners[path] = rank
+    assert len(outs) == 256 and len(set(reads)) == 256 and len(reads) == 256
+    loads = np.bincount(list(owners.values()), minlength=8)
+    assert loads.min() >= 16                                              # no rank starves
+    # one rank alone writes the same bytes
+    n, _, written = batch.run_batch(targets, str(tmp_path / "out1"), 1, 0, state_dict={}, device="cpu")
+    assert n == 256
+    for path in written:
+        assert open(path).read() == outs[os.path.join(str(tmp_path / "out8"), os.path.basename(path))]
+
+
+def test_scan_target_estimates_without_parsing(tmp_path):
+    from dmpfold2_amd.batch import scan_target
+    p = tmp_path / "x.aln"
+    synth.write_aln(str(p), synth.synth_msa(57, 123, 4))
+    assert scan_target(str(p)) == (57, 123)
+    a3m = tmp_path / "y.a3m"
+    a3m.write_text(">q\nACDEFGHIKL\n>h1\nACdeDEFGHIKL\n>h2\nACDEFGHIKL\n")
+    L, N = scan_target(str(a3m))
+    assert L == 10 and 1 <= N <= 4
+    assert scan_target(str(tmp_path / "missing.aln")) == (0, 0)
+
+
+def test_batch_unreadable_file_fails_that_target_only(tmp_path, monkeypatch):
+    """a missing / undecodable alignment is that target's failure, not the shard's."""
+    from dmpfold2_amd import batch
+    monkeypatch.setattr(batch, "Pipeline", _FakePipeline)
+    good = tmp_path / "good.aln"
+    synth.write_aln(str(good), synth.synth_msa(24, 5, 1))
+    binary = tmp_path / "binary.aln"
+    binary.write_bytes(b"ACDE\xff\xfeFGH\nACDEFGHIK\n")
+    with pytest.raises(batch.BatchFailures) as ei:
+        batch.run_batch([(str(tmp_path / "nope.aln"), None), (str(good), None), (str(binary), None)],
+                        str(tmp_path / "out"), 0, 0, state_dict={}, device="cpu")
+    kinds = {os.path.basename(a): type(e) for a, e in ei.value.failed}
+    assert kinds["nope.aln"] is FileNotFoundError and issubclass(kinds["binary.aln"], (UnicodeDecodeError, ValueError, IndexError))
+    assert [os.path.basename(p) for p in ei.value.outputs] == ["good.pdb"]
+
+
+def test_bench_stub_world_8_over_gloo():
+    """The driver's 8-rank command line (torch.distributed.run, one process per GPU) through bench.py's launch,
+    barrier and max-over-ranks code with the stand-in workload: ONE JSON line, n_gpus = ranks = 8."""
+    import json
+    env = dict(os.environ, DMP_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks"] == 8
+    assert out["ms_per_step"] >= 0.02 * 8 * 1e3 * 0.95           # the slowest rank (rank 7) sets the time
