@@ -32,6 +32,7 @@ SIGNATURES = {
     "dmp_dca_contacts": (_i, [_vp, _fp, _i, _fp, _vp]),
     "dmp_dca_features": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "dmp_gru_vertical": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
+    "dmp_gru_vertical_group": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp), _vp]),
     "dmp_gru_bidir": (_i, [_vp, _i, _fp, _i, _fp, _vp]),
     "dmp_stem_static": (_i, [_vp, _fp, _fp, _fp, _i, _fp, _vp]),
     "dmp_stem_update": (_i, [_vp, _fp, _fp, _i, _fp, _vp]),

@@ -384,7 +384,9 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   c->max_N = max_N;
   c->max_passes = 128;
   const int64_t L = max_L, N = max_N, D = NS * L, LL = L * L;
-  const int64_t Lb = round_up(max_L, 64), P = act_pitch(max_L), T = act_tiles(max_L);   // 64 = vertical-GRU column tile
+  // vertical-GRU state: the members of a group side by side (up to 4 alignments of max_L columns, 32-column tiles)
+  c->vg_cap_cols = 4 * round_up(max_L, 64);
+  const int64_t Lb = c->vg_cap_cols, P = act_pitch(max_L), T = act_tiles(max_L);
   int rc = 0;
 #define A_(field, count) if (!rc) rc = dev_alloc(c->allocs, c->bytes, &c->field, (count))
   A_(msa_words, N * cdiv64(L, 4));
@@ -406,7 +408,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
       A_(hT[l][p], (int64_t)WIDTH * Lb);
       A_(hH[l][p], (int64_t)2 * WIDTH * Lb);
     }
-  A_(vgru_run, 64);
+  A_(vgru_run, 256);                 // VRun (legacy) / VGroupRec (vgru.hip)
   A_(vout, L * WIDTH);
   A_(seq_g, L * 1536);
   A_(seq_a, L * WIDTH);
@@ -444,6 +446,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   if (hipMemset(c->seq_abort, 0, 2 * sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
   if ((rc = trunk_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
   if ((rc = mds_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
+  if ((rc = vgru_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
   for (int i = 0; i < 2; ++i) {
     hipEvent_t e;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
@@ -467,6 +470,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "conv_f32_exact") { ctx->conv_mode = value ? 1 : 0; return DMP_OK; }
   if (k == "tridiag_single") { ctx->tridiag_single = value ? 1 : 0; return DMP_OK; }
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
+  if (k == "vgru_legacy") { ctx->vgru_legacy = value ? 1 : 0; return DMP_OK; }
   if (k == "conv_mode") {
     DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
     ctx->conv_mode = value;
@@ -483,6 +487,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "conv_f32_exact") { *h_value = ctx->conv_mode == 1; return DMP_OK; }
   if (k == "tridiag_single") { *h_value = ctx->tridiag_single; return DMP_OK; }
   if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
+  if (k == "vgru_legacy") { *h_value = ctx->vgru_legacy; return DMP_OK; }
   set_error("unknown option %s", name);
   return DMP_ERR_ARG;
 }
@@ -562,6 +567,15 @@ int dmp_weights_finalize(dmp_ctx* c) {
       set_error("missing key %s in state_dict", k.key.c_str());
       return DMP_ERR_WEIGHTS;
     }
+  {
+    uint64_t h = 1469598103934665603ull;               // FNV-1a over keys and bytes, in spec order
+    for (const auto& k : spec) {
+      const auto& v = c->W.host[k.key];
+      const unsigned char* b = reinterpret_cast<const unsigned char*>(v.data());
+      for (size_t i = 0; i < v.size() * sizeof(float); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    }
+    c->W.hash = h;
+  }
   DMP_HIP(hipSetDevice(c->device));
   for (void* p : c->W.allocs) { (void)hipFree(p); }
   c->W.allocs.clear();
@@ -636,6 +650,26 @@ int dmp_gru_vertical(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_
   CHECK_W();
   DMP_ARG(d_msa && d_out && N >= 1, "bad argument");
   return gru_vertical(ctx, d_msa, N, L, d_out, STREAM);
+}
+
+int dmp_gru_vertical_group(dmp_ctx* const* ctxs, int n, const uint8_t* const* d_msas, const int* Ns,
+                           const int* Ls, float* const* d_outs, void* stream) {
+  DMP_ARG(ctxs && d_msas && Ns && Ls && d_outs && n >= 1 && n <= 8, "bad argument");
+  int maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    dmp_ctx* ctx = ctxs[i];
+    DMP_ARG(ctx && d_msas[i] && d_outs[i] && Ns[i] >= 1, "bad argument for member %d", i);
+    CHECK_CAP(Ls[i], Ns[i]);
+    CHECK_W();
+    DMP_ARG(ctx->device == ctxs[0]->device, "the members of a group must live on one GPU");
+    maxN = std::max(maxN, Ns[i]);
+  }
+  int rc;
+  if ((rc = vgru_group_setup(ctxs[0], ctxs, d_msas, Ns, Ls, n, STREAM))) return rc;
+  if ((rc = vgru_group_steps(ctxs[0], 0, maxN + 1, STREAM))) return rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = vgru_group_output(ctxs[0], i, Ns[i], Ls[i], d_outs[i], STREAM))) return rc;
+  return DMP_OK;
 }
 
 int dmp_gru_bidir(dmp_ctx* ctx, int which, const float* d_in, int T, float* d_out, void* stream) {

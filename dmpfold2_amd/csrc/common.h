@@ -76,6 +76,7 @@ struct BlockW {
 
 struct Weights {
   bool ready = false;
+  uint64_t hash = 0;                                       // FNV-1a of the tensors handed over (equal weights <=> equal hash)
   std::map<std::string, std::vector<float>> host;          // raw tensors by key
   std::map<std::string, std::vector<int64_t>> shapes;
   // vertical GRU: f16 pieces of scale*W, [piece 2][gate 3][k/8][512][8] (see vgru.hip)
@@ -132,9 +133,13 @@ struct dmp_ctx {
   float* x3 = nullptr;
   double* apc_sums = nullptr;  // [2L+1]
   // sequence trunk
-  float* hT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [layer][parity][128][Lb][4] float32 state
+  float* hT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [layer][parity][128][Lb][4] float32 state (Lb: the group's columns)
   uint16_t* hH[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // same state as f16 pieces [2][64][Lb][8]
-  uint8_t* vgru_run = nullptr;             // device VRun record read by the graph's step kernels
+  uint8_t* vgru_run = nullptr;             // device VRun / VRun2 record read by the graph's step kernels
+  int vg_ntiles = 0, vg_maxN = 0;          // group this context leads (vgru.hip): column tiles, deepest member alignment
+  int vg_tile0[8] = {0};                   // ... first column tile of every member
+  int vg_cap_cols = 0;                     // columns the state buffers hold (a group's members side by side)
+  int vgru_legacy = 0;                     // option: 1 = the round-2 step kernel (one target per launch, K split over waves)
   std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
   std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain
   int tridiag_single = 0;                  // option: 1 = single-workgroup tridiagonalisation
@@ -228,6 +233,14 @@ int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, h
 // writes d_out)
 int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
                        hipStream_t s);
+// Vertical GRUs of several contexts in ONE launch per alignment row (vgru.hip): setup writes the column-tile
+// records of all members into the leader's buffer and clears their states, steps runs rows [t_lo, t_hi), output
+// hands a member its L x 512 result.
+int vgru_kernel_attrs(dmp_ctx* c);
+int vgru_group_setup(dmp_ctx* lead, dmp_ctx* const* members, const uint8_t* const* msas, const int* Ns,
+                     const int* Ls, int n, hipStream_t s);
+int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s);
+int vgru_group_output(dmp_ctx* lead, int member_index, int N, int L, float* d_out, hipStream_t s);
 int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hipStream_t s);
 // trunk.hip
 int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const float* d_contacts,

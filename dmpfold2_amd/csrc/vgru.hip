@@ -250,16 +250,394 @@ void vgru_step_kernel(VStatic st, const VRun* __restrict__ run, int idx) {
       make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
 }
 
+
+// =====================================================================================================
+// Round 3: the GROUP step kernel.  One launch per alignment row serves the columns of several targets
+// (contexts) at once, and inside a workgroup the weight fragments are fetched ONCE and shared by the
+// waves through LDS.
+//
+//   unit of work   one wave = one (32 hidden x 32 column) tile of ONE product (layer 1: recurrent W_hh h1 or
+//                  input W_ih h0; layer 0: recurrent W_hh h0 + the one-hot input), the whole K = 512 in one
+//                  accumulator chain per gate: 32 k-steps x 9 MFMAs = 288 MFMAs, the same for every wave
+//   workgroup      2 NW waves on one hidden tile: layer 1 = NW column tiles x {recurrent, input} (the two
+//                  products of a column tile meet through LDS in the epilogue), layer 0 = 2 NW column tiles.
+//                  The weight fragments of a product (6 KB per k-step: 2 pieces x 3 gates) are streamed into an
+//                  LDS ring by LDS-DMA (global_load_lds_dwordx4), two k-steps per slot, three slots, and read by
+//                  all waves of the product; each wave streams the state fragments of its own column tile
+//                  into registers one slot ahead.  All VMEM traffic of the main loop is inline asm with
+//                  counted waits (the compiler would otherwise drain the DMA queue at every use).
+//   traffic        per workgroup and step (layer 1, NW = 4): weights 2 x 196 KB once + state 8 x 64 KB, for the
+//                  work the round-2 kernel pulled 4 x (393 + 128) KB for; the column tiles of a launch may belong
+//                  to different contexts (VTile), so four targets' GRUs cost 215 MB of L2 reads per step
+//                  instead of 4 x 123 MB
+//   arithmetic     identical whatever NW and whatever the grouping: a tile's result depends only on its own
+//                  operands (accumulation order k = 0..511 for the recurrent product, then the exchange adds
+//                  recurrent + input), so a target predicted alone and in a group gives the same bits.
+// Block b runs on XCD b % 8; XCD x owns hidden tiles 2x, 2x+1 (1.2 MB of weight pieces stay in its L2).
+// =====================================================================================================
+#ifndef VG_CK_N
+#define VG_CK_N 2       // measured: 4 k-steps per slot with 2 or 3 slots (half the barriers, 96-144 KB of LDS) gives the
+#endif                  // same step time as 2 x 3 (72 KB): the loop is bound by what a CU's vector memory path delivers
+#ifndef VG_R_N
+#define VG_R_N 3
+#endif
+constexpr int VG_CK = VG_CK_N;                            // k-steps (16 k each) per ring slot (2 or 4)
+constexpr int VG_R = VG_R_N;                              // ring slots per product: the weight DMA runs VG_R - 1 slots ahead
+static_assert((VG_CK == 2 || VG_CK == 4) && VG_R >= 2 && VG_R <= 3, "unsupported ring shape");
+constexpr int VG_FRAGS = 6;                               // weight fragments per k-step: piece x gate
+constexpr int VG_NC = 32 / VG_CK;                         // slots per K = 512 product
+constexpr int VG_RING_SLOTS = VG_R * VG_CK * VG_FRAGS * 64;   // 16-byte slots of one product's ring (36 KB)
+constexpr int VG2_LDS_BYTES = 2 * VG_RING_SLOTS * 16;     // 73 728: two products
+constexpr int VG_MAX_MEMBERS = 8;                         // contexts served by one group launch
+
+// The state of a group lives in the LEADER's buffers as one wide alignment: member m owns the column tiles
+// [tile0, tile0 + ceil(L / 32)), the column pitch is 32 x (number of tiles of the group).  A step kernel therefore
+// derives every address of its main loop from its kernel arguments; the record below (device memory, cold at
+// every kernel start) is only needed for what happens after the loop: is the tile active at this row, and which
+// residue codes does layer 0 read.
+struct VMember { const uint8_t* msa; int N, L, tile0, pad; };
+struct VGroupRec { int t0, t_end, nmem, pad; VMember mem[VG_MAX_MEMBERS]; };
+static_assert(sizeof(VGroupRec) <= 256, "dmp_ctx_create sizes vgru_run for 256 bytes");
+
+__global__ void vgru_set_group_kernel(VGroupRec* rec, VGroupRec v) { *rec = v; }
+__global__ void vgru_set_run2_kernel(VGroupRec* rec, int t0, int t_end) { rec->t0 = t0; rec->t_end = t_end; }
+
+typedef unsigned vg_u32x4 __attribute__((ext_vector_type(4)));
+
+// Gate functions on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): sigma(x) =
+// 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 sigma(-2x).  Absolute error below 2e-7 over the whole range (saturating
+// correctly at +-1 / 0 / 1), a tenth of the float32 rounding of the 1024-term sums they are fed with; the device
+// library's expf / tanhf cost 4.8 us per step (8 evaluations per lane, dependent chains) - measured, more than
+// the matrix products.
+__device__ __forceinline__ float vg_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.442695040888963f));
+}
+__device__ __forceinline__ float vg_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
+}
+
+__device__ __forceinline__ void vg_dma16(const void* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ vg_u32x4 vg_gload16(const void* gsrc) {
+  vg_u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(gsrc) : "memory");
+  return v;
+}
+// wait until at most N VMEM operations of this wave are outstanding; the state fragments about to be used are
+// threaded through the statement so that no MFMA that reads them can be scheduled above it
+template <int N> __device__ __forceinline__ void vg_wait(vg_u32x4 (&b)[VG_CK][2]) {
+#if VG_CK_N == 2
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N) : "memory");
+#else
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]),
+                                       "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1]) : "n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ f32x16 vg_mfma2(uint4 a, vg_u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vg_f16x8, a), __builtin_bit_cast(vg_f16x8, b),
+                                                c, 0, 0, 0);
+}
+
+// cgs = column groups of the XCD map (1, 2 or 4): XCD x works on hidden group x / cgs (16 / (8 / cgs) = 2 cgs hidden
+// tiles) and on the supertiles st with st % cgs == x % cgs.
+__host__ __device__ inline int vgru2_grid(int ntiles, int nw, int cgs) {
+  const int nst = (ntiles + nw - 1) / nw;
+  return 8 * 3 * cgs * ((nst + cgs - 1) / cgs);
+}
+
+// grid: vgru2_grid(ntiles, NW)   block: 128 NW   dynamic LDS: VG2_LDS_BYTES
+// Per hidden-tile pair and supertile (NW column tiles): two layer-1 workgroups (one per hidden tile; halves = the
+// recurrent and the input product) and one layer-0 workgroup (halves = the two hidden tiles).  Every wave belongs
+// to a half of NW waves that feeds and reads its own weight ring, so all waves run the same VMEM schedule.
+// XCD map.  The L2 of an XCD keeps nothing across a kernel boundary (PMC: 24 MB of fabric reads per step for one
+// target = every weight piece + every XCD's copy of the state), so a step costs what the XCDs pull over the
+// fabric: weights x (column groups) + state x (hidden groups).  One target: cgs = 1 (9.4 + 10.5 MB); four
+// targets: cgs = 2 (18.8 + 21 MB instead of 9.4 + 42).
+template <int NW>
+__global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const VGroupRec* __restrict__ rec,
+                                                             int idx, int cgs, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vg2_smem[];
+  constexpr int D = VG_CK * VG_FRAGS / NW;            // LDS-DMA instructions per slot and wave
+  // Every address of the main loop comes from the kernel arguments: with a cold L2 (see above) a dependent global
+  // read at the head of a step costs 1-2 us, so the weight and state streams start at once and the group record
+  // (which row is this, is the tile still active, where are its residue codes) is consumed after the loop.  The
+  // buffer parity of a row is the parity of the node index: chains start at even rows.
+  const int nst = (ntiles + NW - 1) / NW, nsth = (nst + cgs - 1) / cgs;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nj = 2 * cgs, hg = xcd / cgs, cg = xcd % cgs;     // hidden tiles hg nj .. hg nj + nj - 1
+  if (slot >= 3 * cgs * nsth) return;
+  const int layer = slot < nj * nsth ? 1 : 0;
+  const int s2 = slot - nj * nsth;
+  const int st_i = (layer ? slot / nj : s2 / cgs) * cgs + cg;
+  if (st_i >= nst) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kk = lane >> 5, li = lane & 31;
+  const int half = w / NW, wl = w % NW;               // the half's ring; index inside the half = column tile
+  const int prod = layer ? half : 0;                  // layer 1: 0 = recurrent (h1), 1 = input (h0)
+  const int j0 = (hg * nj + (layer ? slot % nj : 2 * (s2 % cgs) + half)) * 32;
+  const int tix = st_i * NW + wl;                     // a wave past the last tile shadows tile 0 and stores nothing
+  const int tcol = (tix < ntiles ? tix : 0) * VG_TB;  // first column of the tile in the group's state
+  const int Lb = ntiles * VG_TB;                      // column pitch of the group's state
+  const int par = idx & 1;    // layer 0 reads parity t, writes t+1; layer 1 (step t-1) reads t+1, writes t
+  const uint4* wbase = layer ? (prod ? st.wx[1] : st.wh[1]) : st.wh[0];
+  const uint4* wsrc = wbase + (int64_t)kk * 512 + j0 + li;                        // + (f*64 + 2s) * 512
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)vg2_smem;
+  const unsigned ring_addr = lds_base + half * (VG_RING_SLOTS * 16);
+  const uint4* ring_l = reinterpret_cast<const uint4*>(vg2_smem) + half * VG_RING_SLOTS + lane;
+#ifdef VG_DBG_NOTHING
+  if (ntiles > 0) return;
+#endif
+
+  auto dma_slot = [&](int c) {                        // this wave's share of slot c (weights of k-steps 2c, 2c+1)
+    const unsigned dst = ring_addr + (unsigned)((c % VG_R) * VG_CK * VG_FRAGS) * 1024u;
+#pragma unroll
+    for (int n = 0; n < D; ++n) {
+      const int i = wl + n * NW, ks = i / VG_FRAGS, f = i - ks * VG_FRAGS;
+#ifdef VG_DBG_SAMEADDR
+      vg_dma16(wsrc + (int64_t)(f * 64 + 2 * ks) * 512, dst + (unsigned)i * 1024u);
+#else
+      vg_dma16(wsrc + (int64_t)(f * 64 + 2 * (c * VG_CK + ks)) * 512, dst + (unsigned)i * 1024u);
+#endif
+    }
+  };
+  constexpr int DIST = VG_R - 1;                      // the weight DMA runs DIST slots ahead of the MFMAs
+#pragma unroll
+  for (int i = 0; i < DIST; ++i) dma_slot(i);
+  const uint16_t* hsrc = layer ? (prod ? st.hH[0][par] : st.hH[1][par ^ 1]) : st.hH[0][par];
+  const uint4* xsrc = reinterpret_cast<const uint4*>(hsrc) + (int64_t)kk * Lb + tcol + li;   // + (p*64 + 2s) * Lb
+  const float* hprev = layer ? st.hT[1][par ^ 1] : st.hT[0][par];
+  // the group record: requested now (scalar loads), first used after the main loop
+  const int t = rec->t0 + idx;
+  const int t_end = rec->t_end, nmem = rec->nmem;
+  int mi = 0;
+  for (int m = 1; m < VG_MAX_MEMBERS; ++m)
+    if (m < nmem && tix >= rec->mem[m].tile0) mi = m;
+  const VMember M = rec->mem[mi];
+  const int N = M.N, L = M.L, b0 = (tix - M.tile0) * VG_TB;          // b0: the tile's first column in ITS alignment
+  // What the epilogue will read - biases, the tile's previous state - is touched now (one word
+  // per 128-byte line, results discarded) so that it is in the L2 by then.  The touches land in ONE register that
+  // stays allocated until the first counted wait has retired them (a dead asm output would be handed to another
+  // value and overwritten when the data arrives).
+  unsigned pf = 0;
+  {
+    const unsigned char* q;
+    if (lane < 4) q = reinterpret_cast<const unsigned char*>(st.bias[layer] + lane * 512 + j0);
+    else q = reinterpret_cast<const unsigned char*>(hprev + ((int64_t)((j0 >> 2) + (((lane - 4) >> 2) & 7)) * Lb + tcol) * 4) + ((lane - 4) & 3) * 128;
+    asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory");
+    if (layer == 0) {
+      // layer 0's one-hot input weights (24 rows of 512 bytes: piece, gate, k octet): 96 lines, read after the loop
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int line = (n * 64 + lane) % 96;
+        q = reinterpret_cast<const unsigned char*>(st.wx[0] + (int64_t)(line >> 2) * 512 + j0) + (line & 3) * 128;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory");
+      }
+    }
+  }
+  // The state fragments are asm loads the compiler does not count: every one of them is unconditional and is
+  // waited for by exactly one statement that names its registers, so that no copy of a register can be placed
+  // between a load and its wait (a conditional load or a wait chosen by a branch makes the compiler merge
+  // registers with v_mov BEFORE the data has landed - seen, as NaNs in every second column tile).
+  auto load_b = [&](vg_u32x4 (&b)[VG_CK][2], int c) {
+#pragma unroll
+    for (int ks = 0; ks < VG_CK; ++ks)
+#pragma unroll
+#ifdef VG_DBG_SAMEADDR
+      for (int p = 0; p < 2; ++p) b[ks][p] = vg_gload16(xsrc + (int64_t)(p * 64 + 2 * ks) * Lb);
+#else
+      for (int p = 0; p < 2; ++p) b[ks][p] = vg_gload16(xsrc + (int64_t)(p * 64 + 2 * (c * VG_CK + ks)) * Lb);
+#endif
+  };
+
+  f32x16 acc_r, acc_z, acc_t, acc_in;     // r, z, third gate (recurrent: W_hn h; input: W_in x); layer 0: + W_in x
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_t[r] = 0.f; acc_in[r] = 0.f; }
+
+  auto compute = [&](const vg_u32x4 (&b)[VG_CK][2], int c) {
+    const uint4* a_l = ring_l + (c % VG_R) * (VG_CK * VG_FRAGS * 64);
+#pragma unroll
+    for (int ks = 0; ks < VG_CK; ++ks) {
+      uint4 a[VG_FRAGS];                               // a[piece * 3 + gate]
+#pragma unroll
+      for (int f = 0; f < VG_FRAGS; ++f) a[f] = a_l[(ks * VG_FRAGS + f) * 64];
+#ifdef VG_DBG_NOMFMA
+      acc_r[0] += __builtin_bit_cast(float, a[0].x ^ a[1].y ^ a[2].z ^ a[3].w ^ a[4].x ^ a[5].y ^ b[ks][0].x ^ b[ks][1].y);
+      continue;
+#endif
+      acc_r = vg_mfma2(a[0], b[ks][1], acc_r);         // small products first: w0 h1, w1 h0, then w0 h0
+      acc_z = vg_mfma2(a[1], b[ks][1], acc_z);
+      acc_t = vg_mfma2(a[2], b[ks][1], acc_t);
+      acc_r = vg_mfma2(a[3], b[ks][0], acc_r);
+      acc_z = vg_mfma2(a[4], b[ks][0], acc_z);
+      acc_t = vg_mfma2(a[5], b[ks][0], acc_t);
+      acc_r = vg_mfma2(a[0], b[ks][0], acc_r);
+      acc_z = vg_mfma2(a[1], b[ks][0], acc_z);
+      acc_t = vg_mfma2(a[2], b[ks][0], acc_t);
+    }
+  };
+
+  // VMEM order of a wave: DMA(0 .. DIST-1) touch B(0) | slot c: B(c+1) DMA(c+DIST).  At the top of slot c+1
+  // everything up to B(c+1) must have landed; behind it only DMA(c+DIST) is outstanding, which may stay in flight
+  // if it fills a later slot (DIST >= 2: D operations).  The first wait and the last two slots stand outside the
+  // loop so that every wait is a straight-line statement.
+  constexpr int WAITN = DIST >= 2 ? D : 0;
+  vg_u32x4 bA[VG_CK][2], bB[VG_CK][2];
+  load_b(bA, 0);
+  vg_wait<0>(bA);
+  asm volatile("" : "+v"(pf));                         // the touches have retired
+  // the group record has arrived by now (requested before the first loads): layer 0 touches the line of residue
+  // codes it reads after the loop; the touch retires at the next counted wait, `pf2` lives until after the loop
+  unsigned pf2 = 0;
+  if (layer == 0) {
+    const int col = b0 + (li & 16) < L ? b0 + (li & 16) : L - 1;
+    const unsigned char* q = M.msa + (int64_t)(t < N ? t : 0) * L + col;
+    asm volatile("global_load_ubyte %0, %1, off" : "+v"(pf2) : "v"(q) : "memory");
+  }
+#ifdef VG_DBG_NOLOOP
+  constexpr int C_END = 0;
+#else
+  constexpr int C_END = VG_NC - 2;
+#endif
+#pragma unroll 1
+  for (int c = 0; c < C_END; c += 2) {
+    __syncthreads();                                   // slot c is complete; every wave is done with slot c-1
+    load_b(bB, c + 1);
+    dma_slot(c + DIST);
+    compute(bA, c);
+    vg_wait<WAITN>(bB);
+    __syncthreads();
+    load_b(bA, c + 2);
+    dma_slot(c + 1 + DIST);                            // c <= VG_NC - 4 and DIST <= 2: the slot exists
+    compute(bB, c + 1);
+    vg_wait<WAITN>(bA);
+  }
+  {
+    constexpr int c = VG_NC - 2;
+    __syncthreads();
+    load_b(bB, c + 1);
+    if (c + DIST < VG_NC) dma_slot(c + DIST);
+    compute(bA, c);
+    vg_wait<0>(bB);
+    __syncthreads();
+    compute(bB, c + 1);
+  }
+
+  asm volatile("" : "+v"(pf2));
+  const bool active = tix < ntiles && t < t_end && (layer ? (t >= 1 && t <= N) : (t < N));
+  if (layer == 0 && active) {
+    // layer 0 input: one-hot of the residue code (value 1024 = the state scale), K = 32 (rows 22..31 of the
+    // packed weights are 0); fragments straight from L2
+    const uint4* wp = st.wx[0] + (j0 + li);
+    const int b = b0 + li;
+    const int code = (b < L) ? (int)M.msa[(int64_t)t * L + b] : 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kq = 2 * s + kk;
+      const int d = code - 8 * kq;                     // position of the hot element among this lane's 8 k
+      const unsigned hot = (d >= 0 && d < 8) ? (0x6400u << (16 * (d & 1))) : 0u;
+      vg_u32x4 x;
+      x.x = (d >> 1) == 0 ? hot : 0u;
+      x.y = (d >> 1) == 1 ? hot : 0u;
+      x.z = (d >> 1) == 2 ? hot : 0u;
+      x.w = (d >> 1) == 3 ? hot : 0u;
+      acc_r = vg_mfma2(wp[(int64_t)((1 * 3 + 0) * 4 + kq) * 512], x, acc_r);
+      acc_z = vg_mfma2(wp[(int64_t)((1 * 3 + 1) * 4 + kq) * 512], x, acc_z);
+      acc_in = vg_mfma2(wp[(int64_t)((1 * 3 + 2) * 4 + kq) * 512], x, acc_in);
+      acc_r = vg_mfma2(wp[(int64_t)((0 * 3 + 0) * 4 + kq) * 512], x, acc_r);
+      acc_z = vg_mfma2(wp[(int64_t)((0 * 3 + 1) * 4 + kq) * 512], x, acc_z);
+      acc_in = vg_mfma2(wp[(int64_t)((0 * 3 + 2) * 4 + kq) * 512], x, acc_in);
+    }
+  }
+
+  // ---- epilogue.  Accumulator register r of lane (kk, li): hidden row j0 + 8 (r / 4) + 4 kk + (r % 4), column
+  // b0 + li.  Layer 1: the two waves of a column tile swap halves through LDS - the recurrent wave finishes the
+  // register groups g4 = 0, 1, the input wave g4 = 2, 3; sums are formed as recurrent + input.
+  float* xb = reinterpret_cast<float*>(vg2_smem);      // [wl][dir 2][gate 3][reg 8][64]  (12 KB per column tile)
+  int g_lo = 0, g_hi = 4;
+  if (layer == 1) {
+    __syncthreads();                                   // every wave is done with the rings
+    float* out = xb + ((wl * 2 + prod) * 3) * 8 * 64 + lane;
+    const int ro = prod ? 0 : 8;                       // the half the partner finishes
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        out[(0 * 8 + r) * 64] = acc_r[ro + r];
+        out[(1 * 8 + r) * 64] = acc_z[ro + r];
+        out[(2 * 8 + r) * 64] = acc_t[ro + r];
+      }
+    }
+    __syncthreads();
+    g_lo = prod ? 2 : 0;
+    g_hi = g_lo + 2;
+  }
+  if (!active) return;
+  const float* in_l = xb + ((wl * 2 + (prod ^ 1)) * 3) * 8 * 64 + lane;
+  const float* bias = st.bias[layer];
+  const float inv = st.inv_scale[layer];
+  float* hnext = layer ? st.hT[1][par] : st.hT[0][par ^ 1];
+  uint16_t* gnext = layer ? st.hH[1][par] : st.hH[0][par ^ 1];
+  const int b = tcol + li;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    if (g4 < g_lo || g4 >= g_hi) continue;
+    const int j4 = j0 + 8 * g4 + 4 * kk;
+    const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
+    const float4 hp4 = *reinterpret_cast<const float4*>(hprev + hoff);
+    const float4 bR = *reinterpret_cast<const float4*>(bias + j4);
+    const float4 bZ = *reinterpret_cast<const float4*>(bias + 512 + j4);
+    const float4 bI = *reinterpret_cast<const float4*>(bias + 1024 + j4);
+    const float4 bH = *reinterpret_cast<const float4*>(bias + 1536 + j4);
+    const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+    const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
+    const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
+    float hn[4];
+    unsigned short q0[4], q1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * g4 + q;
+      float s_r, s_z, s_in, s_hn;
+      if (layer == 0) {
+        s_r = acc_r[r]; s_z = acc_z[r]; s_hn = acc_t[r]; s_in = acc_in[r];
+      } else {
+        const int rl = r & 7;                          // register inside the exchanged half
+        const float o_r = in_l[(0 * 8 + rl) * 64], o_z = in_l[(1 * 8 + rl) * 64], o_t = in_l[(2 * 8 + rl) * 64];
+        if (prod == 0) { s_r = acc_r[r] + o_r; s_z = acc_z[r] + o_z; s_hn = acc_t[r]; s_in = o_t; }
+        else           { s_r = o_r + acc_r[r]; s_z = o_z + acc_z[r]; s_hn = o_t; s_in = acc_t[r]; }
+      }
+#ifdef VG_DBG_NOEPI
+      const float rg = s_r * inv + br[q], zg = s_z * inv + bz[q];
+      const float ng = (s_in * inv + bi[q]) + rg * (s_hn * inv + bh[q]);
+#else
+      const float rg = vg_sigmoid(s_r * inv + br[q]);
+      const float zg = vg_sigmoid(s_z * inv + bz[q]);
+      const float ng = vg_tanh((s_in * inv + bi[q]) + rg * (s_hn * inv + bh[q]));
+#endif
+      hn[q] = (hp[q] - ng) * zg + ng;
+      const float hs = hn[q] * VGRU_STATE_SCALE;
+      const _Float16 p0 = (_Float16)hs;
+      const _Float16 p1 = (_Float16)(hs - (float)p0);
+      q0[q] = __builtin_bit_cast(unsigned short, p0);
+      q1[q] = __builtin_bit_cast(unsigned short, p1);
+    }
+    *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
+    *reinterpret_cast<uint2*>(gnext + goff) =
+        make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
+    *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
+        make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
+  }
+}
+
 // out[l][j] = hP[j/4][l][j%4]
 __global__ __launch_bounds__(128) void vgru_out_kernel(const float* __restrict__ hP, int Lb,
                                                        float* __restrict__ out) {
   const int l = blockIdx.x, j4 = threadIdx.x;
   const float4 v = *reinterpret_cast<const float4*>(hP + ((int64_t)j4 * Lb + l) * 4);
   *reinterpret_cast<float4*>(out + (int64_t)l * WIDTH + 4 * j4) = v;
-}
-
-int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s) {
-  return gru_vertical_steps(c, d_msa, N, L, 0, N + 1, d_out, s);
 }
 
 __global__ void vgru_set_run_kernel(VRun* run, const uint8_t* msa, int N, int L, int Lb, int t0, int t_end) {
@@ -310,8 +688,8 @@ static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
   return DMP_OK;
 }
 
-int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
-                       hipStream_t s) {
+static int gru_vertical_steps_legacy(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
+                                     hipStream_t s) {
   const int Lb = vgru_pitch(L);
   const size_t hbytes = sizeof(float) * WIDTH * Lb;
   if (t_lo <= 0) {
@@ -339,6 +717,167 @@ int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo,
     DMP_LAUNCH_CHECK();
   }
   return DMP_OK;
+}
+
+
+// ---- group launcher ---------------------------------------------------------------------------------
+static int vgru2_nw(int ntiles) {
+  static const int forced = getenv("DMP_VGRU_NW") ? atoi(getenv("DMP_VGRU_NW")) : 0;     // tuning experiments
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  return ntiles >= 24 ? 4 : (ntiles >= 12 ? 2 : 1);
+}
+
+static int vgru2_cgs(int ntiles) {
+  static const int forced = getenv("DMP_VGRU_CGS") ? atoi(getenv("DMP_VGRU_CGS")) : 0;   // tuning experiments
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  return ntiles >= 24 ? 2 : 1;
+}
+
+static int vgru2_graph(dmp_ctx* c, int ntiles, int nw, int cgs, int len, hipGraphExec_t* out) {
+  const int grid = vgru2_grid(ntiles, nw, cgs);
+  const int64_t key = ((int64_t)1 << 62) | ((int64_t)cgs << 52) | ((int64_t)nw << 48) | ((int64_t)ntiles << 16) | len;
+  auto it = c->vgru_graphs.find(key);
+  if (it != c->vgru_graphs.end()) { *out = (hipGraphExec_t)it->second; return DMP_OK; }
+  const Weights& W = c->W;
+  VStatic st{};
+  for (int l = 0; l < 2; ++l) {
+    st.wx[l] = reinterpret_cast<const uint4*>(W.v_wx[l]);
+    st.wh[l] = reinterpret_cast<const uint4*>(W.v_wh[l]);
+    st.inv_scale[l] = W.v_inv_scale[l];
+    for (int p = 0; p < 2; ++p) { st.hT[l][p] = c->hT[l][p]; st.hH[l][p] = c->hH[l][p]; }
+  }
+  st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
+  const VGroupRec* rec = reinterpret_cast<const VGroupRec*>(c->vgru_run);
+  void* fn = nw == 4 ? (void*)vgru2_step_kernel<4> : (nw == 2 ? (void*)vgru2_step_kernel<2> : (void*)vgru2_step_kernel<1>);
+  hipGraph_t g;
+  DMP_HIP(hipGraphCreate(&g, 0));
+  hipGraphNode_t prev = nullptr;
+  for (int idx = 0; idx < len; ++idx) {
+    int idx_arg = idx;
+    int cgs_arg = cgs, nt_arg = ntiles;
+    void* params[5] = {(void*)&st, (void*)&rec, (void*)&idx_arg, (void*)&cgs_arg, (void*)&nt_arg};
+    hipKernelNodeParams kp{};
+    kp.func = fn;
+    kp.gridDim = dim3(grid);
+    kp.blockDim = dim3(128 * nw);
+    kp.sharedMemBytes = VG2_LDS_BYTES;
+    kp.kernelParams = params;
+    kp.extra = nullptr;
+    hipGraphNode_t node;
+    hipError_t e = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); return hip_fail(e, "hipGraphAddKernelNode", __FILE__, __LINE__); }
+    prev = node;
+  }
+  hipGraphExec_t ge;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+  c->vgru_graphs[key] = (void*)ge;
+  *out = ge;
+  return DMP_OK;
+}
+
+int vgru_kernel_attrs(dmp_ctx*) {
+  DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
+  DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
+  DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
+  return DMP_OK;
+}
+
+// Group record of n member alignments (their column tiles one after the other in the LEADER's state buffers)
+// and the state cleared; all on stream s.
+int vgru_group_setup(dmp_ctx* lead, dmp_ctx* const* members, const uint8_t* const* msas, const int* Ns,
+                     const int* Ls, int n, hipStream_t s) {
+  if (n < 1 || n > VG_MAX_MEMBERS) { set_error("a vertical-GRU group has 1..%d members, got %d", VG_MAX_MEMBERS, n); return DMP_ERR_ARG; }
+  VGroupRec rec{};
+  int nt = 0, maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    if (members[i]->W.hash != lead->W.hash || !members[i]->W.ready) {
+      set_error("vertical-GRU group: member %d does not hold the leader's weights", i);
+      return DMP_ERR_WEIGHTS;
+    }
+    rec.mem[i].msa = msas[i];
+    rec.mem[i].N = Ns[i];
+    rec.mem[i].L = Ls[i];
+    rec.mem[i].tile0 = nt;
+    lead->vg_tile0[i] = nt;
+    nt += vgru_pitch(Ls[i]) / VG_TB;
+    maxN = std::max(maxN, Ns[i]);
+  }
+  if (nt * VG_TB > lead->vg_cap_cols) {
+    set_error("vertical-GRU group of %d columns exceeds the leader's capacity %d", nt * VG_TB, lead->vg_cap_cols);
+    return DMP_ERR_CAPACITY;
+  }
+  rec.nmem = n;
+  rec.t0 = 0;
+  rec.t_end = 0;
+  const size_t hbytes = sizeof(float) * WIDTH * (size_t)nt * VG_TB;
+  for (int l = 0; l < 2; ++l) {
+    DMP_HIP(hipMemsetAsync(lead->hT[l][0], 0, hbytes, s));
+    DMP_HIP(hipMemsetAsync(lead->hH[l][0], 0, hbytes, s));     // 2 pieces x 512 x columns x 2 bytes
+  }
+  hipLaunchKernelGGL(vgru_set_group_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<VGroupRec*>(lead->vgru_run), rec);
+  DMP_LAUNCH_CHECK();
+  lead->vg_ntiles = nt;
+  lead->vg_maxN = maxN;
+  return DMP_OK;
+}
+
+// time steps [t_lo, t_hi) of the group set up on `lead` (t_hi is cut at max N + 1); t_lo must be even (the buffer
+// parity of a row is the parity of its node index in the chain)
+int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
+  const int nt = lead->vg_ntiles, nw = vgru2_nw(nt);
+  if (t_hi > lead->vg_maxN + 1) t_hi = lead->vg_maxN + 1;
+  if (t_lo < 0) t_lo = 0;
+  if (t_lo & 1) { set_error("vertical-GRU chunks start at even rows (got %d)", t_lo); return DMP_ERR_ARG; }
+  VGroupRec* rec = reinterpret_cast<VGroupRec*>(lead->vgru_run);
+  for (int t = t_lo; t < t_hi;) {
+    // whole 128-row chains, then 16-row chains: an idle node of a chain costs a full step (a step learns its row
+    // number only after its main loop)
+    const int len = (t_hi - t >= VGRU_CHUNK) ? VGRU_CHUNK : VGRU_CHUNK_SMALL;
+    hipGraphExec_t ge;
+    int rc = vgru2_graph(lead, nt, nw, vgru2_cgs(nt), len, &ge);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vgru_set_run2_kernel, dim3(1), dim3(1), 0, s, rec, t, t_hi);
+    DMP_HIP(hipGraphLaunch(ge, s));
+    t += len;
+  }
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// out[l][j] = state[j/4][col0 + l][j%4] with column pitch Lb
+__global__ __launch_bounds__(128) void vgru2_out_kernel(const float* __restrict__ hP, int Lb, int col0,
+                                                        float* __restrict__ out) {
+  const int l = blockIdx.x, j4 = threadIdx.x;
+  const float4 v = *reinterpret_cast<const float4*>(hP + ((int64_t)j4 * Lb + col0 + l) * 4);
+  *reinterpret_cast<float4*>(out + (int64_t)l * WIDTH + 4 * j4) = v;
+}
+
+// member `mi` of the group on `lead`: its result (top-layer state after its last row) as L x 512
+int vgru_group_output(dmp_ctx* lead, int mi, int N, int L, float* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(vgru2_out_kernel, dim3(L), dim3(128), 0, s, lead->hT[1][N & 1], lead->vg_ntiles * VG_TB,
+                     lead->vg_tile0[mi] * VG_TB, d_out);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
+                       hipStream_t s) {
+  if (c->vgru_legacy) return gru_vertical_steps_legacy(c, d_msa, N, L, t_lo, t_hi, d_out, s);
+  int rc;
+  if (t_lo <= 0) {
+    t_lo = 0;
+    if ((rc = vgru_group_setup(c, &c, &d_msa, &N, &L, 1, s))) return rc;
+  }
+  if (t_hi > N + 1) t_hi = N + 1;
+  if ((rc = vgru_group_steps(c, t_lo, t_hi, s))) return rc;
+  if (t_hi == N + 1) return vgru_group_output(c, 0, N, L, d_out, s);
+  return DMP_OK;
+}
+
+int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s) {
+  return gru_vertical_steps(c, d_msa, N, L, 0, N + 1, d_out, s);
 }
 
 }  // namespace dmp

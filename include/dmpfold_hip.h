@@ -73,6 +73,8 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * "tridiag_single" = 1 runs the Householder tridiagonalisation of the MDS eigensolver in a single
  * workgroup (one launch) instead of one multi-workgroup launch per step; same algorithm, different
  * summation order (results agree to float64 rounding).
+ * "vgru_legacy" = 1 runs the vertical GRU with the round-2 step kernel (one target per launch, K split over the
+ * waves of a workgroup; different summation order, results agree to float32 rounding; no group form).
  * "refine_single" = 1 runs the minimiser (dmp_refine_coords, dmp_predict*) in one workgroup instead
  * of a cluster of 16 that hands the coordinates over every step; same iteration, different
  * partial-sum slices (results agree to float32 rounding). */
@@ -125,6 +127,14 @@ int dmp_dca_features(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_
  * d_out: L x 512, top-layer state after the last row. */
 int dmp_gru_vertical(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_out,
                      void* stream);
+/* The same for n <= 8 alignments at once (contexts of one GPU holding the same weights, their alignments may
+ * differ in N and L): ONE launch per alignment row serves the columns of all members, and the weight
+ * fragments a workgroup fetches are shared by its column tiles - the independent targets of a throughput job are
+ * the batch axis the reference's GRU call (batch = L, network.py:224) does not have.  Each member's result is
+ * bit-identical to dmp_gru_vertical on it alone.  Everything is enqueued on `stream`; ctxs[0] leads (its
+ * record buffers are used). */
+int dmp_gru_vertical_group(dmp_ctx* const* ctxs, int n, const uint8_t* const* d_msas, const int* Ns,
+                           const int* Ls, float* const* d_outs, void* stream);
 /* hgru (which = 0; network.py:225, in T x 512) or coord_gru (which = 1; network.py:253,
  * in T x 520): multi-layer bidirectional GRU along the sequence, batch 1.
  * d_out: T x 512 (forward | reverse halves). */
