@@ -454,6 +454,11 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
     c->side_ev[i] = (void*)e;
   }
+  {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+    c->vg_done_ev = (void*)e;
+  }
   *out = c;
   return DMP_OK;
 }
@@ -532,6 +537,7 @@ void dmp_ctx_destroy(dmp_ctx* c) {
     if (e) (void)hipEventDestroy((hipEvent_t)e);
   for (void* e : c->side_ev)
     if (e) (void)hipEventDestroy((hipEvent_t)e);
+  if (c->vg_done_ev) (void)hipEventDestroy((hipEvent_t)c->vg_done_ev);
   if (c->side_stream) (void)hipStreamDestroy((hipStream_t)c->side_stream);
   for (auto& kv : c->vgru_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
   for (auto& kv : c->tri_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);
@@ -835,7 +841,11 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
     const int k = u - 1, m = std::min(c->fe_inv, c->fe_vgru);
     bool inv;
     int j;
-    if (k < 2 * m) { inv = (k & 1) != 0; j = k >> 1; }
+    if (c->vg_leader == c && c->vg_members.size() > 1) {
+      // a group leader issues the whole chain first (every member waits for it) and its own inverse afterwards
+      inv = k >= c->fe_vgru;
+      j = inv ? k - c->fe_vgru : k;
+    } else if (k < 2 * m) { inv = (k & 1) != 0; j = k >> 1; }
     else { inv = c->fe_inv > m; j = m + (k - 2 * m); }
     if (inv) {
       used = side;
@@ -843,6 +853,31 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
       if (!rc && j == c->fe_inv - 1) {
         rc = dca_contacts(c, c->cov, L, c->contacts, side);
         if (!rc && fork) DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[1], side));
+      }
+    } else if (c->vg_leader == c) {
+      // the chain of the whole group: this context's units serve every member
+      const int n = (int)c->vg_members.size();
+      if (j == 0) {
+        const uint8_t* msas[8];
+        int Ns[8], Ls[8];
+        for (int i = 0; i < n; ++i) { msas[i] = c->vg_members[i]->run_msa; Ns[i] = c->vg_members[i]->last_N; Ls[i] = c->vg_members[i]->last_L; }
+        rc = vgru_group_setup(c, c->vg_members.data(), msas, Ns, Ls, n, s);
+      }
+      // a real group's chain is ONE unit (every member waits for its end, and nothing else wants this stream
+      // meanwhile): chunked, the chain stood still for 2-3 ms between chunks whenever the scheduler thread was busy
+      // issuing the members' inverse units (kernel trace: 40 ms of a 97 ms front-end phase)
+      const bool whole = n > 1;
+      if (!rc) rc = whole ? vgru_group_steps(c, 0, c->vg_maxN + 1, s)
+                          : vgru_group_steps(c, j * FE_VGRU_STEPS, (j + 1) * FE_VGRU_STEPS, s);
+      if (!rc && j == c->fe_vgru - 1) {
+        for (int i = 0; !rc && i < n; ++i) {
+          dmp_ctx* m = c->vg_members[i];
+          rc = vgru_group_output(c, i, m->last_N, m->last_L, m->vout, s);
+        }
+        if (!rc) {
+          DMP_HIP(hipEventRecord((hipEvent_t)c->vg_done_ev, s));
+          c->vg_done_issued = true;
+        }
       }
     } else {
       rc = gru_vertical_steps(c, d_msa, N, L, j * FE_VGRU_STEPS, std::min((j + 1) * FE_VGRU_STEPS, N + 1),
@@ -852,7 +887,17 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
     const float* inv = N > 1 ? c->cov : nullptr;
     const float* contacts = N > 1 ? c->contacts : nullptr;
     if (fork) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->side_ev[1], 0));
-    rc = gru_bidir(c, 0, c->vout, L, c->seq_b, s);
+    if (c->vg_leader && c->vg_leader != c) {
+      // this member's vertical GRU ran in its leader's chain, on the leader's stream
+      dmp_ctx* lead = c->vg_leader;
+      DMP_ARG(lead->vg_done_issued, "the leader of this context's vertical-GRU group has not issued the chain's last "
+                                    "unit yet (dmp_predict_next_unit answers DMP_UNIT_WAIT until it has)");
+      DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)lead->vg_done_ev, 0));
+      lead->vg_waiters--;
+      c->vg_leader = nullptr;
+    }
+    if (c->ext_vout && c->ext_vout_ev) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->ext_vout_ev, 0));
+    rc = gru_bidir(c, 0, c->ext_vout ? c->ext_vout : c->vout, L, c->seq_b, s);
     if (!rc) rc = transpose_f32(c->seq_b, L, WIDTH, c->mat1d, s);
     if (!rc) rc = stem_static(c, c->mat1d, inv, contacts, L, c->z0, s);
     if (!rc) rc = c->run_template ? pair_distances(c->run_template, L, 0, c->dmap, s)
@@ -874,6 +919,13 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   DMP_ARG(d_template_ca == nullptr || Lt == L,
           "template has %d CA atoms but the alignment has %d columns", Lt, L);
   dmp_ctx* c = ctx;
+  DMP_ARG(c->vg_waiters == 0, "members of the vertical-GRU group this context led have not taken their results yet");
+  DMP_ARG(c->vg_leader == nullptr || c->vg_leader == c, "this context still waits for the vertical GRU of its group");
+  c->vg_leader = nullptr;
+  c->vg_members.clear();
+  c->vg_done_issued = false;
+  c->ext_vout = nullptr;
+  c->ext_vout_ev = nullptr;
   c->last_L = L;
   c->last_N = N;
   c->passes_done = 0;
@@ -902,8 +954,54 @@ int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const fl
   return rc;
 }
 
+int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n) {
+  DMP_ARG(ctxs && n >= 1 && n <= 8, "a group has 1..8 members");
+  dmp_ctx* lead = ctxs[0];
+  int cols = 0, maxN = 0;
+  for (int i = 0; i < n; ++i) {
+    dmp_ctx* c = ctxs[i];
+    DMP_ARG(c != nullptr, "null context");
+    for (int k = 0; k < i; ++k) DMP_ARG(ctxs[k] != c, "a context appears twice in the group");
+    DMP_ARG(c->fe_total > 0 && c->fe_next == 0 && c->vg_leader == nullptr,
+            "member %d: group its vertical GRU right after dmp_predict_begin_units, before any unit is issued", i);
+    DMP_ARG(c->device == lead->device, "the members of a group must live on one GPU");
+    DMP_ARG(c->W.ready && c->W.hash == lead->W.hash, "member %d does not hold the leader's weights", i);
+    DMP_ARG(!c->vgru_legacy, "member %d runs the legacy vertical GRU (option vgru_legacy): no group form", i);
+    cols += round_up(c->last_L, 32);
+    maxN = std::max(maxN, c->last_N);
+  }
+  if (cols > lead->vg_cap_cols) {
+    set_error("the group's %d alignment columns exceed the leader's capacity %d", cols, lead->vg_cap_cols);
+    return DMP_ERR_CAPACITY;
+  }
+  lead->vg_members.assign(ctxs, ctxs + n);
+  lead->vg_done_issued = false;
+  lead->vg_waiters = n - 1;
+  for (int i = 0; i < n; ++i) {
+    dmp_ctx* c = ctxs[i];
+    c->vg_leader = lead;
+    c->vg_index = i;
+    c->fe_vgru = i == 0 ? (n > 1 ? 1 : cdiv(maxN + 1, FE_VGRU_STEPS)) : 0;
+    c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
+  }
+  return DMP_OK;
+}
+
+int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event) {
+  DMP_ARG(ctx && d_vout, "null argument");
+  DMP_ARG(ctx->fe_total > 0 && ctx->fe_next == 0 && ctx->vg_leader == nullptr,
+          "hand the vertical-GRU result over right after dmp_predict_begin_units, before any unit is issued");
+  ctx->ext_vout = d_vout;
+  ctx->ext_vout_ev = event;
+  ctx->fe_vgru = 0;
+  ctx->fe_total = 1 + ctx->fe_inv + 1;
+  return DMP_OK;
+}
+
 int dmp_predict_next_unit(const dmp_ctx* ctx) {
   if (!ctx) return DMP_UNIT_NONE;
+  if (ctx->fe_next == ctx->fe_total - 1 && ctx->vg_leader && ctx->vg_leader != ctx && !ctx->vg_leader->vg_done_issued)
+    return DMP_UNIT_WAIT;      // the leader's chain has not been issued to its end yet
   if (ctx->fe_next < ctx->fe_total) return DMP_UNIT_LIGHT;
   if (ctx->passes_done > ctx->run_nloops) return DMP_UNIT_NONE;
   return (ctx->unit_next >= 1 && ctx->unit_next <= NBLOCK) ? DMP_UNIT_CONV : DMP_UNIT_LIGHT;

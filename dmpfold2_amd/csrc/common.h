@@ -139,6 +139,15 @@ struct dmp_ctx {
   int vg_ntiles = 0, vg_maxN = 0;          // group this context leads (vgru.hip): column tiles, deepest member alignment
   int vg_tile0[8] = {0};                   // ... first column tile of every member
   int vg_cap_cols = 0;                     // columns the state buffers hold (a group's members side by side)
+  // dmp_predict_group_vgru: the vertical GRUs of several predictions in flight as one launch chain
+  dmp_ctx* vg_leader = nullptr;            // the context whose units run the chain (itself for the leader; null: no group)
+  std::vector<dmp_ctx*> vg_members;        // leader: the members, itself first
+  int vg_index = 0;                        // this context's index among its leader's members
+  bool vg_done_issued = false;             // leader: the chain's last unit (and the members' outputs) has been enqueued
+  int vg_waiters = 0;                      // leader: members that have not yet enqueued their wait for vg_done_ev
+  void* vg_done_ev = nullptr;              // hipEvent_t recorded behind the chain's last unit
+  const float* ext_vout = nullptr;         // dmp_predict_set_vgru_result: the vertical GRU of this prediction was run ahead
+  void* ext_vout_ev = nullptr;             // ... hipEvent_t recorded behind it (not owned)
   int vgru_legacy = 0;                     // option: 1 = the round-2 step kernel (one target per launch, K split over waves)
   std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
   std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain

@@ -393,11 +393,38 @@ class Pipeline:
         # tails interleave.  Measured on three boxes, alternating runs: +0.8 .. +1.5 % structures/s for 5-12
         # blocks against 0 (7.06-7.11 against 7.01; 7.00 against 6.92).  DMP_TAIL_STAGGER overrides (0 = off).
         self._tail_stagger = int(os.environ.get("DMP_TAIL_STAGGER", "8"))
+        # Group start: predictions that begin together run their vertical GRUs (2001 dependent launches each at the
+        # north-star size) as ONE launch chain that serves the columns of all of them (dmp_predict_group_vgru): four
+        # targets take 52-55 ms in one chain against 110 ms as four chains side by side.  A free engine therefore
+        # waits for the engines that are about to finish (at most DMP_GROUP_PATIENCE residual blocks left) and
+        # starts together with them, up to DMP_VGRU_GROUP members (1 = every prediction runs its own chain).
+        self._group_max = max(1, min(4, int(os.environ.get("DMP_VGRU_GROUP", "4"))))   # state buffers hold 4 x max_L columns
+        self._group_patience = int(os.environ.get("DMP_GROUP_PATIENCE", "40"))
+        # Look-ahead: the chain of the NEXT group touches none of the buffers the trunk passes use, so it is run
+        # beside the last DMP_VGRU_LOOKAHEAD residual blocks of the predictions in flight (on its own stream, in the
+        # state buffers of a context that predicts nothing itself) and handed to the engines when they start those
+        # targets (dmp_predict_set_vgru_result).  0 = off (the default): the chain runs in the group's front-end phase.
+        # Measured (bench.py, same box): 6.07-6.36 structures/s with a look-ahead of 24-176 blocks against 6.98-7.24
+        # without - a step kernel's 240 workgroups (8 waves, 72 KB of LDS each) only get onto a CU when a
+        # convolution workgroup retires there, so beside the convolutions the chain crawls and slows them.
+        self._lookahead = int(os.environ.get("DMP_VGRU_LOOKAHEAD", "0")) if S > 1 else 0
+        self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain)
+        self._fe = None
+        if self._lookahead > 0:
+            with torch.cuda.device(self.device):
+                st = torch.cuda.Stream(device=self.device)
+            fe = Engine(self.device, max_L, max_N, stream=st)
+            fe.set_weights(state_dict)
+            self._fe = fe
 
     def close(self):
         for e in self.engines:
             e.close()
         self.engines = []
+        if self._fe is not None:
+            self._fe.close()
+            self._fe = None
+        self._ahead = {}
         if self._lane:
             self.lib.dmp_lane_destroy(self._lane)
             self._lane = C.c_void_p()
@@ -432,6 +459,57 @@ class Pipeline:
         self._jobs[t] = job
         return t
 
+    def _start_ahead(self, jobs):
+        """The vertical GRUs of these queued targets as one chain on the look-ahead stream, beside whatever the
+        engines are doing."""
+        fe = self._fe
+        cur = torch.cuda.current_stream(self.device)
+        fe._stream.wait_stream(cur)
+        k = len(jobs)
+        with torch.cuda.device(self.device):
+            outs = [torch.empty((job[1].shape[1], 512), dtype=torch.float32, device=self.device) for job in jobs]
+        for job, out in zip(jobs, outs):
+            job[1].record_stream(fe._stream)
+            out.record_stream(fe._stream)
+        ctxs = (C.c_void_p * k)(*[fe.ctx] * k)
+        mp = (C.c_void_p * k)(*[job[1].data_ptr() for job in jobs])
+        op = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
+        Ns = (C.c_int * k)(*[job[1].shape[0] for job in jobs])
+        Ls = (C.c_int * k)(*[job[1].shape[1] for job in jobs])
+        _lib.check(self.lib.dmp_gru_vertical_group(ctxs, k, mp, Ns, Ls, op, fe.stream()))
+        ev = torch.cuda.Event()
+        ev.record(fe._stream)
+        for job, out in zip(jobs, outs):
+            self._ahead[job[0]] = (out, ev)
+
+    def _begin_group(self, slots):
+        """Start the next len(slots) queued targets on these free engines; those whose vertical GRU was not run
+        ahead form one vertical-GRU group (the first of them leads)."""
+        grouped = []
+        for s in slots:
+            self._done[s] = 0
+            self._total[s] = (self._pending[0][2] + 1) * 16
+            job = self._pending.pop(0)
+            self._begin(s, job)
+            ahead = self._ahead.pop(job[0], None)
+            if ahead is not None:
+                out, ev = ahead
+                out.record_stream(self.engines[s]._stream)
+                _lib.check(self.lib.dmp_predict_set_vgru_result(self.engines[s].ctx, out.data_ptr(),
+                                                                C.c_void_p(ev.cuda_event)))
+                self._slot[s] = self._slot[s] + (ahead,)          # keeps the tensor and the event alive
+            else:
+                grouped.append(s)
+        slots = grouped
+        if len(slots) > 1:
+            lead = self.engines[slots[0]]
+            for s in slots[1:]:                       # the leader's stream reads every member's alignment
+                for x in self._slot[s][3]:
+                    if x is not None:
+                        x.record_stream(lead._stream)
+            ctxs = (C.c_void_p * len(slots))(*[self.engines[s].ctx for s in slots])
+            _lib.check(self.lib.dmp_predict_group_vgru(ctxs, len(slots)))
+
     def _begin(self, s, job):
         t, d_msa, nloops, minsteps, d_tpl = job
         e = self.engines[s]
@@ -461,28 +539,43 @@ class Pipeline:
         # lane, so it may queue its next block behind the running one instead of draining first
         n_conv = sum(1 for s, e in enumerate(self.engines)
                      if self._slot[s] is not None and lib.dmp_predict_next_unit(e.ctx) == 2) if gated else 0
-        for s, e in enumerate(self.engines):
-            if self._slot[s] is None:
-                if not self._pending:
-                    continue
+        free = [s for s in range(len(self.engines)) if self._slot[s] is None]
+        if self._fe is not None and self._pending and len(free) < len(self.engines):
+            # look-ahead: one group of queued targets at a time, once every prediction in flight is near its end
+            nxt = self._pending[:self._group_max]
+            if not any(j[0] in self._ahead for j in nxt) and all(
+                    self._total[r] - self._done[r] <= self._lookahead
+                    for r in range(len(self.engines)) if self._slot[r] is not None):
+                self._start_ahead(nxt)
+        if free and self._pending:
+            # engines about to finish: wait for them and start together (one vertical-GRU chain for the group)
+            soon = [r for r in range(len(self.engines)) if self._slot[r] is not None
+                    and self._total[r] - self._done[r] <= self._group_patience]
+            want = min(self._group_max, len(self._pending))
+            if len(free) >= want or not soon or self._group_max == 1:
                 # optional phase spacing (stagger=True): a prediction starts only when every other one
                 # in flight is at least 1/S of its way through its residual blocks.  Measured at
                 # L=300, N=2000, 3 engines, 48 targets: 5.24 structures/s with spacing, 5.75 without
                 # (the waiting engines cost more than coinciding front ends), so it is off by default.
                 S = len(self.engines)
-                if self._stagger and any(self._slot[r] is not None and self._done[r] * S < self._total[r]
-                                         for r in range(S) if r != s):
-                    continue
-                self._done[s] = 0
-                self._total[s] = (self._pending[0][2] + 1) * 16
-                self._begin(s, self._pending.pop(0))
-                progressed = True
+                if not (self._stagger and any(self._slot[r] is not None and self._done[r] * S < self._total[r]
+                                              for r in range(S))):
+                    if self._group_max == 1:
+                        for s in free[:len(self._pending)]:
+                            self._begin_group([s])
+                    else:
+                        self._begin_group(free[:want])
+                    progressed = True
+        for s, e in enumerate(self.engines):
+            if self._slot[s] is None:
                 continue
             while True:
                 kind = lib.dmp_predict_next_unit(e.ctx)
+                if kind == 3:                         # waits for its group leader's vertical-GRU chain
+                    break
                 if kind == 0:
                     # final refinement + backbone; neither needs the lane
-                    t, coords, confs, _ = self._slot[s]
+                    t, coords, confs = self._slot[s][:3]
                     _lib.check(lib.dmp_predict_end(e.ctx, coords.data_ptr(), confs.data_ptr(), e.stream()))
                     self._results[t] = (coords, confs)
                     self._slot[s] = None

@@ -222,9 +222,25 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream);
 #define DMP_UNIT_NONE 0   /* every pass of this prediction was issued: call dmp_predict_end */
 #define DMP_UNIT_LIGHT 1  /* no convolution in the unit */
 #define DMP_UNIT_CONV 2   /* residual block: one lane turn */
+#define DMP_UNIT_WAIT 3   /* nothing to issue now: the unit waits for another context's units (dmp_predict_group_vgru) */
 int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L,
                             const float* d_template_ca, int Lt, int nloops, int refine_steps);
 int dmp_predict_next_unit(const dmp_ctx* ctx);
+/* Vertical GRUs of n <= 8 predictions as ONE launch chain (dmp_gru_vertical_group inside the unit machinery): call
+ * right after dmp_predict_begin_units on every member, before any of their units is issued.  ctxs[0] leads: its
+ * vertical-GRU units serve all members on the stream its units are issued on (which must be ordered behind the
+ * producers of every member's alignment), the other members have no vertical-GRU units; their last front-end unit
+ * waits (event) for the leader's last vertical-GRU unit, and dmp_predict_next_unit answers DMP_UNIT_WAIT for it
+ * until that unit has been issued.  Results are bit-identical to ungrouped predictions.  The members must hold
+ * the same weights; the leader cannot begin another prediction before every member has issued that unit. */
+int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n);
+/* The vertical GRU of this prediction has been (or is being) computed ahead of time by dmp_gru_vertical /
+ * dmp_gru_vertical_group on the same alignment: d_vout (L x 512, device) is its result, `event` (hipEvent_t or
+ * NULL) was recorded behind it.  Call right after dmp_predict_begin_units, before any unit is issued: the
+ * prediction then has no vertical-GRU units and its last front-end unit waits for the event and reads d_vout -
+ * a scheduler can run the launch chains of the NEXT targets beside the trunk passes of the current ones (the
+ * chain touches none of the buffers the trunk uses).  d_vout must stay valid until that unit has run. */
+int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event);
 /* After the last pass: dmp_predict_end_refine enqueues the final minimisation of the best trace
  * alone (optional: dmp_predict_end does it itself if it was not called), for callers that want to
  * interleave other work between the minimisation and the backbone kernel. */

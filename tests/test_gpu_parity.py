@@ -458,6 +458,64 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
     pipe.close()
 
 
+@pytest.mark.parametrize("group,lookahead", [(1, 0), (2, 0), (4, 0), (4, 24), (3, 400)])
+def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead):
+    """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE launch chain
+    (group leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so
+    groups of every size up to `group` form.  With a look-ahead the chains of the next group run beside the
+    predictions in flight and are handed over (dmp_predict_set_vgru_result).  Every result equals the single
+    engine's, bit for bit."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Pipeline, encode_aln
+    monkeypatch.setenv("DMP_VGRU_GROUP", str(group))
+    monkeypatch.setenv("DMP_VGRU_LOOKAHEAD", str(lookahead))
+    shapes = [(82, 200), (33, 64), (128, 300), (40, 1), (64, 257), (96, 31), (120, 129), (50, 64), (128, 17)]
+    msas = [encode_aln(synth.synth_msa(L, N, 40 + i)) for i, (L, N) in enumerate(shapes)]
+    dev = torch.device("cuda:0")
+    pipe = Pipeline(dev, 128, 512, synth_sd, streams=4)
+    assert pipe._group_max == group and (pipe._fe is not None) == (lookahead > 0)
+    tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 3) for m in msas]
+    pipe.drain()
+    pipe.sync_check()
+    for m, t in zip(msas, tickets):
+        coords, confs = pipe.result(t)
+        ref_c, ref_f = st_engine.eng.predict(m, None, 1, 3)
+        st_engine.eng.sync_check()
+        assert torch.equal(coords, ref_c) and torch.equal(confs, ref_f), m.shape
+    pipe.close()
+
+
+def test_gru_vertical_group_stage_call(st, synth_sd):
+    """dmp_gru_vertical_group (the stage-level form): three alignments of different shape through one chain,
+    each result bit-identical to dmp_gru_vertical alone and within 1e-5 of the oracle's GRU."""
+    import ctypes as C
+    from dmpfold2_amd import _lib, synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    shapes = [(82, 100), (33, 7), (128, 64)]
+    msas = [encode_aln(synth.synth_msa(L, N, 70 + i)) for i, (L, N) in enumerate(shapes)]
+    alone = [st.gru_vertical(m).clone() for m in msas]
+    others = [Engine("cuda:0", 128, 512) for _ in range(2)]
+    try:
+        for e in others:
+            e.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+        engs = [st.eng] + others
+        d = [st.to(m, torch.uint8) for m in msas]
+        outs = [st.f32(L, 512) for L, _ in shapes]
+        k = len(engs)
+        ctxs = (C.c_void_p * k)(*[e.ctx for e in engs])
+        mp = (C.c_void_p * k)(*[x.data_ptr() for x in d])
+        op = (C.c_void_p * k)(*[x.data_ptr() for x in outs])
+        Ns = (C.c_int * k)(*[N for _, N in shapes])
+        Ls = (C.c_int * k)(*[L for L, _ in shapes])
+        _lib.check(st.lib.dmp_gru_vertical_group(ctxs, k, mp, Ns, Ls, op, st.eng.stream()))
+        torch.cuda.synchronize()
+        for a, o in zip(alone, outs):
+            assert torch.equal(a, o)
+    finally:
+        for e in others:
+            e.close()
+
+
 def test_batch_front_end_matches_cli(weights_file, tmp_path):
     """dmpfold2_amd.batch (targets file -> one PDB per target through the scheduler, template in
     the second column) writes exactly the text the single-target CLI prints."""

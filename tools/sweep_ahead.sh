@@ -1,0 +1,15 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+run() { label=$1; shift
+  out=$(env "$@" python $R/bench.py --no-cpu-baseline --no-exact-f32 --steps ${STEPS:-3} --warmup 1 2>/dev/null)
+  python3 - "$label" "$out" <<'PY'
+import json, sys
+try:
+    j = json.loads(sys.argv[2].strip().splitlines()[-1])
+    print("%-44s %.3f structures/s  chip_ms/launch %.4f  in flight %.2f  ok %s" % (sys.argv[1], j["value"], j["roofline"]["chip_ms_per_launch"], j["roofline"]["launches_in_flight"], j["verify"]["ok"]))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+}
+for la in ${LAS:-0 24 48 80 120 176}; do run "lookahead $la" DMP_VGRU_LOOKAHEAD=$la; done
+run "lookahead 48 queues 12" DMP_VGRU_LOOKAHEAD=48 GPU_MAX_HW_QUEUES=12
