@@ -740,14 +740,15 @@ def pdb_text(coords, confs, alnmat):
     confs = confs.detach().cpu()
     lines = ["REMARK  CONF:  " + repr(confs.mean().item())]
     atoms = (" N  ", " CA ", " C  ", " O  ", " CB ")
+    xyz, cf = coords.tolist(), confs.tolist()      # Python floats of the float32 values, as .item() gives them
     atomnum = 1
     for ri in range(coords.size(0)):
         code = int(alnmat[0, ri])
         for ai, an in enumerate(atoms):
             if code != 7 or ai != 4:          # glycine has no CB
+                x, y, z = xyz[ri][ai]
                 lines.append("ATOM   %4d %s %s  %4d    %8.3f%8.3f%8.3f  1.00%6.2f" % (
-                    atomnum, an, _RESNAMES[code], ri + 1, coords[ri, ai, 0].item(),
-                    coords[ri, ai, 1].item(), coords[ri, ai, 2].item(), confs[ri]))
+                    atomnum, an, _RESNAMES[code], ri + 1, x, y, z, cf[ri]))
                 atomnum += 1
     lines.append("END")
     return "\n".join(lines) + "\n"

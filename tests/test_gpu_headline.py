@@ -126,6 +126,57 @@ def test_north_star_size_and_depth_vs_reference(ns_engine, mode):
         eng.set_option("conv_mode", 0)
 
 
+# ------------------------------------------------------------------ a second weight distribution
+@pytest.mark.parametrize("mode", ["f16x3", "f32", "bf16x6"])
+def test_second_weight_set_vs_reference(mode):
+    """Every other golden uses synth_weights(0): this one is seed 1 with InstanceNorm gamma / beta x 4 (the
+    residual stream reaches several hundred, block-16 activations 6e9 in sum of squares instead of 1e8), L=128,
+    N=500, four trunk passes through the reference itself - the f16 pieces of the default convolution at a
+    different activation scale.  Stage tensors by sampled index, every pass, final structure; the per-pass
+    bound carries the reference's own thread-count floor (1, 2, 3, 5 against 8 threads) where it exceeds 1e-3."""
+    from dmpfold2_amd import synth
+    g = load_golden("w1x4_L128_N500_n3_m0")
+    sd = synth.synth_weights(int(g["weights_seed"]), coord_scale=float(g["coord_scale"]), act_scale=float(g["act_scale"]))
+    assert synth.weights_checksum(sd) == bytes(g["weights_sha256"]).decode()
+    alnmat = g["alnmat"]
+    L = alnmat.shape[1]
+    from abi import Stages
+    st = Stages(sd, 128, 512)
+    eng = st.eng
+    try:
+        eng.set_option("conv_mode", {"f16x3": 0, "f32": 1, "bf16x6": 2}[mode])
+        eng.predict(alnmat, None, 0, 0)
+        eng.sync_check()
+        assert np.array_equal(eng.fetch("w", alnmat.shape[0]).cpu().numpy(), g["w"])
+        mat1d = eng.fetch("mat1d", 512 * L).reshape(512, L).clone()
+        contacts = eng.fetch("contacts", L * L).reshape(L, L).clone()
+        inv = eng.fetch("inv_cov", (21 * L) ** 2).reshape(21 * L, 21 * L).clone()
+        assert np.abs(mat1d.cpu().numpy() - g["mat1d"]).max() < 1e-5
+        assert np.abs(contacts.cpu().numpy() - g["contacts"]).max() <= 1e-5 * max(1.0, np.abs(g["contacts"]).max())
+        # the trunk of the first pass stage by stage on the device's own features: sampled entries of the
+        # tensors the REFERENCE produced (stem, block 1, block 16), relative 1e-4 of each tensor's scale
+        x = st.stem_update(st.stem_static(mat1d, inv, contacts), st.to(np.full((L, L), -1.0, np.float32)))
+        def check(name, t):
+            ref = g[name + ".val"]
+            got = t.cpu().numpy().ravel()[g[name + ".idx"]]
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), name
+        check("stem_p0", x)
+        for block in range(1, 17):
+            u, stats = st.conv(block, x)
+            x = st.norm(block, u, stats, x)
+            if block == 1:
+                check("block1_p0", x)
+        check("block16_p0", x)
+        coords, confs = eng.predict(alnmat, None, 3, 0)
+        eng.sync_check()
+        dev = _check_passes(eng, g, 4, L, 1e-3)
+        print("second weight set", mode, "per-pass CA-RMSD", dev, "floors", g["noise_ca_pass"])
+        assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= 1e-3
+        assert np.abs(confs.cpu().numpy() - g["confs"]).max() < 1e-4
+    finally:
+        eng.close()
+
+
 # ------------------------------------------------------------------ the benchmark's minimiser setting
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", ["fit3fgx_L96_N50_n0_m100", "fit3fgx_L96_N50_n10_m100"])
@@ -390,6 +441,64 @@ def test_config3_batch_sharded_two_ways(tmp_path, weights_file):
     # %8.3f text: 5e-4 A of rounding per coordinate on top of the 1e-3 A tolerance
     assert ca_rmsd(ca, g["coords"][:, 1]) <= 1e-3 + 5e-4
     assert abs(conf - float(g["confs"].mean())) < 1e-4
+
+
+def test_config3_full_256_targets_world_8(tmp_path, weights_file):
+    """BASELINE configs[3] IN FULL: 256 synthetic targets, L uniform in [100, 300], N=2000,
+    iterations=10, minsteps=100, split over world=8 (the eight shards run here one after the other on the
+    one GPU, each through its own 4-engine scheduler, as eight ranks would).  Every target is written exactly
+    once, by the rank plan_shard gives it to; a sample of targets (the two longest, the two shortest and one
+    per shard) equals the text of the single-target CLI byte for byte; every structure is finite
+    (no poisoned output slips through)."""
+    from dmpfold2_amd import run_dmpfold, synth
+    from dmpfold2_amd.batch import run_batch, plan_shard
+    import subprocess
+    import sys
+    rng = np.random.Generator(np.random.Philox(key=256))
+    lengths = rng.integers(100, 301, size=256)
+    paths = [str(tmp_path / f"t{k:03d}_L{L}.aln") for k, L in enumerate(lengths)]
+    # the 256 alignments (0.1 GB of text) are written by a pool of fresh processes (no HIP state to fork)
+    maker = ("import sys, multiprocessing as mp\n"
+             "sys.path.insert(0, sys.argv[1])\n"
+             "from dmpfold2_amd import synth\n"
+             "def one(a):\n"
+             "    synth.write_aln(a[0], synth.synth_msa(a[1], 2000, seed=a[2]))\n"
+             "if __name__ == '__main__':\n"
+             "    jobs = [l.split() for l in open(sys.argv[2])]\n"
+             "    with mp.Pool(min(16, mp.cpu_count())) as pool:\n"
+             "        pool.map(one, [(p, int(L), int(sd)) for p, L, sd in jobs], chunksize=4)\n")
+    (tmp_path / "make.py").write_text(maker)
+    (tmp_path / "jobs.txt").write_text("".join(f"{p} {int(L)} {1000 + k}\n" for k, (p, L) in enumerate(zip(paths, lengths))))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, str(tmp_path / "make.py"), root, str(tmp_path / "jobs.txt")], check=True)
+    targets = [(a, None) for a in paths]
+    out_dir = tmp_path / "out"
+    owner, total_s = {}, 0.0
+    for rank in range(8):
+        mine = plan_shard(targets, 10, rank, 8)
+        n, secs, outs = run_batch(targets, str(out_dir), 10, 100, weights_file=weights_file,
+                                  streams=4, device="cuda:0", rank=rank, world=8)
+        assert n == len(mine) == len(outs)
+        total_s += secs
+        for o in outs:
+            assert o not in owner, o                     # exactly once over the ranks
+            owner[o] = rank
+    assert len(owner) == 256
+    assert {os.path.basename(o) for o in owner} == {os.path.splitext(os.path.basename(a))[0] + ".pdb" for a in paths}
+    print("configs[3]: 256 targets in %.1f s of shard time = %.1f structures/s on one GPU" % (total_s, 256 / total_s))
+    for o in owner:
+        ca, conf = _parse_pdb(open(o).read())
+        assert np.isfinite(ca).all() and 0.0 < conf < 1.0, o
+    order = np.argsort(lengths)
+    sample = {int(order[0]), int(order[1]), int(order[-1]), int(order[-2])}
+    for rank in range(8):
+        sample.add(int(plan_shard(targets, 10, rank, 8)[-1]))
+    for i in sorted(sample):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            run_dmpfold(["-i", paths[i], "-d", "cuda:0", "-n", "10", "-m", "100", "-w", weights_file])
+        name = os.path.splitext(os.path.basename(paths[i]))[0] + ".pdb"
+        assert (out_dir / name).read_text() == buf.getvalue(), paths[i]
 
 
 def test_accuracy_harness_runs_when_trained_weights_exist():
