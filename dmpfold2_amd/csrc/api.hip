@@ -811,6 +811,39 @@ static bool side_stream_enabled() {
   return !off;
 }
 
+// The launch chain of the vertical-GRU group `c` leads, chunk j of c->fe_vgru (a real group's chain is ONE chunk),
+// enqueued on s; behind the last chunk the members' results and the event every member's last front-end unit waits for.
+static bool vg_done(const dmp_ctx* lead) { return __atomic_load_n(&lead->vg_done_issued, __ATOMIC_ACQUIRE); }
+
+static int issue_group_chain(dmp_ctx* c, int j, hipStream_t s) {
+  const int n = (int)c->vg_members.size();
+  int rc = DMP_OK;
+  if (j == 0) {
+    const uint8_t* msas[8];
+    int Ns[8], Ls[8];
+    for (int i = 0; i < n; ++i) { msas[i] = c->vg_members[i]->run_msa; Ns[i] = c->vg_members[i]->last_N; Ls[i] = c->vg_members[i]->last_L; }
+    rc = vgru_group_setup(c, c->vg_members.data(), msas, Ns, Ls, n, s);
+  }
+  // a real group's chain is ONE unit (every member waits for its end, and nothing else wants this stream
+  // meanwhile): chunked, the chain stood still for 2-3 ms between chunks whenever the scheduler thread was busy
+  // issuing the members' inverse units (kernel trace: 40 ms of a 97 ms front-end phase)
+  const bool whole = n > 1;
+  const int chunks = whole ? 1 : cdiv(c->vg_maxN + 1, FE_VGRU_STEPS);
+  if (!rc) rc = whole ? vgru_group_steps(c, 0, c->vg_maxN + 1, s)
+                      : vgru_group_steps(c, j * FE_VGRU_STEPS, (j + 1) * FE_VGRU_STEPS, s);
+  if (!rc && j == chunks - 1) {
+    for (int i = 0; !rc && i < n; ++i) {
+      dmp_ctx* m = c->vg_members[i];
+      rc = vgru_group_output(c, i, m->last_N, m->last_L, m->vout, s);
+    }
+    if (!rc) {
+      DMP_HIP(hipEventRecord((hipEvent_t)c->vg_done_ev, s));
+      __atomic_store_n(&c->vg_done_issued, true, __ATOMIC_RELEASE);
+    }
+  }
+  return rc;
+}
+
 static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   const int L = c->last_L, N = c->last_N, u = c->fe_next;
   const uint8_t* d_msa = c->run_msa;
@@ -856,29 +889,7 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
       }
     } else if (c->vg_leader == c) {
       // the chain of the whole group: this context's units serve every member
-      const int n = (int)c->vg_members.size();
-      if (j == 0) {
-        const uint8_t* msas[8];
-        int Ns[8], Ls[8];
-        for (int i = 0; i < n; ++i) { msas[i] = c->vg_members[i]->run_msa; Ns[i] = c->vg_members[i]->last_N; Ls[i] = c->vg_members[i]->last_L; }
-        rc = vgru_group_setup(c, c->vg_members.data(), msas, Ns, Ls, n, s);
-      }
-      // a real group's chain is ONE unit (every member waits for its end, and nothing else wants this stream
-      // meanwhile): chunked, the chain stood still for 2-3 ms between chunks whenever the scheduler thread was busy
-      // issuing the members' inverse units (kernel trace: 40 ms of a 97 ms front-end phase)
-      const bool whole = n > 1;
-      if (!rc) rc = whole ? vgru_group_steps(c, 0, c->vg_maxN + 1, s)
-                          : vgru_group_steps(c, j * FE_VGRU_STEPS, (j + 1) * FE_VGRU_STEPS, s);
-      if (!rc && j == c->fe_vgru - 1) {
-        for (int i = 0; !rc && i < n; ++i) {
-          dmp_ctx* m = c->vg_members[i];
-          rc = vgru_group_output(c, i, m->last_N, m->last_L, m->vout, s);
-        }
-        if (!rc) {
-          DMP_HIP(hipEventRecord((hipEvent_t)c->vg_done_ev, s));
-          c->vg_done_issued = true;
-        }
-      }
+      rc = issue_group_chain(c, j, s);
     } else {
       rc = gru_vertical_steps(c, d_msa, N, L, j * FE_VGRU_STEPS, std::min((j + 1) * FE_VGRU_STEPS, N + 1),
                               c->vout, s);
@@ -887,14 +898,15 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
     const float* inv = N > 1 ? c->cov : nullptr;
     const float* contacts = N > 1 ? c->contacts : nullptr;
     if (fork) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->side_ev[1], 0));
-    if (c->vg_leader && c->vg_leader != c) {
-      // this member's vertical GRU ran in its leader's chain, on the leader's stream
+    if (c->vg_leader && (c->vg_leader != c || c->vg_detached)) {
+      // this member's vertical GRU ran in its leader's chain, on the leader's stream - or, detached
+      // (dmp_predict_detach_group_chain), on the stream the chain was issued on, which the leader waits for too
       dmp_ctx* lead = c->vg_leader;
-      DMP_ARG(lead->vg_done_issued, "the leader of this context's vertical-GRU group has not issued the chain's last "
-                                    "unit yet (dmp_predict_next_unit answers DMP_UNIT_WAIT until it has)");
+      DMP_ARG(vg_done(lead), "the vertical-GRU chain of this context's group has not been issued to its end yet "
+                             "(dmp_predict_next_unit answers DMP_UNIT_WAIT until it has)");
       DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)lead->vg_done_ev, 0));
       lead->vg_waiters--;
-      c->vg_leader = nullptr;
+      if (lead != c) c->vg_leader = nullptr;
     }
     if (c->ext_vout && c->ext_vout_ev) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->ext_vout_ev, 0));
     rc = gru_bidir(c, 0, c->ext_vout ? c->ext_vout : c->vout, L, c->seq_b, s);
@@ -924,6 +936,7 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->vg_leader = nullptr;
   c->vg_members.clear();
   c->vg_done_issued = false;
+  c->vg_detached = 0;
   c->ext_vout = nullptr;
   c->ext_vout_ev = nullptr;
   c->last_L = L;
@@ -987,6 +1000,25 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n) {
   return DMP_OK;
 }
 
+int dmp_predict_detach_group_chain(dmp_ctx* lead) {
+  DMP_ARG(lead != nullptr, "null context");
+  DMP_ARG(lead->vg_leader == lead && lead->vg_members.size() > 1 && lead->fe_next == 0 && !lead->vg_detached,
+          "detach the chain right after dmp_predict_group_vgru (two or more members), before the leader issues a unit");
+  lead->vg_detached = 1;
+  lead->vg_waiters = (int)lead->vg_members.size();      // the leader waits for the chain's event like every member
+  lead->fe_vgru = 0;
+  lead->fe_total = 1 + lead->fe_inv + 1;
+  return DMP_OK;
+}
+
+int dmp_predict_issue_group_chain(dmp_ctx* lead, void* stream) {
+  DMP_ARG(lead != nullptr, "null context");
+  DMP_ARG(lead->vg_leader == lead && lead->vg_detached && !vg_done(lead),
+          "no detached vertical-GRU chain to issue on this context (dmp_predict_detach_group_chain, once per group)");
+  DMP_HIP(hipSetDevice(lead->device));
+  return issue_group_chain(lead, 0, STREAM);
+}
+
 int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event) {
   DMP_ARG(ctx && d_vout, "null argument");
   DMP_ARG(ctx->fe_total > 0 && ctx->fe_next == 0 && ctx->vg_leader == nullptr,
@@ -1000,8 +1032,9 @@ int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event) 
 
 int dmp_predict_next_unit(const dmp_ctx* ctx) {
   if (!ctx) return DMP_UNIT_NONE;
-  if (ctx->fe_next == ctx->fe_total - 1 && ctx->vg_leader && ctx->vg_leader != ctx && !ctx->vg_leader->vg_done_issued)
-    return DMP_UNIT_WAIT;      // the leader's chain has not been issued to its end yet
+  if (ctx->fe_next == ctx->fe_total - 1 && ctx->vg_leader && (ctx->vg_leader != ctx || ctx->vg_detached) &&
+      !vg_done(ctx->vg_leader))
+    return DMP_UNIT_WAIT;      // the group's chain has not been issued to its end yet
   if (ctx->fe_next < ctx->fe_total) return DMP_UNIT_LIGHT;
   if (ctx->passes_done > ctx->run_nloops) return DMP_UNIT_NONE;
   return (ctx->unit_next >= 1 && ctx->unit_next <= NBLOCK) ? DMP_UNIT_CONV : DMP_UNIT_LIGHT;

@@ -144,6 +144,8 @@ struct dmp_ctx {
   std::vector<dmp_ctx*> vg_members;        // leader: the members, itself first
   int vg_index = 0;                        // this context's index among its leader's members
   bool vg_done_issued = false;             // leader: the chain's last unit (and the members' outputs) has been enqueued
+                                           // (written by the thread that issues a detached chain: atomic accesses)
+  int vg_detached = 0;                     // leader: the chain is issued by dmp_predict_issue_group_chain, not by its units
   int vg_waiters = 0;                      // leader: members that have not yet enqueued their wait for vg_done_ev
   void* vg_done_ev = nullptr;              // hipEvent_t recorded behind the chain's last unit
   const float* ext_vout = nullptr;         // dmp_predict_set_vgru_result: the vertical GRU of this prediction was run ahead

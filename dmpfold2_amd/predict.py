@@ -407,6 +407,21 @@ class Pipeline:
         # Measured (bench.py, same box): 6.07-6.36 structures/s with a look-ahead of 24-176 blocks against 6.98-7.24
         # without - a step kernel's 240 workgroups (8 waves, 72 KB of LDS each) only get onto a CU when a
         # convolution workgroup retires there, so beside the convolutions the chain crawls and slows them.
+        # Detached chain: enqueuing a group's 2001 dependent launches keeps the calling thread busy for about as long
+        # as they run (kernel trace of the round-3 scheduler: between the first and the last step kernel of a
+        # chain - 58 ms - no other stream received anything, the members' inverses only started when the chain had
+        # ended).  The chain is therefore issued by a helper thread on its own stream
+        # (dmp_predict_detach_group_chain / dmp_predict_issue_group_chain) while this thread keeps issuing the
+        # members' covariance and inverse units, which run beside it.  DMP_VGRU_DETACH=0: the leader's unit as before.
+        self._detach = os.environ.get("DMP_VGRU_DETACH", "1") != "0" and S > 1 and self._group_max > 1
+        self._chain_stream = None
+        self._chain_pool = None
+        self._chain_futures = []
+        if self._detach:
+            from concurrent.futures import ThreadPoolExecutor
+            with torch.cuda.device(self.device):
+                self._chain_stream = torch.cuda.Stream(device=self.device)
+            self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
         self._lookahead = int(os.environ.get("DMP_VGRU_LOOKAHEAD", "0")) if S > 1 else 0
         self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain)
         self._fe = None
@@ -417,7 +432,23 @@ class Pipeline:
             fe.set_weights(state_dict)
             self._fe = fe
 
+    def _reap_chains(self, wait=False):
+        """Surface an error of the helper thread (a chain that failed to enqueue) in the scheduler's thread."""
+        keep = []
+        for f in self._chain_futures:
+            if wait or f.done():
+                f.result()
+            else:
+                keep.append(f)
+        self._chain_futures = keep
+
     def close(self):
+        if self._chain_pool is not None:
+            try:
+                self._reap_chains(wait=True)
+            finally:
+                self._chain_pool.shutdown(wait=True)
+                self._chain_pool = None
         for e in self.engines:
             e.close()
         self.engines = []
@@ -509,6 +540,19 @@ class Pipeline:
                         x.record_stream(lead._stream)
             ctxs = (C.c_void_p * len(slots))(*[self.engines[s].ctx for s in slots])
             _lib.check(self.lib.dmp_predict_group_vgru(ctxs, len(slots)))
+            if self._detach:
+                cs = self._chain_stream
+                cs.wait_stream(torch.cuda.current_stream(self.device))
+                for s in slots:
+                    for x in self._slot[s][3]:
+                        if x is not None:
+                            x.record_stream(cs)
+                _lib.check(self.lib.dmp_predict_detach_group_chain(lead.ctx))
+                self._chain_futures.append(self._chain_pool.submit(self._issue_chain, lead.ctx, cs.cuda_stream))
+
+    def _issue_chain(self, lead_ctx, stream_handle):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dmp_predict_issue_group_chain(lead_ctx, C.c_void_p(stream_handle)))
 
     def _begin(self, s, job):
         t, d_msa, nloops, minsteps, d_tpl = job
@@ -535,6 +579,8 @@ class Pipeline:
         lib = self.lib
         gated = len(self.engines) > 1
         progressed = False
+        if self._chain_futures:
+            self._reap_chains()
         # engines whose next unit is a residual block: when there is only one, nobody else can use the
         # lane, so it may queue its next block behind the running one instead of draining first
         n_conv = sum(1 for s, e in enumerate(self.engines)
@@ -632,6 +678,7 @@ class Pipeline:
             while self._pending or any(x is not None for x in self._slot):
                 if not self._pump():
                     self._idle()
+        self._reap_chains(wait=True)
         cur = torch.cuda.current_stream(self.device)
         for e in self.engines:
             cur.wait_stream(e._stream)

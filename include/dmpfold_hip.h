@@ -234,6 +234,19 @@ int dmp_predict_next_unit(const dmp_ctx* ctx);
  * until that unit has been issued.  Results are bit-identical to ungrouped predictions.  The members must hold
  * the same weights; the leader cannot begin another prediction before every member has issued that unit. */
 int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n);
+/* Take the chain of a group of two or more out of the leader's units (call right after dmp_predict_group_vgru,
+ * before the leader issues a unit): the leader then has no vertical-GRU units either, and the whole chain - group
+ * record, every alignment row, the members' results, the event - is enqueued by ONE call of
+ * dmp_predict_issue_group_chain(lead, stream), which may come from another host thread and on another stream than
+ * any member's (enqueuing the 2001 dependent launches keeps the calling thread busy for about as long as they run;
+ * issued from the scheduler's own thread, the members' covariance / inverse units would queue up behind it instead
+ * of running beside it).  `stream` must be ordered behind the producers of every member's alignment.  Every member,
+ * the leader included, waits (event) in its last front-end unit, for which dmp_predict_next_unit answers
+ * DMP_UNIT_WAIT until the chain has been issued to its end.  While the chain is being issued the leader's other
+ * units may be issued concurrently from the scheduler's thread; no other call on the leader context is allowed.
+ * Results are bit-identical to ungrouped predictions. */
+int dmp_predict_detach_group_chain(dmp_ctx* lead);
+int dmp_predict_issue_group_chain(dmp_ctx* lead, void* stream);
 /* The vertical GRU of this prediction has been (or is being) computed ahead of time by dmp_gru_vertical /
  * dmp_gru_vertical_group on the same alignment: d_vout (L x 512, device) is its result, `event` (hipEvent_t or
  * NULL) was recorded behind it.  Call right after dmp_predict_begin_units, before any unit is issued: the

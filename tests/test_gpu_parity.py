@@ -458,22 +458,27 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
     pipe.close()
 
 
-@pytest.mark.parametrize("group,lookahead", [(1, 0), (2, 0), (4, 0), (4, 24), (3, 400)])
-def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead):
+@pytest.mark.parametrize("group,lookahead,detach", [(1, 0, 1), (2, 0, 1), (4, 0, 1), (4, 0, 0), (2, 0, 0), (4, 24, 1),
+                                                    (3, 400, 0)])
+def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead, detach):
     """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE launch chain
     (group leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so
-    groups of every size up to `group` form.  With a look-ahead the chains of the next group run beside the
+    groups of every size up to `group` form.  detach = 1 (the default): the chain is issued by a helper thread on
+    its own stream (dmp_predict_detach_group_chain / dmp_predict_issue_group_chain) while the scheduler's thread
+    issues the members' other front-end units.  With a look-ahead the chains of the next group run beside the
     predictions in flight and are handed over (dmp_predict_set_vgru_result).  Every result equals the single
     engine's, bit for bit."""
     from dmpfold2_amd import synth
     from dmpfold2_amd.predict import Pipeline, encode_aln
     monkeypatch.setenv("DMP_VGRU_GROUP", str(group))
     monkeypatch.setenv("DMP_VGRU_LOOKAHEAD", str(lookahead))
+    monkeypatch.setenv("DMP_VGRU_DETACH", str(detach))
     shapes = [(82, 200), (33, 64), (128, 300), (40, 1), (64, 257), (96, 31), (120, 129), (50, 64), (128, 17)]
     msas = [encode_aln(synth.synth_msa(L, N, 40 + i)) for i, (L, N) in enumerate(shapes)]
     dev = torch.device("cuda:0")
     pipe = Pipeline(dev, 128, 512, synth_sd, streams=4)
     assert pipe._group_max == group and (pipe._fe is not None) == (lookahead > 0)
+    assert pipe._detach == bool(detach and group > 1)
     tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 3) for m in msas]
     pipe.drain()
     pipe.sync_check()
