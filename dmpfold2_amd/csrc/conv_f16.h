@@ -128,6 +128,30 @@ __device__ __forceinline__ void ch_lane_pixel(int li, int& row, int& x) {
   else x = li < 12 ? li - 4 : (li < 20 ? li - 8 : li - 16);
 }
 
+// Issue efficiency is NOT what bounds this kernel (round 3, gpurun_out r03d, profiles/r03_conv_variants.txt).  The
+// compiler sinks a row pair's ds_reads down to their first use (a wait for a read issued two instructions earlier
+// before every third to ninth MFMA: the LDS latency shows on every row pair).  CH_PINNED=1 puts a scheduling barrier
+// behind the reads so that they stay one row pair ahead, as written (needs 188 VGPRs: CH_WPE=2 lifts the 168 cap),
+// and CH_PIPE=1 additionally software-pipelines the passes (next pass's weight fragments and first B fragment
+// fetched during the current one, 206 VGPRs).  Sustained at L = 300, same box: 0.659 ms per launch as shipped, 0.654
+// uncapped, 0.650 pinned, 0.647 pipelined (two launches in flight: 0.646 / 0.644 / 0.642 / 0.637): the stalls go and
+// 1.8 % of the time with them - the chip sits at its power cap (section 4 of DESIGN.md) and gives the issue slots
+// back as clock.  In the scheduler the shipped form is the fastest (6.95 structures/s against 6.82 .. 6.91): the
+// larger footprints take registers from the kernels that run beside the convolutions.
+#ifndef CH_PIPE
+#define CH_PIPE 0
+#endif
+#ifndef CH_WPE
+#define CH_WPE (CH_PIPE ? 2 : 3)
+#endif
+#ifndef CH_PINNED
+#define CH_PINNED CH_PIPE
+#endif
+#if CH_PINNED
+#define CH_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CH_PIN() do {} while (0)
+#endif
 // One pass of a tap column: NT taps (rows dy = PAR, PAR + 2, ..) whose weight fragments a[t][piece] sit in
 // registers, against the row pairs r = PAR, PAR + 2, .. < 19 read from the halo tile at `il`.
 // Per fragment the small products go first (w0 x1, w1 x0), then w0 x0.
@@ -142,6 +166,7 @@ __device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const ui
       bn0 = il[(r + 2) * CH_PITCH];
       bn1 = il[(r + 2) * CH_PITCH + PIECE];
     }
+    CH_PIN();                                          // the next row pair's reads stay ahead of this one's MFMAs
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int q = (r - PAR - 2 * t) / 2;
@@ -160,6 +185,47 @@ __device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const ui
   }
 }
 
+// Software-pipelined form of a pass (CH_PIPE): the pass's first B fragment arrives in (f0, f1) - loaded during
+// the previous pass - and the first fragment of the NEXT pass (at `nxt`, null at the end of a stage) is loaded
+// during the last row pair; `hook(r)` runs after the MFMAs of row pair r (the caller fetches the next pass's weight
+// fragments there), so that a pass starts with everything it needs in registers.
+template <int NT, int PAR, class Hook>
+__device__ __forceinline__ void ch_column_pass_p(const uint4 (&a)[NT][2], const uint4* il, uint4& f0, uint4& f1,
+                                                 const uint4* nxt, ch_f32x16 (&acc)[8], Hook hook) {
+  constexpr int PIECE = 2 * CH_HALO * CH_PITCH;
+  uint4 bn0 = f0, bn1 = f1;
+#pragma unroll
+  for (int r = PAR; r < 19; r += 2) {
+    const uint4 b0 = bn0, b1 = bn1;
+    if (r + 2 < 19) {
+      bn0 = il[(r + 2) * CH_PITCH];
+      bn1 = il[(r + 2) * CH_PITCH + PIECE];
+    } else if (nxt) {
+      bn0 = nxt[0];
+      bn1 = nxt[PIECE];
+    }
+    CH_PIN();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int q = (r - PAR - 2 * t) / 2;
+      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b1, acc[q]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int q = (r - PAR - 2 * t) / 2;
+      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][1], b0, acc[q]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int q = (r - PAR - 2 * t) / 2;
+      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b0, acc[q]);
+    }
+    hook(r);
+  }
+  f0 = bn0;
+  f1 = bn1;
+}
+
 // Footprint: the register budget is capped at 168 VGPRs (3 waves per SIMD; the input-tile DMA plan is
 // recomputed per stage instead of living in registers - kept there, the cap parked it and some epilogue
 // constants in 68 bytes of scratch per lane, 25 MB of extra writes per launch in WRITE_SIZE; 8 bytes remain),
@@ -168,7 +234,7 @@ __device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const ui
 // throughput mode (vertical GRU step 156 registers / 32 KB, norm 108, Gauss-Jordan update 92); uncapped
 // (194 registers) the same kernel cost the scheduler 6 % although it is faster alone.
 // grid: conv_f16_grid(tiles) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_WPE))) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
                                                                const uint16_t* __restrict__ wq,
                                                                const float* __restrict__ bias, float inv_scale,
                                                                int L, int P, int tiles, int nwork,
@@ -231,6 +297,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       for (int i = 0; i < 6; ++i) ch_dma16(src + 64 * i, w_lds_addr + 1024 * i);
     }
   };
+#if CH_PIPE
+  // software pipeline over the 80 passes: the weight fragments of pass h+1 are read from the wave's buffer in the
+  // middle of pass h (the buffer is then refilled for pass h+2), and the first B fragment of pass h+1 at its end
+  constexpr int PIECE = 2 * CH_HALO * CH_PITCH;
+  uint4 ae[3][2], ao[2][2], f0, f1;
+  wdma(0);
+  ch_wait_vm<0>();
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    ae[t][0] = w_l[t * CH_WSLOT + a_off];
+    ae[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  wdma(1);
+  for (int g = 0; g < 8; ++g) {
+    __syncthreads();                                   // every wave is done with the previous tile
+    {
+      const uint4* src = xs4 + (int64_t)g * 2 * PP;
+      const unsigned dst = lds_base + (wave * 64) * 16;
+      int t = tid;
+      asm volatile("" : "+v"(t));                    // opaque per stage: the plan is not hoisted out of the loop
+#pragma unroll
+      for (int e = 0; e < CH_IN_SLOTS / 256; ++e) ch_dma16(src + in_src(e, t), dst + e * 4096);
+      if (wave * 64 < CH_IN_SLOTS % 256) ch_dma16(src + in_src(CH_IN_SLOTS / 256, t), dst + (CH_IN_SLOTS / 256) * 4096);
+    }
+    ch_wait_vm<0>();                                   // the tile (and the odd-pass weights issued before it)
+    __syncthreads();                                   // the tile of every wave has landed
+    f0 = in_l[b_base];
+    f1 = in_l[b_base + PIECE];
+#pragma unroll 1
+    for (int dx = 0; dx < 5; ++dx) {
+      const uint4* il = in_l + b_base + dx;
+      const int h0 = 2 * (g * 5 + dx);
+      ch_column_pass_p<3, 0>(ae, il, f0, f1, il + CH_PITCH, acc, [&](int r) {
+        if (r == 6) {                                  // the odd pass's weights (in flight since the previous pass)
+          __builtin_amdgcn_sched_barrier(0);
+          ch_wait_vm<0>();
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            ao[t][0] = w_l[t * CH_WSLOT + a_off];
+            ao[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (r == 10) {                          // the buffer is free: stream the next even pass
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (h0 + 2 < 80) wdma(h0 + 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      ch_column_pass_p<2, 1>(ao, il, f0, f1, dx < 4 ? il + 1 : nullptr, acc, [&](int r) {
+        if (r == 7) {
+          __builtin_amdgcn_sched_barrier(0);
+          ch_wait_vm<0>();
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            ae[t][0] = w_l[t * CH_WSLOT + a_off];
+            ae[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (r == 11) {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (h0 + 3 < 80) wdma(h0 + 3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    }
+  }
+#else
   wdma(0);
 
   for (int g = 0; g < 8; ++g) {
@@ -277,6 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
 
+#endif
   // epilogue: undo the weight scale, bias, 4-way max, store, per-channel partial sums
   const float* bsp = bias + split * 128 + wave * 32;
   const int64_t LL = (int64_t)L * L;

@@ -79,12 +79,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
     const int kk = lane >> 5, li = lane & 31;
+    // fragments of k + 2 are read while the four MFMAs of k run (the scheduling barrier keeps the compiler from
+    // sinking the ds_reads to their first use, where their latency would show before every fourth MFMA)
+    float an0 = As[buf][kk][wm * 64 + li], an1 = As[buf][kk][wm * 64 + 32 + li];
+    float bn0 = Bs[buf][kk][wn * 64 + li], bn1 = Bs[buf][kk][wn * 64 + 32 + li];
 #pragma unroll
     for (int k = 0; k < BK; k += 2) {
-      float a0 = As[buf][k + kk][wm * 64 + li];
-      float a1 = As[buf][k + kk][wm * 64 + 32 + li];
-      float b0 = Bs[buf][k + kk][wn * 64 + li];
-      float b1 = Bs[buf][k + kk][wn * 64 + 32 + li];
+      const float a0 = an0, a1 = an1, b0 = bn0, b1 = bn1;
+      if (k + 2 < BK) {
+        an0 = As[buf][k + 2 + kk][wm * 64 + li];
+        an1 = As[buf][k + 2 + kk][wm * 64 + 32 + li];
+        bn0 = Bs[buf][k + 2 + kk][wn * 64 + li];
+        bn1 = Bs[buf][k + 2 + kk][wn * 64 + 32 + li];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);

@@ -457,8 +457,13 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_t[r] = 0.f; acc_in[r] = 0.f; }
 
+  // The weight fragments of k-step ks+1 are read from the ring while the nine MFMAs of k-step ks run: left to itself
+  // the compiler sinks every ds_read to its first use (read, wait, one MFMA, read, wait, ... - the LDS latency shows
+  // four times per k-step); the scheduling barrier behind the reads keeps them a k-step ahead.  VG_NOPIN=1: the
+  // unpinned form for comparison.
   auto compute = [&](const vg_u32x4 (&b)[VG_CK][2], int c) {
     const uint4* a_l = ring_l + (c % VG_R) * (VG_CK * VG_FRAGS * 64);
+#if defined(VG_NOPIN) || defined(VG_DBG_NOMFMA)
 #pragma unroll
     for (int ks = 0; ks < VG_CK; ++ks) {
       uint4 a[VG_FRAGS];                               // a[piece * 3 + gate]
@@ -478,6 +483,31 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
       acc_z = vg_mfma2(a[1], b[ks][0], acc_z);
       acc_t = vg_mfma2(a[2], b[ks][0], acc_t);
     }
+#else
+    uint4 an[VG_FRAGS];
+#pragma unroll
+    for (int f = 0; f < VG_FRAGS; ++f) an[f] = a_l[f * 64];
+#pragma unroll
+    for (int ks = 0; ks < VG_CK; ++ks) {
+      uint4 a[VG_FRAGS];                               // a[piece * 3 + gate]
+#pragma unroll
+      for (int f = 0; f < VG_FRAGS; ++f) a[f] = an[f];
+      if (ks + 1 < VG_CK) {
+#pragma unroll
+        for (int f = 0; f < VG_FRAGS; ++f) an[f] = a_l[((ks + 1) * VG_FRAGS + f) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc_r = vg_mfma2(a[0], b[ks][1], acc_r);         // small products first: w0 h1, w1 h0, then w0 h0
+      acc_z = vg_mfma2(a[1], b[ks][1], acc_z);
+      acc_t = vg_mfma2(a[2], b[ks][1], acc_t);
+      acc_r = vg_mfma2(a[3], b[ks][0], acc_r);
+      acc_z = vg_mfma2(a[4], b[ks][0], acc_z);
+      acc_t = vg_mfma2(a[5], b[ks][0], acc_t);
+      acc_r = vg_mfma2(a[0], b[ks][0], acc_r);
+      acc_z = vg_mfma2(a[1], b[ks][0], acc_z);
+      acc_t = vg_mfma2(a[2], b[ks][0], acc_t);
+    }
+#endif
   };
 
   // VMEM order of a wave: DMA(0 .. DIST-1) touch B(0) | slot c: B(c+1) DMA(c+DIST).  At the top of slot c+1

@@ -412,15 +412,20 @@ class Pipeline:
         # chain - 58 ms - no other stream received anything, the members' inverses only started when the chain had
         # ended).  The chain is therefore issued by a helper thread on its own stream
         # (dmp_predict_detach_group_chain / dmp_predict_issue_group_chain) while this thread keeps issuing the
-        # members' covariance and inverse units, which run beside it.  DMP_VGRU_DETACH=0: the leader's unit as before.
-        self._detach = os.environ.get("DMP_VGRU_DETACH", "1") != "0" and S > 1 and self._group_max > 1
+        # members' covariance and inverse units, which run beside it.
+        # MEASURED (bench.py, alternating runs on one box, gpurun_out r03c): slower - 5.99 / 6.11 structures/s detached
+        # against 6.95 / 6.96: beside four inverses the chain's steps take 45 us instead of 26 (their 240 workgroups
+        # wait for CU slots 2001 times), the front-end phase grows from 99 to 110 ms.  Off by default;
+        # DMP_VGRU_DETACH=1 switches it on, DMP_VGRU_CHAIN_PRIO=1 gives the chain's stream the high HIP priority.
+        self._detach = os.environ.get("DMP_VGRU_DETACH", "0") == "1" and S > 1 and self._group_max > 1
         self._chain_stream = None
         self._chain_pool = None
         self._chain_futures = []
         if self._detach:
             from concurrent.futures import ThreadPoolExecutor
             with torch.cuda.device(self.device):
-                self._chain_stream = torch.cuda.Stream(device=self.device)
+                prio = -1 if os.environ.get("DMP_VGRU_CHAIN_PRIO") == "1" else 0
+                self._chain_stream = torch.cuda.Stream(device=self.device, priority=prio)
             self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
         self._lookahead = int(os.environ.get("DMP_VGRU_LOOKAHEAD", "0")) if S > 1 else 0
         self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain)

@@ -367,19 +367,31 @@ def main():
                                            "ridge": np.float64(ridge)})
 
     # THE HEADLINE WORKLOAD ITSELF: bench target 0 (L=300, N=2000, alignment seed 0) at
-    # iterations=10, minsteps=100, with coord_fc fitted so that the first trace is protein-like (a synthetic
-    # self-avoiding 300-residue trace; the reference tree has no 300-residue structure)
+    # iterations=10, minsteps=100, on weights designed so that the reference is stable there
+    # (tools/design_coord_fc.py, measured on the GPU box): coord_fc fitted with a small ridge to a protein-like
+    # 300-residue trace (a synthetic self-avoiding one: the reference tree has no 300-residue structure) AND the 8
+    # MDS columns of the coordinate GRU's first-layer input weights scaled by 0.02.  The loop gain of recycling is
+    # (sensitivity of the coordinate GRU to its MDS inputs) x |coord_fc|; fitting alone (first attempt, ridge 0.1,
+    # unscaled) left the gain above one: the reference's own 8- and 4-thread runs ended 120 A apart.  With the
+    # scaled columns the traces still move by 15-30 A from pass to pass with the trunk's output, but the reference's
+    # thread-count noise stays at the 1e-4 A level through all 11 passes and both refinements.
     name = "fitns_L300_N2000_n10_m100"
     if want(name):
         rows300 = synth.synth_msa(300, 2000, 0)
         target = protein_like_trace(300, 0)
+        eps = np.float32(0.02)
         sd3 = dict(sd)
-        sd3["coord_fc.weight"] = fit_coord_fc(sd, rows300, target, 1e-1)
+        for k in ("coord_gru.weight_ih_l0", "coord_gru.weight_ih_l0_reverse"):
+            w = np.array(sd[k]).copy()
+            w[:, 512:520] *= eps
+            sd3[k] = w
+        sd3["coord_fc.weight"] = fit_coord_fc(sd3, rows300, target, 1e-3)
         wf3 = f"/tmp/golden_weights_{name}.pt"
         synth.save_state_dict(wf3, sd3)
         capture_case(name, rows300, 10, 100, wf3, synth.weights_checksum(sd3), stages=False, report=report,
                      store_aln=False, noise_threads=(4, 5),
-                     extra={"coord_fc": sd3["coord_fc.weight"], "target_ca": target, "ridge": np.float64(1e-1),
+                     extra={"coord_fc": sd3["coord_fc.weight"], "target_ca": target, "ridge": np.float64(1e-3),
+                            "coord_gru_mds_scale": np.float64(eps),
                             "msa_seed": np.int64(0), "msa_rows": np.int64(2000)})
 
     # a second weight set: different seed AND a different activation regime (InstanceNorm gamma / beta x 4:

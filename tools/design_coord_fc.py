@@ -1,17 +1,21 @@
 #!/usr/bin/env python
-"""GPU box: design a coord_fc (3 x 512) for which the FIRST-pass CA trace of a synthetic alignment is
-protein-like (3.8 A bonds, no clashes) with weights as small as that allows, and measure how stable the
-benchmark's full setting (iterations=10, minsteps=100) is on it.
+"""GPU box: design synthetic weights on which the benchmark's FULL setting (iterations=10, minsteps=100) at
+L=300, N=2000 is reference-stable, so that the reference itself can pin it (tests/golden/make_goldens.py).
 
-The first trace is G W^T with G (L x 512) the pass-0 coordinate-GRU output, independent of coord_fc
-(tests/golden/make_goldens.fit_coord_fc).  Regressing onto a foreign structure with a small ridge needs weights
-large enough at L=300 to make recycling expansive (the reference's own 8- and 4-thread runs then differ by tens
-of Angstrom: fixture fitns_L300_N2000_n10_m100 of the first attempt).  Designs compared here: (a) the principal
-axes of G itself scaled to 3.8 A mean bonds (the smallest weights for a given extent), (b) ridge regression onto
-the stored protein-like target with increasing ridge.  Stability proxy: the HIP path's three convolution
-arithmetics (f16x3, exact f32, bf16x6) against each other on every pass, at n=10 with m=0 and m=100; a fixture
-on which they agree to a few 1e-4 A is one on which the reference's thread-count noise is of that size too.
-The chosen W goes to gpurun_out/ and from there into the golden generator.
+The first CA trace is G W^T with G (L x 512) the pass-0 coordinate-GRU output, independent of coord_fc.  What was
+tried and measured (gpurun_out r03a / r03c, stability proxy = the HIP path's three convolution arithmetics against
+each other on every pass, at n=10 with m=0 and m=100):
+  * ridge regression of coord_fc onto a protein-like 300-residue trace, ridge 0.1 (the fixture of the first
+    attempt): protein-like after refinement, but rms|W| = 7.7 makes RECYCLING expansive even at m=0 (3e-4 A at
+    pass 0 -> 0.4 A at pass 10; the reference's own 8- and 4-thread runs end 120 A apart);
+  * larger ridges (1, 10, 100) and the principal axes of G: stable at m=0 (1e-5 .. 3e-4 A) but the first trace is
+    collapsed (bonds 0.1-1.2 A) or stretched (bonds up to 96 A) and the minimiser amplifies 1e-4 to 1-3 A;
+  * minimising the minimiser's own energy over W (Adam): does not reach a protein-like trace.
+The loop gain of recycling is (sensitivity of the coordinate GRU to its 8 MDS inputs) x |W|.  This version lowers the
+first factor instead of the second: the 8 MDS columns of coord_gru.weight_ih_l0(_reverse) are scaled by `eps`, and
+coord_fc is fitted with a SMALL ridge, so that every pass's trace stays close to the protein-like target (regular
+regime of the minimiser: 3.8 A bonds, no clashes) while the trunk, the best-of selection and both refinements run
+at the benchmark's size and depth.
 """
 import argparse, os, sys
 import numpy as np
@@ -27,7 +31,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--L", type=int, default=300)
 ap.add_argument("--N", type=int, default=2000)
 ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--ridge", type=float, nargs="*", default=[0.1, 1.0, 10.0, 100.0])
+ap.add_argument("--eps", type=float, nargs="*", default=[0.0, 0.02, 0.1, 0.3, 1.0])
+ap.add_argument("--ridge", type=float, nargs="*", default=[1e-3, 1e-1])
 ap.add_argument("--out", default="gpurun_out/coord_fc")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -36,27 +41,9 @@ st = Stages(sd, a.L, a.N)
 eng = st.eng
 L = a.L
 alnmat = encode_aln(synth.synth_msa(a.L, a.N, a.seed))
-eng.predict(alnmat, None, 0, 0)
-eng.sync_check()
-mat1d = eng.fetch("mat1d", 512 * L).reshape(512, L).clone()
-mds = eng.fetch("mds", L * 8).reshape(L, 8).clone()
-emb = torch.cat((mat1d.t().contiguous(), mds), dim=1).contiguous()
-G = st.gru_bidir(1, emb).clone()                      # (L, 512)
-torch.cuda.synchronize()
-print("G: rows", G.shape, "row norm", float(G.norm(dim=1).mean()), flush=True)
-
-
-def energy(x):
-    d = torch.cdist(x, x) + torch.eye(L, device=dev) * 1e3
-    i = torch.arange(L - 1, device=dev)
-    bond = ((d[i, i + 1] - 3.8) ** 2).sum()
-    i2 = torch.arange(L - 2, device=dev)
-    ang = (torch.relu(5.2 - d[i2, i2 + 2]) ** 2).sum() + (torch.relu(d[i2, i2 + 2] - 7.0) ** 2).sum()
-    mask = (torch.arange(L, device=dev)[:, None] - torch.arange(L, device=dev)[None, :]).abs() > 2
-    rep = (torch.relu(4.6 - d)[mask] ** 2).sum() / 2
-    r = (x - x.mean(0)).norm(dim=1)
-    comp = (torch.relu(r - (3.3 * L ** (1 / 3) + 6.0)) ** 2).sum()
-    return bond + ang + rep + 0.1 * comp
+gpath = os.path.join(ROOT, "tests", "golden", "fitns_L300_N2000_n10_m100.npz")
+T = torch.from_numpy(np.load(gpath)["target_ca"]).double().to(dev)
+T = T - T.mean(0, keepdim=True)
 
 
 def stats(x):
@@ -74,46 +61,45 @@ def rmsd(p, q):
 
 
 os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
-Gd = G.double()
-Gc = Gd - Gd.mean(0, keepdim=True)
-sv = torch.linalg.svdvals(Gc)
-print("singular values of centred G:", " ".join(f"{float(v):.3g}" for v in sv[:12]), "...", f"{float(sv[-1]):.3g}", flush=True)
-designs = []
-# (a) principal axes of G itself: the smallest weights that give the trace a given extent
-U, S, Vh = torch.linalg.svd(Gc, full_matrices=False)
-for k0 in (0, 1):
-    Wp = Vh[k0:k0 + 3]                                 # (3, 512)
-    x = Gd @ Wp.t()
-    bond = float((x[1:] - x[:-1]).norm(dim=1).mean())
-    designs.append((f"pca{k0}", (Wp * (3.8 / bond)).float()))
-# (b) ridge regression onto the stored protein-like target, increasing ridge = smaller weights
-gpath = os.path.join(ROOT, "tests", "golden", "fitns_L300_N2000_n10_m100.npz")
-if os.path.exists(gpath) and a.L == 300:
-    T = torch.from_numpy(np.load(gpath)["target_ca"]).double().to(dev)
-    T = T - T.mean(0, keepdim=True)
+for eps in a.eps:
+    sde = dict(sd)
+    for k in ("coord_gru.weight_ih_l0", "coord_gru.weight_ih_l0_reverse"):
+        w = np.array(sd[k]).copy()
+        w[:, 512:520] *= np.float32(eps)
+        sde[k] = w
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sde.items()})
+    eng.predict(alnmat, None, 0, 0)
+    eng.sync_check()
+    mat1d = eng.fetch("mat1d", 512 * L).reshape(512, L).clone()
+    mds = eng.fetch("mds", L * 8).reshape(L, 8).clone()
+    emb = torch.cat((mat1d.t().contiguous(), mds), dim=1).contiguous()
+    Gd = st.gru_bidir(1, emb).clone().double()           # (L, 512)
+    torch.cuda.synchronize()
     for ridge in a.ridge:
         A = Gd @ Gd.t() + ridge * torch.eye(L, dtype=torch.float64, device=dev)
-        designs.append((f"ridge{ridge:g}", (Gd.t() @ torch.linalg.solve(A, T)).t().float()))
-for tag, Wf in designs:
-    Wf = Wf.contiguous()
-    x = G @ Wf.t()
-    print(f"{tag}: max|W| {float(Wf.abs().max()):.2f} rms W {float((Wf ** 2).mean().sqrt()):.3f}  first trace: {stats(x)}", flush=True)
-    sd2 = dict(sd)
-    sd2["coord_fc.weight"] = Wf.cpu().numpy()
-    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd2.items()})
-    for (n, m) in ((10, 0), (10, 100)):
-        runs = {}
-        for mode in (0, 1, 2):
-            eng.set_option("conv_mode", mode)
-            coords, confs = eng.predict(alnmat, None, n, m)
-            eng.sync_check()
-            runs[mode] = (coords.cpu(), confs.cpu(), eng.fetch("ca_pass", 11 * L * 3).reshape(11, L, 3).cpu(),
-                          eng.fetch("conf_means", 11).cpu())
-        eng.set_option("conv_mode", 0)
-        for mo in (1, 2):
-            per = [rmsd(runs[0][2][p], runs[mo][2][p]) for p in range(11)]
-            print(f"   n={n} m={m} mode 0 vs {mo}: final CA-RMSD {rmsd(runs[0][0][:, 1], runs[mo][0][:, 1]):.2e} max|dconf| "
-                  f"{float((runs[0][1] - runs[mo][1]).abs().max()):.2e} per pass " + " ".join(f"{v:.1e}" for v in per), flush=True)
-        print("   conf means", " ".join(f"{float(v):.4f}" for v in runs[0][3]),
-              " first trace of the run:", stats(runs[0][2][0].to(dev)), " final:", stats(runs[0][0][:, 1].to(dev)), flush=True)
-    np.save(f"{a.out}_L{a.L}_{tag}.npy", Wf.cpu().numpy())
+        Wf = (Gd.t() @ torch.linalg.solve(A, T)).t().float().contiguous()
+        x = Gd.float() @ Wf.t()
+        tag = f"eps{eps:g}_ridge{ridge:g}"
+        print(f"{tag}: max|W| {float(Wf.abs().max()):.2f} rms W {float((Wf ** 2).mean().sqrt()):.3f}  first trace: {stats(x)}  "
+              f"fit rmsd {rmsd(x.double(), T):.3f}", flush=True)
+        sd2 = dict(sde)
+        sd2["coord_fc.weight"] = Wf.cpu().numpy()
+        eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd2.items()})
+        for (n, m) in ((10, 0), (10, 100)):
+            runs = {}
+            for mode in (0, 1, 2):
+                eng.set_option("conv_mode", mode)
+                coords, confs = eng.predict(alnmat, None, n, m)
+                eng.sync_check()
+                runs[mode] = (coords.cpu(), confs.cpu(), eng.fetch("ca_pass", 11 * L * 3).reshape(11, L, 3).cpu(),
+                              eng.fetch("conf_means", 11).cpu())
+            eng.set_option("conv_mode", 0)
+            for mo in (1, 2):
+                per = [rmsd(runs[0][2][p], runs[mo][2][p]) for p in range(11)]
+                print(f"   n={n} m={m} mode 0 vs {mo}: final CA-RMSD {rmsd(runs[0][0][:, 1], runs[mo][0][:, 1]):.2e} max|dconf| "
+                      f"{float((runs[0][1] - runs[mo][1]).abs().max()):.2e} per pass " + " ".join(f"{v:.1e}" for v in per), flush=True)
+            moved = [rmsd(runs[0][2][p], runs[0][2][0]) for p in range(11)]
+            print("   conf means", " ".join(f"{float(v):.4f}" for v in runs[0][3]),
+                  " trace of pass p against pass 0:", " ".join(f"{v:.2g}" for v in moved),
+                  " final:", stats(runs[0][0][:, 1].to(dev)), flush=True)
+        np.save(f"{a.out}_L{a.L}_{tag}.npy", Wf.cpu().numpy())
