@@ -409,6 +409,33 @@ def main(argv=None):
                 "ca_rmsd_A": rmsd, "max_dconf": dconf, "same_input": same_input,
                 "ok": bool(same_input and rmsd <= 1e-3 and dconf < 1e-4)}
             ok = ok and verify["reference_golden_L300_N2000_n1_m0"]["ok"]
+        # (4) THE METRIC'S CONFIGURATION ITSELF against the reference: bench target 0 at iterations=10,
+        #     minsteps=100 on the weight set on which the reference is stable there (coord_fc fitted to a
+        #     protein-like trace, MDS feedback attenuated: tests/golden/fitns_L300_N2000_n10_m100.npz holds the
+        #     reference's output, its thread-count floor and the fitted matrix; data only).  Own engine: the
+        #     pipeline's weights stay untouched.
+        gpath = os.path.join(ROOT, "tests", "golden", "fitns_L300_N2000_n10_m100.npz")
+        if os.path.exists(gpath):
+            from dmpfold2_amd.predict import Engine
+            g = np.load(gpath)
+            sdh = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]))
+            eh = Engine(device, L_NS, N_NS)
+            try:
+                eh.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sdh.items()})
+                gc, gf = eh.predict_device(targets[0], None, ITERS, MINSTEPS)
+                eh.sync_check()
+                d = gc.cpu().numpy()[:, 1].astype(np.float64) - g["coords"][:, 1].astype(np.float64)
+                rmsd = float(np.sqrt((d ** 2).sum(-1).mean()))
+                dconf = float(np.abs(gf.cpu().numpy() - g["confs"]).max())
+                floor = float(g["noise_ca_rmsd"])
+                same = (hashlib.sha256(targets[0].cpu().numpy().tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+                        and synth.weights_checksum(sdh) == bytes(g["weights_sha256"]).decode())
+                verify["reference_golden_L300_N2000_n10_m100"] = {
+                    "ca_rmsd_A": rmsd, "max_dconf": dconf, "reference_thread_noise_A": floor, "same_input": bool(same),
+                    "ok": bool(same and rmsd <= max(1e-3, 3.0 * floor) and dconf < 1e-4)}
+                ok = ok and verify["reference_golden_L300_N2000_n10_m100"]["ok"]
+            finally:
+                eh.close()
 
     # ---- host side of one aln_to_coords call (SURVEY 8d's unit of work; outside the timed region, whose
     #      inputs are resident in HBM): alignment file -> rows -> residue codes -> device, and the PDB text

@@ -419,6 +419,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(seq_abort, 2);      // [0] fault word of the prediction in flight, [1] faults latched by finished ones
   A_(refine_gx, 2 * 3 * L);
   A_(z0, (int64_t)STEM_OUT * LL);
+  A_(planes, (int64_t)(NS * NS + 1) * LL);
   A_(dmap, LL);
   A_(u, (int64_t)CW * LL);
   A_(xa, (int64_t)CW * P * P);

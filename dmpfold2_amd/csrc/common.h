@@ -167,6 +167,7 @@ struct dmp_ctx {
   int refine_xcd = 0;                    // XCD the minimiser cluster of this context runs on
   // pair trunk
   float* z0 = nullptr;      // [384][L][L]
+  float* planes = nullptr;  // [442][L][L]: the coupling channels 21a+b and the contact channel as planes (stem_static's B operand)
   float* dmap = nullptr;    // [L][L]
   float* u = nullptr;       // [128][L][L]
   float* xa = nullptr;      // padded activations

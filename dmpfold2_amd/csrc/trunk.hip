@@ -5,6 +5,7 @@
 // interior at [2, 2+L): the 5x5 halo reads need no bounds checks and the conv tiles of
 // 16x16 pixels never straddle the border logic.  The pre-norm maxout output `u` is dense.
 #include "common.h"
+#include <type_traits>
 #define CONV_BF16_KERNELS
 #include "conv_bf16.h"
 #define CONV_F16_KERNELS
@@ -100,22 +101,48 @@ int act_clear(float* d_xpad, int L, hipStream_t s) {
 // stem, input-independent part (once per structure)
 //   Z0[o,i,j] = b_o + sum_{c<512} W[o,c] m[c,i] m[c,j]
 //             + sum_{a,b} W[o,512+21a+b] inv[21i+a, 21j+b] + W[o,953] contacts[i,j]
-// GEMM per row i: M = 384 output channels (A = W^T[k][o]), N = 64 columns j, K = 954, the B
-// operand is generated on the fly from m / inv / contacts.  f32 MFMA 32x32x2.
-// grid: (ceil(L/64), L)   block: 256 (wave w owns channel blocks 3w..3w+2)
+// GEMM M = 384 output channels (A = W^T[k][o]), N = 64 consecutive pixels, K = 954 on the f32 matrix cores
+// (32x32x2; same k pairing and order as before: results unchanged bit for bit).  Round 3: the coupling channels
+// are first re-laid as planes[21a+b][i][j] (stem_planes_kernel: coalesced rows of the inverse through LDS; the
+// contact map becomes plane 441), so every B operand is a coalesced load, and the k loop is software-pipelined in
+// chunks of 8 k pairs - the loads of chunk c+1 are issued before the MFMAs of chunk c and pinned there (the
+// round-2 kernel gathered inv with an 84-byte lane stride and waited for every load right where it was issued:
+// 1.8 ms = 0.23 of the f32 MFMA peak at L = 300).
+// grid: ceil(L*L/64)   block: 256 (wave w owns channel blocks 3w..3w+2)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stem_static_kernel(const float* __restrict__ wT,
-                                                          const float* __restrict__ bias,
-                                                          const float* __restrict__ m,
-                                                          const float* __restrict__ inv,
-                                                          const float* __restrict__ contacts, int L,
-                                                          float* __restrict__ z0) {
+constexpr int SP_JT = 256;      // columns j per workgroup of the re-layout kernel
+// grid: (ceil(L/SP_JT), L rows i, 21 a)   block: 256
+__global__ __launch_bounds__(256) void stem_planes_kernel(const float* __restrict__ inv, int L,
+                                                          float* __restrict__ planes) {
+  __shared__ float row[SP_JT * NS];
+  const int j0 = blockIdx.x * SP_JT, i = blockIdx.y, a = blockIdx.z;
+  const int nj = min(SP_JT, L - j0);
+  const int64_t D = (int64_t)L * NS, LL = (int64_t)L * L;
+  const float* src = inv + ((int64_t)i * NS + a) * D + (int64_t)j0 * NS;
+  for (int t = threadIdx.x; t < nj * NS; t += 256) row[t] = src[t];
+  __syncthreads();
+  const int j = threadIdx.x;
+  if (j < nj) {
+#pragma unroll
+    for (int b = 0; b < NS; ++b) planes[(int64_t)(a * NS + b) * LL + (int64_t)i * L + j0 + j] = row[j * NS + b];
+  }
+}
+
+constexpr int SS_CH = 8;        // k pairs per pipeline chunk
+__global__ __launch_bounds__(256, 2) void stem_static_kernel(const float* __restrict__ wT,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ m,
+                                                             const float* __restrict__ planes, int L,
+                                                             float* __restrict__ z0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 5, li = lane & 31;
-  const int i = blockIdx.y, j0 = blockIdx.x * 64;
-  const int jq[2] = {j0 + li, j0 + 32 + li};
-  const bool ok[2] = {jq[0] < L, jq[1] < L};
-  const int64_t D = (int64_t)L * NS;
+  const int64_t LL = (int64_t)L * L;
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  const int64_t pq[2] = {p0 + li, p0 + 32 + li};
+  const bool ok[2] = {pq[0] < LL, pq[1] < LL};
+  const int64_t pc[2] = {ok[0] ? pq[0] : LL - 1, ok[1] ? pq[1] : LL - 1};      // clamped: loads stay in range
+  const int iq[2] = {(int)(pc[0] / L), (int)(pc[1] / L)};
+  const int jq[2] = {(int)(pc[0] - (int64_t)iq[0] * L), (int)(pc[1] - (int64_t)iq[1] * L)};
 
   f32x16 acc[3][2];
 #pragma unroll
@@ -125,42 +152,98 @@ __global__ __launch_bounds__(256) void stem_static_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][q][r] = 0.f;
 
-  const float* wbase = wT + wave * 96 + li;
-  auto step = [&](int k, float b0, float b1) {
-    const float* wk = wbase + (int64_t)k * STEM_OUT;
+  // buffer loads: 128-bit descriptor + wave-uniform byte offset of the k pair (scalar) + a 32-bit lane offset that
+  // is fixed for the whole loop (with flat loads the compiler kept a 64-bit address per load in flight and spilled)
+  const unsigned woff = 4u * (unsigned)(kk * STEM_OUT + wave * 96 + li);
+  const unsigned moff_i[2] = {4u * (unsigned)(kk * L + iq[0]), 4u * (unsigned)(kk * L + iq[1])};
+  const unsigned moff_j[2] = {4u * (unsigned)(kk * L + jq[0]), 4u * (unsigned)(kk * L + jq[1])};
+  const unsigned poff[2] = {4u * (unsigned)(kk * LL + pc[0]), 4u * (unsigned)(kk * LL + pc[1])};
+  constexpr int NCH1 = WIDTH / 2 / SS_CH;                           // 32 chunks of outer-product channels
+  const int npairs = planes ? (STEM_IN - 1) / 2 : WIDTH / 2;        // 477 (k = 0..953) or 256
+  const int nchunks = (npairs + SS_CH - 1) / SS_CH;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wT), 0, (STEM_IN - 1) * STEM_OUT * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m), 0, WIDTH * L * 4, 0x00020000);
+  auto ldb = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
+  float av[2][SS_CH][3], r0[2][SS_CH][2], r1[2][SS_CH][2];
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  // chunk c -> registers of buffer BUF.  Phase 1 (k < 512): B = r0 * r1 = m[k][i] m[k][j]; phase 2: B = r0 = plane
+  auto load1 = [&](auto BUF, int c) {
+    constexpr int buf = decltype(BUF)::value;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float av = wk[a * 32];
-      acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[a][0], 0, 0, 0);
-      acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[a][1], 0, 0, 0);
+    for (int u = 0; u < SS_CH; ++u) {
+      const unsigned k2 = 2u * (unsigned)(c * SS_CH + u);           // uniform
+#pragma unroll
+      for (int x = 0; x < 3; ++x) av[buf][u][x] = ldb(wrs, woff + 128u * x, k2 * (STEM_OUT * 4u));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        r0[buf][u][q] = ldb(mrs, moff_i[q], k2 * (4u * (unsigned)L));
+        r1[buf][u][q] = ldb(mrs, moff_j[q], k2 * (4u * (unsigned)L));
+      }
     }
   };
-  // outer-product channels
-#pragma unroll 4
-  for (int p = 0; p < 256; ++p) {
-    const int k = 2 * p + kk;
-    const float mi = m[(int64_t)k * L + i];
-    const float b0 = ok[0] ? mi * m[(int64_t)k * L + jq[0]] : 0.f;
-    const float b1 = ok[1] ? mi * m[(int64_t)k * L + jq[1]] : 0.f;
-    step(k, b0, b1);
-  }
-  if (inv != nullptr) {
-    // coupling channels 512 .. 952 (k = 512 + 21a + b), contact channel 953
-#pragma unroll 2
-    for (int p = 256; p < 477; ++p) {
-      const int k = 2 * p + kk;
-      float b0 = 0.f, b1 = 0.f;
-      if (k < 953) {
-        const int ab = k - 512;
-        const int a = ab / NS, b = ab - a * NS;
-        const float* row = inv + ((int64_t)i * NS + a) * D + b;
-        if (ok[0]) b0 = row[(int64_t)jq[0] * NS];
-        if (ok[1]) b1 = row[(int64_t)jq[1] * NS];
-      } else {
-        if (ok[0]) b0 = contacts[(int64_t)i * L + jq[0]];
-        if (ok[1]) b1 = contacts[(int64_t)i * L + jq[1]];
+  auto load2 = [&](auto BUF, int c) {
+    constexpr int buf = decltype(BUF)::value;
+    // the chunk's 16 planes through their own descriptor (the whole tensor may exceed 4 GB); pairs past the last
+    // one (the padded tail of the last chunk) read out of range, which a buffer load answers with 0
+    const int k0 = 2 * c * SS_CH;
+    const int live_k = min(2 * SS_CH, 2 * npairs - k0);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(planes) + (int64_t)(k0 - WIDTH) * LL, 0, (int)((int64_t)live_k * LL * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(wT) + (int64_t)k0 * STEM_OUT, 0, live_k * STEM_OUT * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < SS_CH; ++u) {
+#pragma unroll
+      for (int x = 0; x < 3; ++x) av[buf][u][x] = ldb(wr2, woff + 128u * x, 2u * u * (STEM_OUT * 4u));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) r0[buf][u][q] = ldb(prs, poff[q], 2u * u * (4u * (unsigned)LL));
+    }
+  };
+  auto compute = [&](auto BUF, auto PHASE) {
+    constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+    for (int u = 0; u < SS_CH; ++u) {
+      float b0 = r0[buf][u][0], b1 = r0[buf][u][1];
+      if (decltype(PHASE)::value == 1) { b0 *= r1[buf][u][0]; b1 *= r1[buf][u][1]; }
+      b0 = ok[0] ? b0 : 0.f;
+      b1 = ok[1] ? b1 : 0.f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][a], b0, acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][a], b1, acc[a][1], 0, 0, 0);
       }
-      step(k, b0, b1);
+    }
+  };
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  // the loads of chunk c+1 are issued before the MFMAs of chunk c and pinned there (scheduling barriers)
+  load1(B0{}, 0);
+#pragma unroll 1
+  for (int c = 0; c < NCH1; c += 2) {                               // NCH1 is even: chunk c lives in buffer c & 1
+    load1(B1{}, c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(B0{}, P1{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < NCH1) load1(B0{}, c + 2);
+    else if (c + 2 < nchunks) load2(B0{}, c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(B1{}, P1{});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll 1
+  for (int c = NCH1; c < nchunks; c += 2) {
+    if (c + 1 < nchunks) load2(B1{}, c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(B0{}, P2{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < nchunks) {
+      if (c + 2 < nchunks) load2(B0{}, c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(B1{}, P2{});
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -171,7 +254,7 @@ __global__ __launch_bounds__(256) void stem_static_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = wave * 96 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        z0[((int64_t)o * L + i) * L + jq[q]] = acc[a][q][r] + bias[o];
+        z0[(int64_t)o * LL + pq[q]] = acc[a][q][r] + bias[o];
       }
     }
 }
@@ -179,8 +262,16 @@ __global__ __launch_bounds__(256) void stem_static_kernel(const float* __restric
 int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const float* d_contacts,
                 int L, float* d_z0, hipStream_t s) {
   const Weights& W = c->W;
-  hipLaunchKernelGGL(stem_static_kernel, dim3(cdiv(L, 64), L), dim3(256), 0, s, W.stemT, W.stem_b,
-                     d_mat1d, d_inv, d_contacts, L, d_z0);
+  const int64_t LL = (int64_t)L * L;
+  const float* planes = nullptr;
+  if (d_inv != nullptr) {
+    hipLaunchKernelGGL(stem_planes_kernel, dim3(cdiv(L, SP_JT), L, NS), dim3(256), 0, s, d_inv, L, c->planes);
+    DMP_LAUNCH_CHECK();
+    DMP_HIP(hipMemcpyAsync(c->planes + (int64_t)NS * NS * LL, d_contacts, sizeof(float) * LL, hipMemcpyDeviceToDevice, s));
+    planes = c->planes;
+  }
+  hipLaunchKernelGGL(stem_static_kernel, dim3((unsigned)cdiv64(LL, 64)), dim3(256), 0, s, W.stemT, W.stem_b,
+                     d_mat1d, planes, L, d_z0);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

@@ -126,6 +126,19 @@ def weights_checksum(sd) -> str:
     return h.hexdigest()
 
 
+def headline_fixture_weights(coord_fc, mds_scale, seed: int = 0, coord_scale: float = 5.0):
+    """The weight set of the fixture that pins the benchmark's full setting (tests/golden/make_goldens.py,
+    fitns_L300_N2000_n10_m100): synth_weights(seed) with the 8 MDS columns of the coordinate GRU's first-layer
+    input weights scaled by `mds_scale` and `coord_fc` replaced by the fitted matrix stored in the fixture."""
+    sd = dict(synth_weights(seed, coord_scale=coord_scale))
+    for k in ("coord_gru.weight_ih_l0", "coord_gru.weight_ih_l0_reverse"):
+        w = np.array(sd[k]).copy()
+        w[:, WIDTH:WIDTH + 8] *= np.float32(mds_scale)
+        sd[k] = w
+    sd["coord_fc.weight"] = np.ascontiguousarray(coord_fc, dtype=np.float32)
+    return sd
+
+
 def synth_msa(L: int, N: int, seed: int = 0):
     """Synthetic alignment as a list of N strings of length L.
 

@@ -20,7 +20,9 @@ def rmsd(a, b):
 for name in sys.argv[1:] or ["pf10963_n10_m0"]:
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     sd = synth.synth_weights(0, coord_scale=5.0)
-    if "coord_fc" in g.files:
+    if "coord_gru_mds_scale" in g.files:
+        sd = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]))
+    elif "coord_fc" in g.files:
         sd["coord_fc.weight"] = g["coord_fc"]
     n, m = int(g["iterations"]), int(g["minsteps"])
     L = g["coords"].shape[0]
