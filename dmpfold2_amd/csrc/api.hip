@@ -370,7 +370,7 @@ const char* dmp_last_error(void) { return g_err; }
 
 int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   DMP_ARG(out != nullptr, "out is NULL");
-  DMP_ARG(max_L >= 8 && max_L <= 1280, "max_L must be in [8, 1280], got %d", max_L);
+  DMP_ARG(max_L >= 8 && max_L <= DMP_MAX_L, "max_L must be in [8, %d], got %d", DMP_MAX_L, max_L);
   DMP_ARG(max_N >= 1, "max_N must be >= 1, got %d", max_N);
   if (max_N > DMP_MAX_SEQS) max_N = DMP_MAX_SEQS;
   DMP_HIP(hipSetDevice(device));

@@ -34,6 +34,7 @@ default_iterations = 10
 default_minsteps = 100
 
 MAX_SEQS = 3000     # predict.py:130-132
+MAX_L = 1280        # include/dmpfold_hip.h DMP_MAX_L (the reference has no limit)
 
 _RESNAMES = {0: "ALA", 1: "ARG", 2: "ASN", 3: "ASP", 4: "CYS", 5: "GLN", 6: "GLU", 7: "GLY",
              8: "HIS", 9: "ILE", 10: "LEU", 11: "LYS", 12: "MET", 13: "PHE", 14: "PRO",
@@ -429,7 +430,11 @@ class Pipeline:
             self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
         self._lookahead = int(os.environ.get("DMP_VGRU_LOOKAHEAD", "0")) if S > 1 else 0
         self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain)
+        self._ahead_pending = None    # (future, jobs, outs): a look-ahead chain the helper thread is still enqueuing
         self._fe = None
+        if self._lookahead > 0 and self._chain_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
         if self._lookahead > 0:
             with torch.cuda.device(self.device):
                 st = torch.cuda.Stream(device=self.device)
@@ -450,6 +455,9 @@ class Pipeline:
     def close(self):
         if self._chain_pool is not None:
             try:
+                if self._ahead_pending is not None:
+                    self._ahead_pending[0].result()
+                    self._ahead_pending = None
                 self._reap_chains(wait=True)
             finally:
                 self._chain_pool.shutdown(wait=True)
@@ -497,7 +505,9 @@ class Pipeline:
 
     def _start_ahead(self, jobs):
         """The vertical GRUs of these queued targets as one chain on the look-ahead stream, beside whatever the
-        engines are doing."""
+        engines are doing.  Enqueued by the helper thread (the 2001 launches keep the enqueuing thread busy for about
+        as long as they run, and this thread has the engines' last units to issue); the targets are started only
+        once the chain has been enqueued to its end (`_ahead_ready`)."""
         fe = self._fe
         cur = torch.cuda.current_stream(self.device)
         fe._stream.wait_stream(cur)
@@ -507,16 +517,32 @@ class Pipeline:
         for job, out in zip(jobs, outs):
             job[1].record_stream(fe._stream)
             out.record_stream(fe._stream)
-        ctxs = (C.c_void_p * k)(*[fe.ctx] * k)
-        mp = (C.c_void_p * k)(*[job[1].data_ptr() for job in jobs])
-        op = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
-        Ns = (C.c_int * k)(*[job[1].shape[0] for job in jobs])
-        Ls = (C.c_int * k)(*[job[1].shape[1] for job in jobs])
-        _lib.check(self.lib.dmp_gru_vertical_group(ctxs, k, mp, Ns, Ls, op, fe.stream()))
-        ev = torch.cuda.Event()
-        ev.record(fe._stream)
+
+        def issue():
+            with torch.cuda.device(self.device):
+                ctxs = (C.c_void_p * k)(*[fe.ctx] * k)
+                mp = (C.c_void_p * k)(*[job[1].data_ptr() for job in jobs])
+                op = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
+                Ns = (C.c_int * k)(*[job[1].shape[0] for job in jobs])
+                Ls = (C.c_int * k)(*[job[1].shape[1] for job in jobs])
+                _lib.check(self.lib.dmp_gru_vertical_group(ctxs, k, mp, Ns, Ls, op, fe.stream()))
+                ev = torch.cuda.Event()
+                ev.record(fe._stream)
+                return ev
+        self._ahead_pending = (self._chain_pool.submit(issue), jobs, outs)
+
+    def _ahead_ready(self):
+        """True when no look-ahead chain is still being enqueued; hands a finished one over to `_ahead`."""
+        if self._ahead_pending is None:
+            return True
+        fut, jobs, outs = self._ahead_pending
+        if not fut.done():
+            return False
+        ev = fut.result()
         for job, out in zip(jobs, outs):
             self._ahead[job[0]] = (out, ev)
+        self._ahead_pending = None
+        return True
 
     def _begin_group(self, slots):
         """Start the next len(slots) queued targets on these free engines; those whose vertical GRU was not run
@@ -594,11 +620,11 @@ class Pipeline:
         if self._fe is not None and self._pending and len(free) < len(self.engines):
             # look-ahead: one group of queued targets at a time, once every prediction in flight is near its end
             nxt = self._pending[:self._group_max]
-            if not any(j[0] in self._ahead for j in nxt) and all(
+            if self._ahead_ready() and not any(j[0] in self._ahead for j in nxt) and all(
                     self._total[r] - self._done[r] <= self._lookahead
                     for r in range(len(self.engines)) if self._slot[r] is not None):
                 self._start_ahead(nxt)
-        if free and self._pending:
+        if free and self._pending and self._ahead_ready():
             # engines about to finish: wait for them and start together (one vertical-GRU chain for the group)
             soon = [r for r in range(len(self.engines)) if self._slot[r] is not None
                     and self._total[r] - self._done[r] <= self._group_patience]
@@ -747,6 +773,9 @@ _ENGINES = {}
 def get_engine(device, L, N, weights_file=None, state_dict=None):
     """Cached engine for `device`, grown when an alignment exceeds its capacity; weights are
     packed once per (engine, weights file)."""
+    if L > MAX_L:
+        raise RuntimeError(f"alignment has {L} columns; this build supports at most {MAX_L} "
+                           "(include/dmpfold_hip.h DMP_MAX_L: the eigensolver's LDS image)")
     dev = _resolve_device(device)
     eng = _ENGINES.get(dev.index)
     if eng is None or L > eng.max_L or min(N, MAX_SEQS) > eng.max_N:

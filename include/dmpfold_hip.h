@@ -56,7 +56,13 @@ const char* dmp_last_error(void);
 
 /* ---- context ------------------------------------------------------------------------
  * Allocates every device buffer the path needs for alignments up to max_N x max_L
- * (max_N is clamped to DMP_MAX_SEQS).  No allocation happens after this call. */
+ * (max_N is clamped to DMP_MAX_SEQS).  No allocation happens after this call.
+ * DEVIATION from the reference, which has no length limit (network.py:218-221): 8 <= max_L <= DMP_MAX_L.
+ * The eigensolver keeps 11 vectors of length L in one workgroup's LDS (112 KB at 1280) and its row kernels hold
+ * 5 x 256 columns per thread block; dmp_ctx_create answers DMP_ERR_ARG ("max_L must be in [8, 1280]") for more,
+ * and the Python front end raises RuntimeError naming the alignment's length before anything is computed.  The
+ * largest configuration of BASELINE.json (L = 1000) needs 8.5 GB of the 288. */
+#define DMP_MAX_L 1280
 int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out);
 void dmp_ctx_destroy(dmp_ctx* ctx);
 /* bytes of device memory held by the context */

@@ -40,7 +40,7 @@ def small_engine(synth_sd):
     eng.close()
 
 
-def _check_passes(eng, g, P, L, tol):
+def _check_passes(eng, g, P, L, tol, first=0):
     """Every pass's confidence mean and CA trace - INTERMEDIATE quantities, not outputs of aln_to_coords (the
     final structure is checked by the callers at the plain north-star tolerance wherever the fixture's own
     thread-noise floor allows).  Recycling is expansive over its first passes before it settles: the
@@ -55,7 +55,9 @@ def _check_passes(eng, g, P, L, tol):
     ca_pass = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
     floor = g["noise_ca_pass"] if "noise_ca_pass" in g else np.full(P, float(g["noise_ca_rmsd"]))
     dev = np.array([ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P)])
-    assert (dev <= np.maximum(tol, 4.0 * floor)).all(), (dev, floor)
+    # first = 1 with minsteps > 0: the fixture's pass-0 trace is the coordinate head's output, the engine records it
+    # after the first refinement (network.py:257-258) - that trace is checked through the final structure instead
+    assert (dev[first:] <= np.maximum(tol, 4.0 * floor)[first:]).all(), (dev, floor)
     return dev
 
 
@@ -156,7 +158,7 @@ def test_headline_workload_with_minimiser_vs_reference(mode):
         coords, confs = eng.predict(alnmat, None, 10, 100)
         eng.sync_check()
         coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
-        dev = _check_passes(eng, g, 11, 300, 1e-3)
+        dev = _check_passes(eng, g, 11, 300, 1e-3, first=1)
         final = ca_rmsd(coords[:, 1], g["coords"][:, 1])
         print("headline workload", mode, "per-pass CA-RMSD", dev, "final", final, "max|dconf|", np.abs(confs - g["confs"]).max())
         assert final <= max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))

@@ -484,3 +484,17 @@ def test_bench_stub_world_8_over_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["ranks"] == 8
     assert out["ms_per_step"] >= 0.02 * 8 * 1e3 * 0.95           # the slowest rank (rank 7) sets the time
+
+
+def test_length_limit_is_reported_before_anything_runs(tmp_path):
+    """The reference has no length cap; this build's is DMP_MAX_L = 1280 (include/dmpfold_hip.h): the drop-in raises
+    RuntimeError naming the length before touching the device, and dmp_ctx_create refuses the size."""
+    import ctypes as C
+    from dmpfold2_amd import _lib, predict
+    assert predict.MAX_L == 1280
+    with pytest.raises(RuntimeError, match="1281 columns"):
+        predict.get_engine("cuda:0", 1281, 4, state_dict={})
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    assert lib.dmp_ctx_create(0, 1281, 4, C.byref(ctx)) != 0
+    assert b"1280" in lib.dmp_last_error()
