@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import shard
-from .predict import (Pipeline, default_iterations, default_minsteps, encode_aln, load_state_dict,
+from .predict import (MAX_SEQS, Pipeline, default_iterations, default_minsteps, encode_aln, load_state_dict,
                       pdb_text, read_a3m, read_aln, read_template_ca)
 
 
@@ -137,58 +137,128 @@ def write_result(out_dir, aln_path, coords, confs, alnmat, fmt="pdb"):
     return path
 
 
+class _StaticQueue:
+    """This rank's share of a static partition (shard.partition_targets on the header scans), longest first."""
+
+    def __init__(self, indices):
+        self._it = iter(indices)
+
+    def take(self):
+        return next(self._it, None)
+
+
+class _SharedQueue:
+    """One queue for all ranks: the targets in descending order of estimated cost, handed out by an atomic counter
+    in the job's torch.distributed key-value store (host side; no collective, nothing on the data path).  A rank
+    that finishes early simply keeps taking targets: no tail of idle GPUs behind a mis-estimated partition."""
+
+    def __init__(self, order, store, key="dmpfold_batch_next"):
+        self._order, self._store, self._key = list(order), store, key
+
+    def take(self):
+        k = int(self._store.add(self._key, 1)) - 1
+        return self._order[k] if k < len(self._order) else None
+
+
+def cost_order(targets, iterations):
+    """(indices in descending order of estimated cost, scans): identical on every rank."""
+    scans = [scan_target(a) for a, _ in targets]
+    costs = [shard.estimate_cost(L, N, iterations) for L, N in scans]
+    return sorted(range(len(targets)), key=lambda i: (-costs[i], i)), scans
+
+
 def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_minsteps,
-              weights_file=None, state_dict=None, streams=4, device=None, rank=0, world=1, fmt="pdb"):
-    """Predict the targets of this rank's shard; returns (number done, seconds, [output paths])."""
+              weights_file=None, state_dict=None, streams=4, device=None, rank=0, world=1, fmt="pdb", store=None):
+    """Predict this rank's targets; returns (number done, seconds, [output paths]).
+
+    Which targets those are: with `store` (a torch.distributed key-value store shared by the ranks of the job) every
+    rank takes the next most expensive target from ONE shared queue whenever it has room; without it the static
+    partition of `plan_shard`.  Either way a rank reads and encodes only the targets it takes, reading / encoding,
+    the GPU and the writing of finished structures overlap (targets are submitted while others run and results are
+    written as they complete), and a failing target never costs the others their results."""
     if fmt not in ("pdb", "ca", "npz"):
         raise ValueError(f"unknown output format {fmt!r} (pdb, ca, npz)")
     check_output_stems(targets)
     os.makedirs(out_dir, exist_ok=True)
-    # shard first, parse afterwards: the partition needs only (L, N) estimates from a header scan, so a rank
-    # reads and encodes its own targets and nobody else's
-    owned = plan_shard(targets, iterations, rank, world)
-    parsed, failed, mine = {}, [], []
-    for i in owned:                                  # longest first: the order partition_targets returns
-        aln_path, tpl_path = targets[i]
-        try:
-            rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
-            tpl = read_template_ca(tpl_path) if tpl_path else None
-            parsed[i] = (aln_path, tpl, encode_aln(rows))
-            mine.append(i)
-        except (IndexError, ValueError, OSError, UnicodeDecodeError) as exc:
-            # unknown residue letter / ragged rows / unreadable file: this target only
-            failed.append((aln_path, exc))
-    if not mine and not failed:
+    # sharding needs only (L, N) estimates from a header scan: a rank parses its own targets and nobody else's
+    order, scans = cost_order(targets, iterations)
+    if store is not None and world > 1:
+        queue = _SharedQueue(order, store)
+        mine_scans = scans                              # any target may come this way
+    else:
+        owned = plan_shard(targets, iterations, rank, world)
+        queue = _StaticQueue(owned)
+        mine_scans = [scans[i] for i in owned]
+    if not mine_scans:
         return 0, 0.0, []
+    # capacity of the engines from the scans (L is exact; N is exact for .aln files, an estimate for .a3m)
+    any_a3m = any(a.endswith(".a3m") for a, _ in targets)
+    max_L = max(8, max(L for L, _ in mine_scans))
+    max_N = MAX_SEQS if any_a3m else max(1, min(MAX_SEQS, max(N for _, N in mine_scans)))
     t0 = time.perf_counter()
-    tickets, results, pipe = [], {}, None
-    if mine:
-        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        max_L = max(parsed[i][2].shape[1] for i in mine)
-        max_N = max(parsed[i][2].shape[0] for i in mine)
-        sd = state_dict if state_dict is not None else load_state_dict(weights_file)
-        pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
-    for i in mine:
-        aln_path, tpl, alnmat = parsed[i]
-        d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
-        tickets.append((i, pipe.submit(d_msa, iterations, minsteps, template_ca=tpl)))
-        pipe.pump()
-    if pipe is not None:
-        results = pipe.collect([t for _, t in tickets])
-    outputs = []
-    for i, t in tickets:
-        aln_path, _, alnmat = parsed[i]
-        if isinstance(results[t], Exception):        # this target only: the others keep their results
-            failed.append((aln_path, results[t]))
-            continue
-        coords, confs = results[t]
+    pipe, dev = None, None
+    failed, outputs, parsed, faulted = [], [], {}, []
+    n_taken = 0
+
+    def ensure_pipe():
+        nonlocal pipe, dev
+        if pipe is None:
+            dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+            sd = state_dict if state_dict is not None else load_state_dict(weights_file)
+            pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
+        return pipe
+
+    def finish(t):
+        aln_path, alnmat = parsed.pop(t)
+        coords, confs = pipe.peek(t)
+        if bool(torch.isnan(confs[:1]).any()):          # a device-side fault poisoned it: repeated alone at the end
+            parsed[t] = (aln_path, alnmat)
+            faulted.append(t)
+            return
+        pipe.result(t)
         outputs.append(write_result(out_dir, aln_path, coords, confs, alnmat, fmt))
+
+    exhausted = False
+    cap = 2 * max(1, int(streams))                      # started + queued per rank
+    while True:
+        while not exhausted and (pipe is None or pipe.backlog() < max(1, int(streams))) and len(parsed) - len(faulted) < cap:
+            i = queue.take()
+            if i is None:
+                exhausted = True
+                break
+            n_taken += 1
+            aln_path, tpl_path = targets[i]
+            try:
+                rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
+                tpl = read_template_ca(tpl_path) if tpl_path else None
+                alnmat = encode_aln(rows)
+                p = ensure_pipe()
+                d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
+                parsed[p.submit(d_msa, iterations, minsteps, template_ca=tpl)] = (aln_path, alnmat)
+            except (IndexError, ValueError, OSError, UnicodeDecodeError, RuntimeError) as exc:
+                # unknown residue letter / ragged rows / unreadable file / larger than the scan said: this target only
+                failed.append((aln_path, exc))
+        if pipe is None or not (pipe.busy() or len(parsed) > len(faulted)):
+            if exhausted:
+                break
+            continue
+        pipe.step()
+        for t in pipe.poll():
+            finish(t)
+    if faulted:
+        res = pipe.collect(faulted)
+        for t in faulted:
+            aln_path, alnmat = parsed.pop(t)
+            if isinstance(res[t], Exception):
+                failed.append((aln_path, res[t]))
+            else:
+                outputs.append(write_result(out_dir, aln_path, res[t][0], res[t][1], alnmat, fmt))
     elapsed = time.perf_counter() - t0
     if pipe is not None:
         pipe.close()
     if failed:
         raise BatchFailures(failed, len(outputs), elapsed, outputs)
-    return len(mine), elapsed, outputs
+    return n_taken, elapsed, outputs
 
 
 def main(argv=None):
@@ -203,6 +273,8 @@ def main(argv=None):
     ap.add_argument("-m", "--minsteps", type=int, default=default_minsteps)
     ap.add_argument("-w", "--model_weights", type=str, default=None)
     ap.add_argument("--streams", type=int, default=4, help="targets in flight per GPU")
+    ap.add_argument("--static-shards", action="store_true",
+                    help="several ranks: fixed partition by estimated cost instead of the shared work queue")
     args = ap.parse_args(argv)
     if not args.list and not args.input:
         ap.error("give -l targets.txt and / or -i alignments ...")
@@ -219,10 +291,13 @@ def main(argv=None):
                                 device_id=torch.device("cuda", local_rank))
     targets = (read_target_list(args.list) if args.list else []) + expand_inputs(args.input)
     status = 0
+    store = None
+    if world > 1 and not args.static_shards:
+        store = torch.distributed.distributed_c10d._get_default_store()
     try:
         n, elapsed, _ = run_batch(targets, args.out_dir, args.iterations, args.minsteps,
                                   weights_file=args.model_weights, streams=args.streams,
-                                  device=f"cuda:{local_rank}", rank=rank, world=world, fmt=args.format)
+                                  device=f"cuda:{local_rank}", rank=rank, world=world, fmt=args.format, store=store)
     except BatchFailures as bf:                      # keep going: the other ranks wait in job_summary
         for aln_path, exc in bf.failed:
             print(f"dmpfold-batch: {aln_path}: {type(exc).__name__}: {exc}", file=sys.stderr)

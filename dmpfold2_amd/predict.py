@@ -381,6 +381,7 @@ class Pipeline:
         self._total = [0] * S
         self._stagger = bool(stagger)
         self._results = {}
+        self._done_ev = {}            # ticket -> event recorded behind dmp_predict_end (poll)
         self._jobs = {}               # ticket -> job, kept until the result is handed out (retry of faults)
         self._tickets = 0
         # DMP_PUMP_SLEEP_US: sleep that long whenever a scheduling round found nothing to issue (default:
@@ -655,6 +656,9 @@ class Pipeline:
                     t, coords, confs = self._slot[s][:3]
                     _lib.check(lib.dmp_predict_end(e.ctx, coords.data_ptr(), confs.data_ptr(), e.stream()))
                     self._results[t] = (coords, confs)
+                    ev = torch.cuda.Event()
+                    ev.record(e._stream)
+                    self._done_ev[t] = ev
                     self._slot[s] = None
                     progressed = True
                     break
@@ -716,7 +720,35 @@ class Pipeline:
 
     def result(self, ticket):
         self._jobs.pop(ticket, None)
+        self._done_ev.pop(ticket, None)
         return self._results.pop(ticket)
+
+    # ---- streaming use (dmpfold2_amd.batch): submit / step / poll, no barrier between targets ----------------
+    def step(self):
+        """One scheduling round; yields the core when nothing could be issued.  True if anything was enqueued."""
+        with torch.cuda.device(self.device):
+            if self._pump():
+                return True
+        self._idle()
+        return False
+
+    def backlog(self):
+        """Targets queued but not yet started on an engine."""
+        return len(self._pending)
+
+    def busy(self):
+        return bool(self._pending) or any(x is not None for x in self._slot)
+
+    def poll(self):
+        """Tickets whose prediction has COMPLETED on the GPU since the last call (their tensors may be read from
+        any stream); `peek` / `result` hand the tensors out."""
+        done = [t for t, ev in self._done_ev.items() if ev.query()]
+        for t in done:
+            del self._done_ev[t]
+        return done
+
+    def peek(self, ticket):
+        return self._results[ticket]
 
     def collect(self, tickets):
         """drain + synchronise + verify.  Returns {ticket: (coords, confs) or Exception}: a target

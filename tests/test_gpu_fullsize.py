@@ -268,8 +268,17 @@ def test_baseline_config_sizes_vs_reference(synth_sd, name):
         assert (dev <= np.maximum(1e-3, 3.0 * floor)).all(), (dev, floor)
         means = eng.fetch("conf_means", P).cpu().numpy()
         assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
-        assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= max(1e-3, 3.0 * max(float(g["noise_ca_rmsd"]), eig))
-        assert np.abs(confs.cpu().numpy() - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
+        final = ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1])
+        dconf = float(np.abs(confs.cpu().numpy() - g["confs"]).max())
+        print(name, "per-pass CA-RMSD", dev, "final", final, "max|dconf|", dconf)
+        if name == "synth_L1000_N2000_n0_m0":
+            # the documented ill-conditioned case (two of the top eight MDS eigenvalues 3e-4 apart: the reference's
+            # float32 LAPACK eigenvectors are 1.8e-3 A from the exact ones of its own matrix); the well-separated
+            # L=1000 fixture below holds the plain tolerance
+            assert final <= max(1e-3, 3.0 * max(float(g["noise_ca_rmsd"]), eig))
+        else:
+            assert final <= 1e-3                       # the output of aln_to_coords: plain north-star tolerance
+        assert dconf < 1e-4
     finally:
         eng.close()
 

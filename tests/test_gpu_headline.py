@@ -127,8 +127,8 @@ def test_north_star_size_and_depth_vs_reference(ns_engine, mode):
         eng.sync_check()
         coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
         _check_passes(eng, g, 11, 300, 1e-3)
-        assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
-        assert np.abs(confs - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
+        assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= 1e-3       # the outputs: plain north-star tolerance
+        assert np.abs(confs - g["confs"]).max() < 1e-4
     finally:
         eng.set_option("conv_mode", 0)
 

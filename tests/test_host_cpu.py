@@ -367,30 +367,58 @@ def test_empty_alignment_raises_index_error(tmp_path):
 
 # ---------------------------------------------------------------------------- round 3
 class _FakePipeline:
-    """Stands in for the GPU scheduler in the host-logic tests of run_batch: the 'prediction' of a target is
-    a function of its alignment only, so results can be compared across shardings."""
+    """Stands in for the GPU scheduler in the host-logic tests of run_batch (its streaming interface: submit /
+    step / poll / peek / result / collect): the 'prediction' of a target is a function of its alignment only, so
+    results can be compared across shardings.  A target completes two scheduling rounds after its submission."""
     made = 0
 
     def __init__(self, device, max_L, max_N, state_dict, streams=2, stagger=False):
         _FakePipeline.made += 1
         self.jobs, self.max_L, self.max_N = [], max_L, max_N
+        self.age, self.ready, self.max_backlog = {}, {}, 0
 
     def submit(self, d_msa, iterations, minsteps, template_ca=None):
-        assert d_msa.shape[1] <= self.max_L and d_msa.shape[0] <= self.max_N
+        if d_msa.shape[1] > self.max_L or d_msa.shape[0] > self.max_N:
+            raise RuntimeError("alignment exceeds the pipeline capacity")
         self.jobs.append(d_msa)
-        return len(self.jobs) - 1
+        t = len(self.jobs) - 1
+        self.age[t] = 0
+        self.max_backlog = max(self.max_backlog, len(self.age))
+        return t
 
-    def pump(self):
-        pass
+    def _value(self, t):
+        m = self.jobs[t]
+        L = m.shape[1]
+        base = m.float().mean() + torch.arange(L * 15, dtype=torch.float32).reshape(L, 5, 3) * 0.01
+        return base, torch.full((L,), float(m.shape[0]) / 1000.0)
+
+    def step(self):
+        for t in list(self.age):
+            self.age[t] += 1
+            if self.age[t] >= 2:
+                del self.age[t]
+                self.ready[t] = self._value(t)
+        return True
+
+    def backlog(self):
+        return 0
+
+    def busy(self):
+        return bool(self.age)
+
+    def poll(self):
+        done = [t for t in self.ready if t not in getattr(self, "_polled", set())]
+        self._polled = getattr(self, "_polled", set()) | set(done)
+        return done
+
+    def peek(self, t):
+        return self.ready[t]
+
+    def result(self, t):
+        return self.ready.pop(t)
 
     def collect(self, tickets):
-        out = {}
-        for t in tickets:
-            m = self.jobs[t]
-            L = m.shape[1]
-            base = m.float().mean() + torch.arange(L * 15, dtype=torch.float32).reshape(L, 5, 3) * 0.01
-            out[t] = (base, torch.full((L,), float(m.shape[0]) / 1000.0))
-        return out
+        return {t: self.ready.pop(t) if t in self.ready else self._value(t) for t in tickets}
 
     def close(self):
         pass
@@ -498,3 +526,53 @@ def test_length_limit_is_reported_before_anything_runs(tmp_path):
     ctx = C.c_void_p()
     assert lib.dmp_ctx_create(0, 1281, 4, C.byref(ctx)) != 0
     assert b"1280" in lib.dmp_last_error()
+
+
+_QUEUE_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import torch, torch.distributed as dist
+from dmpfold2_amd import batch
+import test_host_cpu as T
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+store = dist.distributed_c10d._get_default_store()
+batch.Pipeline = T._FakePipeline
+if rank == 1:                                   # a slow rank: the others take what it does not get to
+    real = T._FakePipeline.step
+    T._FakePipeline.step = lambda self: (time.sleep(0.01), real(self))[1]
+targets = [l.split()[0] for l in open({listfile!r})]
+targets = [(t, None) for t in targets]
+n, secs, outs = batch.run_batch(targets, {out!r}, 1, 0, state_dict={{}}, device="cpu", rank=rank, world=world, store=store)
+gathered = [None] * world
+dist.all_gather_object(gathered, sorted(os.path.basename(o) for o in outs))
+names = sorted(x for g in gathered for x in g)
+assert names == sorted(os.path.splitext(os.path.basename(t))[0] + ".pdb" for t, _ in targets), (len(names), len(targets))
+assert all(len(g) > 0 for g in gathered)
+if rank == 0:
+    print("taken per rank:", [len(g) for g in gathered])
+dist.destroy_process_group()
+print("rank", rank, "ok", n)
+"""
+
+
+def test_shared_work_queue_over_gloo_world_size_2(tmp_path):
+    """Several ranks, one queue: every rank takes the next most expensive target from an atomic counter in the job's
+    key-value store whenever it has room (no collective, nothing on the data path).  Two gloo ranks, one of them slow:
+    every target is predicted exactly once and the fast rank takes more of them."""
+    d = tmp_path / "msas"
+    d.mkdir()
+    targets = _write_synth_targets(d, 40)
+    (tmp_path / "list.txt").write_text("".join(a + "\n" for a, _ in targets))
+    script = tmp_path / "qworker.py"
+    script.write_text(_QUEUE_WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"),
+                                           listfile=str(tmp_path / "list.txt"), out=str(tmp_path / "out")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2
+    taken = eval(r.stdout.split("taken per rank:")[1].splitlines()[0])
+    assert sum(taken) == 40 and taken[0] > taken[1]
+    assert len(os.listdir(tmp_path / "out")) == 40
