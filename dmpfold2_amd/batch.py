@@ -208,6 +208,8 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
         return pipe
 
+    done = []                                           # completed on the GPU, not yet written
+
     def finish(t):
         aln_path, alnmat = parsed.pop(t)
         coords, confs = pipe.peek(t)
@@ -221,7 +223,8 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     exhausted = False
     cap = 2 * max(1, int(streams))                      # started + queued per rank
     while True:
-        while not exhausted and (pipe is None or pipe.backlog() < max(1, int(streams))) and len(parsed) - len(faulted) < cap:
+        while (not exhausted and (pipe is None or pipe.backlog() < max(1, int(streams)))
+               and len(parsed) - len(faulted) - len(done) < cap):
             i = queue.take()
             if i is None:
                 exhausted = True
@@ -242,9 +245,15 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             if exhausted:
                 break
             continue
-        pipe.step()
-        for t in pipe.poll():
-            finish(t)
+        progressed = pipe.step()
+        done += pipe.poll()
+        # Results are brought to the host, formatted and written ONE per scheduling round in which nothing could be
+        # issued (the GPU has work queued) - never while units are waiting to be issued: the four targets of a group
+        # finish together, and 4 x 1.5 ms of host work in front of the next group's start is GPU idle time.
+        if done and (not progressed or not pipe.busy()):
+            finish(done.pop(0))
+    for t in done:
+        finish(t)
     if faulted:
         res = pipe.collect(faulted)
         for t in faulted:
