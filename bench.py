@@ -499,11 +499,17 @@ def main(argv=None):
         eff_ms = conv_union / conv_cnt if conv_cnt else 0.0
         in_flight = conv_tot / conv_union if conv_union > 0 else 0.0
         achieved = CONV_FLOP_PER_LAUNCH / (eff_ms * 1e-3) / 1e12 if eff_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_current = None, None
         pmc = os.path.join(ROOT, "profiles", "conv5x5_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                # the PMC passes are a separate profiler run (counters cannot be collected inside the timed region):
+                # the file carries the hash of the kernel source it was taken from
+                if pj.get("kernel_source_sha256"):
+                    src = os.path.join(ROOT, pj.get("kernel_source", "dmpfold2_amd/csrc/conv_f16.h"))
+                    traffic_current = hashlib.sha256(open(src, "rb").read()).hexdigest() == pj["kernel_source_sha256"]
             except Exception:
                 traffic = None
         verify["ok"] = ok
@@ -555,7 +561,8 @@ def main(argv=None):
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA_TFLOPS / 3.0),
                          "traffic": traffic,
                          "traffic_source": "profiles/conv5x5_pmc.json (rocprofv3 --pmc passes of single "
-                                           "launches, tools/pmc_conv.sh; not re-measured in this run)",
+                                           "launches, tools/profile_bench.sh; a separate profiler run)",
+                         "traffic_taken_from_this_kernel_source": traffic_current,
                          "launches_timed": conv_cnt,
                          "avg_launch_ms": conv_ms, "launches_in_flight": in_flight,
                          "chip_ms_per_launch": eff_ms,

@@ -25,6 +25,7 @@ SIGNATURES = {
     "dmp_clear_faults": (_i, [_vp, _vp]),
     "dmp_weights_set": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
     "dmp_weights_finalize": (_i, [_vp]),
+    "dmp_weights_share": (_i, [_vp, _vp]),
     "dmp_msa_encode": (_i, [_vp, _i64, _vp]),
     "dmp_msa_weights": (_i, [_vp, _fp, _i, _i, _fp, _vp]),
     "dmp_cov_build": (_i, [_vp, _fp, _fp, _i, _i, _fp, _vp]),

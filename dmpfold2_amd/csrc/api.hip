@@ -100,6 +100,21 @@ static std::vector<float> transposed(const std::vector<float>& w, int rows, int 
   return t;
 }
 
+// Packed weights are reference counted: the owner's buffers are freed when the last context using them lets go.
+static void release_weights(dmp_ctx* c) {
+  Weights& W = c->W;
+  if (W.shared) {
+    if (W.shared.use_count() == 1)
+      for (void* p : *W.shared) (void)hipFree(p);
+    W.shared.reset();
+  }
+  for (void* p : W.allocs) (void)hipFree(p);
+  W.allocs.clear();
+  for (auto& kv : c->vgru_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);   // they hold weight pointers
+  c->vgru_graphs.clear();
+  W.ready = false;
+}
+
 static int pack_weights(dmp_ctx* c) {
   Weights& W = c->W;
   auto& H = W.host;
@@ -532,7 +547,7 @@ int dmp_sync_check(dmp_ctx* ctx, void* stream) {
 void dmp_ctx_destroy(dmp_ctx* c) {
   if (!c) return;
   for (void* p : c->allocs) (void)hipFree(p);
-  for (void* p : c->W.allocs) (void)hipFree(p);
+  release_weights(c);
   for (void* e : c->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
   for (void* e : c->unit_ev)
     if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -584,14 +599,31 @@ int dmp_weights_finalize(dmp_ctx* c) {
     c->W.hash = h;
   }
   DMP_HIP(hipSetDevice(c->device));
-  for (void* p : c->W.allocs) { (void)hipFree(p); }
-  c->W.allocs.clear();
-  for (auto& kv : c->vgru_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)kv.second);   // they hold weight pointers
-  c->vgru_graphs.clear();
+  release_weights(c);
   int rc = pack_weights(c);
   if (rc) return rc;
   c->W.host.clear();
+  // hand the buffers to a shared holder so that other contexts of this GPU can use them (dmp_weights_share)
+  c->W.shared = std::make_shared<std::vector<void*>>(std::move(c->W.allocs));
+  c->W.allocs.clear();
   c->W.ready = true;
+  return DMP_OK;
+}
+
+int dmp_weights_share(dmp_ctx* dst, const dmp_ctx* src) {
+  DMP_ARG(dst && src && dst != src, "two different contexts are needed");
+  DMP_ARG(src->W.ready && src->W.shared, "the source context holds no packed weights (dmp_weights_finalize first)");
+  DMP_ARG(dst->device == src->device, "the contexts live on different GPUs");
+  DMP_HIP(hipSetDevice(dst->device));
+  release_weights(dst);
+  dst->W.host.clear();
+  dst->W.shapes.clear();
+  const std::shared_ptr<std::vector<void*>> hold = src->W.shared;
+  dst->W = src->W;                    // pointers, scales, hash
+  dst->W.host.clear();
+  dst->W.shapes.clear();
+  dst->W.allocs.clear();
+  dst->W.shared = hold;
   return DMP_OK;
 }
 

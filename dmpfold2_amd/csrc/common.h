@@ -6,6 +6,7 @@
 #include <vector>
 #include <map>
 #include <algorithm>
+#include <memory>
 #include "../../include/dmpfold_hip.h"
 
 namespace dmp {
@@ -94,7 +95,10 @@ struct Weights {
   BlockW blk[NBLOCK];
   float* head_w = nullptr;                 // [2][128]
   float head_b[2] = {0.f, 0.f};
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;                               // device buffers of the packed weights (owner only)
+  // dmp_weights_share: this context uses the packed weights of `owner` (pointers above copied from it); the device
+  // buffers live as long as any context refers to them
+  std::shared_ptr<std::vector<void*>> shared;
 };
 
 }  // namespace dmp

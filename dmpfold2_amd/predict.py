@@ -231,6 +231,12 @@ class Engine:
             _lib.check(self.lib.dmp_weights_finalize(self._ctx), RuntimeError)
         self.weights_tag = tag
 
+    def share_weights(self, other):
+        """Use the packed weights of `other` (an engine on the same GPU) instead of packing a copy."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dmp_weights_share(self._ctx, other.ctx), RuntimeError)
+        self.weights_tag = other.weights_tag
+
     def predict(self, alnmat, template_ca=None, iterations=default_iterations,
                 minsteps=default_minsteps):
         """codes (N, L) uint8 -> (coords (L,5,3), confs (L,)) float32 tensors on the GPU."""
@@ -370,7 +376,10 @@ class Pipeline:
             with torch.cuda.device(self.device):
                 st = torch.cuda.Stream(device=self.device)
             eng = Engine(self.device, max_L, max_N, stream=st)
-            eng.set_weights(state_dict)
+            if self.engines:
+                eng.share_weights(self.engines[0])       # packed once per pipeline, not once per engine
+            else:
+                eng.set_weights(state_dict)
             if streams > 1:
                 _lib.check(self.lib.dmp_ctx_set_lane(eng.ctx, self._lane))
             self.engines.append(eng)
@@ -440,7 +449,7 @@ class Pipeline:
             with torch.cuda.device(self.device):
                 st = torch.cuda.Stream(device=self.device)
             fe = Engine(self.device, max_L, max_N, stream=st)
-            fe.set_weights(state_dict)
+            fe.share_weights(self.engines[0])
             self._fe = fe
 
     def _reap_chains(self, wait=False):

@@ -521,6 +521,38 @@ def test_gru_vertical_group_stage_call(st, synth_sd):
             e.close()
 
 
+def test_shared_weights_are_the_owners_and_outlive_it(synth_sd):
+    """dmp_weights_share: the engines of a scheduler use ONE packed copy of the weights.  A sharing engine predicts
+    the owner's bits, keeps working after the owner is destroyed (the buffers are reference counted), and can load
+    weights of its own again afterwards."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    w = {k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()}
+    msa = encode_aln(synth.synth_msa(48, 40, 3))
+    a, b = Engine("cuda:0", 64, 64), Engine("cuda:0", 64, 64)
+    try:
+        a.set_weights(w)
+        bytes_owner = a.device_bytes
+        b.share_weights(a)
+        ca, fa = a.predict(msa, None, 1, 2)
+        cb, fb = b.predict(msa, None, 1, 2)
+        a.sync_check(); b.sync_check()
+        assert torch.equal(ca, cb) and torch.equal(fa, fb)
+        assert b.device_bytes < bytes_owner                  # no second copy of the packed weights
+        a.close()
+        cb2, fb2 = b.predict(msa, None, 1, 2)
+        b.sync_check()
+        assert torch.equal(cb2, cb) and torch.equal(fb2, fb)
+        w2 = dict(w)
+        w2["coord_fc.weight"] = w["coord_fc.weight"] * 0.5
+        b.set_weights(w2)
+        cb3, _ = b.predict(msa, None, 1, 2)
+        b.sync_check()
+        assert not torch.equal(cb3, cb) and torch.isfinite(cb3).all()
+    finally:
+        a.close(); b.close()
+
+
 def test_batch_front_end_matches_cli(weights_file, tmp_path):
     """dmpfold2_amd.batch (targets file -> one PDB per target through the scheduler, template in
     the second column) writes exactly the text the single-target CLI prints."""

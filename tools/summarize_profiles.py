@@ -82,6 +82,10 @@ if conv:
                "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
                "algorithmic_bytes_per_launch": algo,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE half-count correction",
-               "source": f"profiles/{tag}_conv5x5_pmc.txt"},
+               "source": f"profiles/{tag}_conv5x5_pmc.txt",
+               # the kernel's source at the time of the PMC passes: bench.py reports whether the tree still has it
+               "kernel_source": "dmpfold2_amd/csrc/conv_f16.h",
+               "kernel_source_sha256": __import__("hashlib").sha256(
+                   open(os.path.join(ROOT, "dmpfold2_amd", "csrc", "conv_f16.h"), "rb").read()).hexdigest()},
               open(os.path.join(P, "conv5x5_pmc.json"), "w"), indent=1)
 print(open(os.path.join(P, f"{tag}_conv5x5_pmc.txt")).read() if conv else "no PMC data")
