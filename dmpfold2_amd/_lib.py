@@ -59,6 +59,9 @@ SIGNATURES = {
     "dmp_predict_issue_unit": (_i, [_vp, _vp]),
     "dmp_ctx_pending": (_i, [_vp]),
     "dmp_predict_begin_units": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i]),
+    "dmp_predict_ahead_begin": (_i, [_vp, _fp, _i, _i]),
+    "dmp_predict_ahead_left": (_i, [_vp]),
+    "dmp_predict_ahead_issue": (_i, [_vp, _vp]),
     "dmp_lane_create": (_i, [C.POINTER(_vp)]),
     "dmp_lane_destroy": (None, [_vp]),
     "dmp_ctx_set_lane": (_i, [_vp, _vp]),

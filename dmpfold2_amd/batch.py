@@ -222,36 +222,55 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
 
     exhausted = False
     cap = 2 * max(1, int(streams))                      # started + queued per rank
+
+    def take_one():
+        """Read, encode and submit the next target of the queue; False when the queue is empty."""
+        nonlocal exhausted, n_taken
+        i = queue.take()
+        if i is None:
+            exhausted = True
+            return False
+        n_taken += 1
+        aln_path, tpl_path = targets[i]
+        try:
+            rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
+            tpl = read_template_ca(tpl_path) if tpl_path else None
+            alnmat = encode_aln(rows)
+            p = ensure_pipe()
+            d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
+            parsed[p.submit(d_msa, iterations, minsteps, template_ca=tpl)] = (aln_path, alnmat)
+        except (IndexError, ValueError, OSError, UnicodeDecodeError, RuntimeError) as exc:
+            # unknown residue letter / ragged rows / unreadable file / larger than the scan said: this target only
+            failed.append((aln_path, exc))
+        return True
+
+    def room():
+        return (not exhausted and (pipe is None or pipe.backlog() < max(1, int(streams)))
+                and len(parsed) - len(faulted) - len(done) < cap)
+
+    # Host work - reading / encoding / uploading the next alignment, bringing a finished structure back, formatting
+    # and writing it - is done ONE item per scheduling round in which nothing could be issued (the GPU has work
+    # queued), never while units are waiting to be issued: the targets of a group finish and start together, and
+    # 4 x (0.6 + 1.5) ms of host work in front of the next group's first launches is GPU idle time.
     while True:
-        while (not exhausted and (pipe is None or pipe.backlog() < max(1, int(streams)))
-               and len(parsed) - len(faulted) - len(done) < cap):
-            i = queue.take()
-            if i is None:
-                exhausted = True
-                break
-            n_taken += 1
-            aln_path, tpl_path = targets[i]
-            try:
-                rows = read_a3m(aln_path) if aln_path.endswith(".a3m") else read_aln(aln_path)
-                tpl = read_template_ca(tpl_path) if tpl_path else None
-                alnmat = encode_aln(rows)
-                p = ensure_pipe()
-                d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
-                parsed[p.submit(d_msa, iterations, minsteps, template_ca=tpl)] = (aln_path, alnmat)
-            except (IndexError, ValueError, OSError, UnicodeDecodeError, RuntimeError) as exc:
-                # unknown residue letter / ragged rows / unreadable file / larger than the scan said: this target only
-                failed.append((aln_path, exc))
-        if pipe is None or not (pipe.busy() or len(parsed) > len(faulted)):
-            if exhausted:
-                break
-            continue
+        if pipe is None or not pipe.busy():
+            while room() and (pipe is None or pipe.backlog() < max(1, int(streams))):
+                if not take_one():
+                    break
+            if pipe is None or not pipe.busy():
+                if done:
+                    finish(done.pop(0))
+                    continue
+                if exhausted or not room():
+                    break
+                continue
         progressed = pipe.step()
         done += pipe.poll()
-        # Results are brought to the host, formatted and written ONE per scheduling round in which nothing could be
-        # issued (the GPU has work queued) - never while units are waiting to be issued: the four targets of a group
-        # finish together, and 4 x 1.5 ms of host work in front of the next group's start is GPU idle time.
-        if done and (not progressed or not pipe.busy()):
-            finish(done.pop(0))
+        if not progressed:
+            if room():
+                take_one()
+            elif done:
+                finish(done.pop(0))
     for t in done:
         finish(t)
     if faulted:

@@ -900,8 +900,10 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
       DMP_HIP(hipStreamWaitEvent(side, (hipEvent_t)c->side_ev[0], 0));
     }
     used = side;
-    rc = msa_weights(c, d_msa, N, L, c->w, side);
-    if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, side);
+    if (!c->fe_have_features) {
+      rc = msa_weights(c, d_msa, N, L, c->w, side);
+      if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, side);
+    }
   } else if (u <= c->fe_inv + c->fe_vgru) {
     // alternate GRU chunk / inverse chunk while both kinds remain
     const int k = u - 1, m = std::min(c->fe_inv, c->fe_vgru);
@@ -988,8 +990,54 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   }
   c->fe_inv = N > 1 ? cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
   c->fe_vgru = cdiv(N + 1, FE_VGRU_STEPS);
+  // features computed ahead for exactly this alignment (dmp_predict_ahead_*): nothing of them is left to do; ahead
+  // work for another alignment, or unfinished work, is dropped (the buffers are simply recomputed)
+  c->fe_have_features = c->ahead_msa == d_msa && c->ahead_N == N && c->ahead_L == L && c->ahead_total > 0 &&
+                        c->ahead_next == c->ahead_total;
+  if (c->fe_have_features) c->fe_inv = 0;
+  c->ahead_msa = nullptr;
+  c->ahead_total = c->ahead_next = 0;
   c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
   return DMP_OK;
+}
+
+int dmp_predict_ahead_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L) {
+  CHECK_CAP(L, N);
+  DMP_ARG(d_msa != nullptr, "null argument");
+  DMP_ARG(N >= 1 && L >= 8, "need N >= 1 and L >= 8 (got N=%d L=%d)", N, L);
+  dmp_ctx* c = ctx;
+  DMP_ARG(c->fe_total > 0 && c->fe_next >= c->fe_total,
+          "features ahead need a prediction in flight that is past its front end (its static stem has consumed the "
+          "feature buffers)");
+  c->ahead_msa = d_msa;
+  c->ahead_N = N;
+  c->ahead_L = L;
+  c->ahead_next = 0;
+  c->ahead_total = N > 1 ? 1 + cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
+  return DMP_OK;
+}
+
+int dmp_predict_ahead_left(const dmp_ctx* ctx) { return ctx ? ctx->ahead_total - ctx->ahead_next : 0; }
+
+int dmp_predict_ahead_issue(dmp_ctx* ctx, void* stream) {
+  DMP_ARG(ctx != nullptr, "null context");
+  dmp_ctx* c = ctx;
+  DMP_ARG(c->ahead_msa && c->ahead_next < c->ahead_total, "no feature unit left to issue ahead");
+  DMP_ARG(c->fe_next >= c->fe_total, "the prediction in flight is still in its front end");
+  hipStream_t s = STREAM;
+  const int N = c->ahead_N, L = c->ahead_L, u = c->ahead_next;
+  int rc;
+  if (u == 0) {
+    rc = msa_weights(c, c->ahead_msa, N, L, c->w, s);
+    if (!rc) rc = cov_build(c, c->ahead_msa, c->w, N, L, c->cov, s);
+  } else {
+    const int j = u - 1;
+    rc = spd_inverse_steps(c, c->cov, NS * L, j * FE_INV_BLOCKS, (j + 1) * FE_INV_BLOCKS, s);
+    if (!rc && u == c->ahead_total - 1) rc = dca_contacts(c, c->cov, L, c->contacts, s);
+  }
+  if (rc) return rc;
+  c->ahead_next = u + 1;
+  return record_unit(c, s);
 }
 
 int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,

@@ -208,6 +208,11 @@ struct dmp_ctx {
   bool fe_side = false;                    // this prediction's front end forks onto the side stream
   long unit_seq = 0;           // units issued since the context was created
   int fe_next = 0, fe_total = 0;           // front-end units (features, sequence trunk, static stem)
+  // features ahead (dmp_predict_ahead_*): reweighting, covariance, inverse and contacts of the NEXT alignment, computed
+  // into this context's feature buffers (idle once the static stem of the prediction in flight exists)
+  const uint8_t* ahead_msa = nullptr;
+  int ahead_N = 0, ahead_L = 0, ahead_next = 0, ahead_total = 0;
+  bool fe_have_features = false;           // this prediction's features were computed ahead
   int fe_inv = 0, fe_vgru = 0;             // ... of which inverse chunks / vertical-GRU chunks
   const uint8_t* run_msa = nullptr;        // arguments of the prediction in flight
   const float* run_template = nullptr;

@@ -438,6 +438,18 @@ class Pipeline:
                 prio = -1 if os.environ.get("DMP_VGRU_CHAIN_PRIO") == "1" else 0
                 self._chain_stream = torch.cuda.Stream(device=self.device, priority=prio)
             self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
+        # Features ahead: an engine in its trunk passes is given its NEXT target early and computes that target's
+        # reweighting, covariance, inverse and contacts into its own (idle) feature buffers, one unit after every
+        # 1 / (units + 1) of its residual blocks, on its own stream (dmp_predict_ahead_*): the f32 GEMMs run beside the
+        # convolutions of the other engines instead of in the front-end phase, where nothing else runs.
+        # MEASURED (bench.py, alternating runs on one box, gpurun_out r03m): the front-end phase shrinks from 94.7 to
+        # 71 ms per round of four as expected - and the convolutions beside which the inverses now run take 0.708
+        # instead of 0.676 ms of chip time each: 6.92 / 6.94 structures/s against 6.97 / 6.99.  The inverse costs the
+        # same machine time wherever it runs.  Off by default; DMP_FEATURES_AHEAD=1 switches it on.
+        self._features_ahead = os.environ.get("DMP_FEATURES_AHEAD", "0") == "1" and S > 1
+        self._reserved = [None] * S   # per engine: the job it will run next (features being computed ahead)
+        self._ahead_issued = [0] * S  # ahead units issued for it / in total
+        self._ahead_total = [0] * S
         self._lookahead = int(os.environ.get("DMP_VGRU_LOOKAHEAD", "0")) if S > 1 else 0
         self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain)
         self._ahead_pending = None    # (future, jobs, outs): a look-ahead chain the helper thread is still enqueuing
@@ -559,9 +571,16 @@ class Pipeline:
         ahead form one vertical-GRU group (the first of them leads)."""
         grouped = []
         for s in slots:
+            if self._reserved[s] is not None:
+                job = self._reserved[s]
+                e = self.engines[s]
+                while self.lib.dmp_predict_ahead_left(e.ctx) > 0:      # what the trunk passes left no room for
+                    _lib.check(self.lib.dmp_predict_ahead_issue(e.ctx, e.stream()))
+            else:
+                job = self._pending.pop(0)
+            self._reserved[s] = None
             self._done[s] = 0
-            self._total[s] = (self._pending[0][2] + 1) * 16
-            job = self._pending.pop(0)
+            self._total[s] = (job[2] + 1) * 16
             self._begin(s, job)
             ahead = self._ahead.pop(job[0], None)
             if ahead is not None:
@@ -634,12 +653,19 @@ class Pipeline:
                     self._total[r] - self._done[r] <= self._lookahead
                     for r in range(len(self.engines)) if self._slot[r] is not None):
                 self._start_ahead(nxt)
-        if free and self._pending and self._ahead_ready():
+        # free engines that can start now: those holding a reserved target, then as many others as targets are queued
+        with_job = [r for r in free if self._reserved[r] is not None]
+        without = [r for r in free if self._reserved[r] is None][:len(self._pending)]
+        startable = with_job + without
+        if startable and self._ahead_ready():
             # engines about to finish: wait for them and start together (one vertical-GRU chain for the group)
             soon = [r for r in range(len(self.engines)) if self._slot[r] is not None
                     and self._total[r] - self._done[r] <= self._group_patience]
-            want = min(self._group_max, len(self._pending))
-            if len(free) >= want or not soon or self._group_max == 1:
+            left = len(self._pending) - len(without)
+            soon_with_work = sum(1 for r in soon if self._reserved[r] is not None) + \
+                min(left, sum(1 for r in soon if self._reserved[r] is None))
+            want = min(self._group_max, len(startable) + soon_with_work)
+            if len(startable) >= want or not soon_with_work or self._group_max == 1:
                 # optional phase spacing (stagger=True): a prediction starts only when every other one
                 # in flight is at least 1/S of its way through its residual blocks.  Measured at
                 # L=300, N=2000, 3 engines, 48 targets: 5.24 structures/s with spacing, 5.75 without
@@ -648,14 +674,33 @@ class Pipeline:
                 if not (self._stagger and any(self._slot[r] is not None and self._done[r] * S < self._total[r]
                                               for r in range(S))):
                     if self._group_max == 1:
-                        for s in free[:len(self._pending)]:
+                        for s in startable:
                             self._begin_group([s])
                     else:
-                        self._begin_group(free[:want])
+                        self._begin_group(startable[:max(want, 1)])
                     progressed = True
         for s, e in enumerate(self.engines):
             if self._slot[s] is None:
                 continue
+            if self._features_ahead and self._done[s] > 0:
+                # in its trunk passes: reserve its next target and slip that target's feature units between its blocks
+                if self._reserved[s] is None and self._pending and self._done[s] < self._total[s]:
+                    job = self._pending.pop(0)
+                    n, L = job[1].shape
+                    if n > 1 and L <= e.max_L and n <= e.max_N:
+                        job[1].record_stream(e._stream)
+                        _lib.check(lib.dmp_predict_ahead_begin(e.ctx, job[1].data_ptr(), n, L))
+                        self._reserved[s] = job
+                        self._ahead_issued[s] = 0
+                        self._ahead_total[s] = lib.dmp_predict_ahead_left(e.ctx)
+                    else:
+                        self._pending.insert(0, job)
+                if self._reserved[s] is not None and self._ahead_issued[s] < self._ahead_total[s]:
+                    due = (self._ahead_issued[s] + 1) * self._total[s] // (self._ahead_total[s] + 1)
+                    if self._done[s] >= min(due, self._total[s]) and _lib.check(lib.dmp_ctx_pending(e.ctx)) <= 1:
+                        _lib.check(lib.dmp_predict_ahead_issue(e.ctx, e.stream()))
+                        self._ahead_issued[s] += 1
+                        progressed = True
             while True:
                 kind = lib.dmp_predict_next_unit(e.ctx)
                 if kind == 3:                         # waits for its group leader's vertical-GRU chain
@@ -719,7 +764,7 @@ class Pipeline:
         """Schedule until every queued target is fully enqueued; the current stream then waits for
         the engines' streams (nothing is synchronised with the host)."""
         with torch.cuda.device(self.device):
-            while self._pending or any(x is not None for x in self._slot):
+            while self._pending or any(x is not None for x in self._slot) or any(x is not None for x in self._reserved):
                 if not self._pump():
                     self._idle()
         self._reap_chains(wait=True)
@@ -746,7 +791,7 @@ class Pipeline:
         return len(self._pending)
 
     def busy(self):
-        return bool(self._pending) or any(x is not None for x in self._slot)
+        return bool(self._pending) or any(x is not None for x in self._slot) or any(x is not None for x in self._reserved)
 
     def poll(self):
         """Tickets whose prediction has COMPLETED on the GPU since the last call (their tensors may be read from

@@ -236,6 +236,18 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream);
 int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L,
                             const float* d_template_ca, int Lt, int nloops, int refine_steps);
 int dmp_predict_next_unit(const dmp_ctx* ctx);
+/* Features ahead.  Reweighting, covariance, Gauss-Jordan inverse and contacts (predict.py:32-61) of the NEXT alignment
+ * this context will predict, in units of the same size as the front end's (unit 0 = sequence weights + covariance, then
+ * 6 block steps of the inverse each, contacts behind the last), computed into the context's own feature buffers -
+ * which are idle from the moment the static stem of the prediction in flight exists.  A scheduler slips these units
+ * between the residual blocks of the prediction in flight (same stream): their f32 GEMMs run beside the convolutions
+ * of the OTHER contexts instead of in a front-end phase with no convolution to run.  dmp_predict_ahead_begin needs a
+ * prediction in flight that is past its front end; dmp_predict_begin_units on the same alignment (same pointer, N,
+ * L) after every ahead unit has been issued finds the features done and has no covariance / inverse units; for any
+ * other alignment, or unfinished ahead work, the features are computed again.  Results are bit-identical. */
+int dmp_predict_ahead_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L);
+int dmp_predict_ahead_left(const dmp_ctx* ctx);
+int dmp_predict_ahead_issue(dmp_ctx* ctx, void* stream);
 /* Vertical GRUs of n <= 8 predictions as ONE launch chain (dmp_gru_vertical_group inside the unit machinery): call
  * right after dmp_predict_begin_units on every member, before any of their units is issued.  ctxs[0] leads: its
  * vertical-GRU units serve all members on the stream its units are issued on (which must be ordered behind the

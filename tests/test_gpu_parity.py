@@ -458,9 +458,10 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
     pipe.close()
 
 
-@pytest.mark.parametrize("group,lookahead,detach", [(1, 0, 1), (2, 0, 1), (4, 0, 1), (4, 0, 0), (2, 0, 0), (4, 24, 1),
-                                                    (3, 400, 0)])
-def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead, detach):
+@pytest.mark.parametrize("group,lookahead,detach,ahead", [(1, 0, 1, 1), (2, 0, 1, 1), (4, 0, 1, 0), (4, 0, 0, 1),
+                                                          (4, 0, 0, 0), (2, 0, 0, 1), (4, 24, 1, 1), (3, 400, 0, 1)])
+def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead, detach,
+                                                            ahead):
     """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE launch chain
     (group leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so
     groups of every size up to `group` form.  detach = 1: the chain is issued by a helper thread on
@@ -473,12 +474,14 @@ def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, 
     monkeypatch.setenv("DMP_VGRU_GROUP", str(group))
     monkeypatch.setenv("DMP_VGRU_LOOKAHEAD", str(lookahead))
     monkeypatch.setenv("DMP_VGRU_DETACH", str(detach))
+    monkeypatch.setenv("DMP_FEATURES_AHEAD", str(ahead))       # features of an engine's next target computed ahead
     shapes = [(82, 200), (33, 64), (128, 300), (40, 1), (64, 257), (96, 31), (120, 129), (50, 64), (128, 17)]
     msas = [encode_aln(synth.synth_msa(L, N, 40 + i)) for i, (L, N) in enumerate(shapes)]
     dev = torch.device("cuda:0")
     pipe = Pipeline(dev, 128, 512, synth_sd, streams=4)
     assert pipe._group_max == group and (pipe._fe is not None) == (lookahead > 0)
-    assert pipe._detach == bool(detach and group > 1)
+    assert pipe._detach == bool(detach and group > 1) and pipe._features_ahead == bool(ahead)
+    msas = msas + msas[:5]                       # more targets than engines: reservations and ahead units happen
     tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 3) for m in msas]
     pipe.drain()
     pipe.sync_check()
