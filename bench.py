@@ -297,9 +297,11 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     red_device = torch.device("cpu") if share_gpu else device          # where the reduced scalars live
 
-    from dmpfold2_amd import synth, _lib
+    from dmpfold2_amd import synth, _lib, shard
     from dmpfold2_amd.predict import Pipeline, encode_aln
     lib = _lib.load()
+    if world > 1 and not share_gpu:
+        shard.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     S = max(1, args.streams)
     sd = synth.synth_weights(0, coord_scale=5.0)
     pipe = Pipeline(device, L_NS, N_NS, {k: torch.from_numpy(np.array(v)) for k, v in sd.items()},

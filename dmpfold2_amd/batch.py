@@ -317,6 +317,8 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+    if world > 1:
+        shard.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     targets = (read_target_list(args.list) if args.list else []) + expand_inputs(args.input)
     status = 0
     store = None

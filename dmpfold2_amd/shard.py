@@ -43,3 +43,24 @@ def job_summary(n_done: int, elapsed: float, group=None):
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     return int(round(cnt.item())), float(tmax.item())
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int) -> list:
+    """One process per GPU on a node: every rank runs a polling scheduler thread (plus a helper).  When the
+    process may run on every core of the machine - nobody has assigned cores yet - give rank r the r-th of
+    `local_world` equal contiguous slices of the core list, so that eight schedulers do not migrate over each other.
+    OPT-IN (DMP_PIN_CORES=1): which slice is close to which GPU depends on the node's topology, and no multi-GPU node
+    was available to this build to measure it; the default leaves placement to the operating system.
+    Returns the cores now allowed (unchanged if not opted in, the affinity was already restricted, the platform has no
+    affinity call, or one rank only)."""
+    import os
+    if not hasattr(os, "sched_getaffinity"):
+        return []
+    cores = sorted(os.sched_getaffinity(0))
+    if (local_world <= 1 or os.environ.get("DMP_PIN_CORES") != "1" or len(cores) != (os.cpu_count() or 0)
+            or len(cores) < 2 * local_world):
+        return cores
+    per = len(cores) // local_world
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine

@@ -576,3 +576,22 @@ def test_shared_work_queue_over_gloo_world_size_2(tmp_path):
     taken = eval(r.stdout.split("taken per rank:")[1].splitlines()[0])
     assert sum(taken) == 40 and taken[0] > taken[1]
     assert len(os.listdir(tmp_path / "out")) == 40
+
+
+def test_rank_core_slices_are_disjoint_and_cover_the_machine():
+    """shard.pin_rank_to_cores: run in child processes (the affinity of the test process stays as it is)."""
+    code = ("import os, sys; sys.path.insert(0, %r); from dmpfold2_amd import shard; "
+            "print(shard.pin_rank_to_cores(int(sys.argv[1]), int(sys.argv[2])))" % ROOT)
+    ncpu = os.cpu_count() or 1
+    if len(os.sched_getaffinity(0)) != ncpu or ncpu < 4:
+        pytest.skip("affinity already restricted or too few cores")
+    world = 2
+    env = dict(os.environ, DMP_PIN_CORES="1")
+    got = [eval(subprocess.run([sys.executable, "-c", code, str(r), str(world)], capture_output=True, text=True,
+                               check=True, env=env).stdout) for r in range(world)]
+    off = eval(subprocess.run([sys.executable, "-c", code, "0", str(world)], capture_output=True, text=True,
+                              check=True, env=dict(os.environ, DMP_PIN_CORES="0")).stdout)
+    assert len(off) == ncpu                           # not opted in: placement is left to the operating system
+    assert not set(got[0]) & set(got[1]) and len(got[0]) == len(got[1]) == ncpu // world
+    one = eval(subprocess.run([sys.executable, "-c", code, "0", "1"], capture_output=True, text=True, check=True).stdout)
+    assert len(one) == ncpu                           # a single rank is left alone
