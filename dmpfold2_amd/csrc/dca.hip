@@ -213,13 +213,14 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
   const int nt = Dp >> 7;
   const int tm = blockIdx.x / nt, tn = blockIdx.x % nt, kb = k0 >> 7;
   if (tm == kb) return;
-  // Gauss-Jordan on a symmetric matrix keeps M_ij = t_i t_j M_ji^T with t = -1 for processed blocks
-  // (including this step's) and +1 otherwise, so outside block row / column k only the tiles on and
-  // below the diagonal are computed and each is also stored as its signed transpose.
-  if (tn != kb && tn > tm) return;
-  const bool mirror = (tn != kb && tn < tm);
-  const float msign = ((tm < kb) != (tn < kb)) ? -1.f : 1.f;
-  __shared__ float tr[4][32][33];
+  // Gauss-Jordan on a symmetric matrix keeps M_ij = t_i t_j M_ji with t = -1 for processed blocks and +1
+  // otherwise, so only the tiles on and below the diagonal are computed.  Round 3: they are no longer mirrored
+  // into the upper triangle at every block step (80 of the 240 MB a step moved at D = 6300): the upper triangle goes
+  // stale, gj_symm_kernel refreshes the two panels a block step reads from it - the block row right of the diagonal
+  // block and the block column above it - from the lower triangle before the step, and gj_mirror_kernel
+  // rebuilds the whole upper triangle once at the end.  The values read are the ones the mirrored matrix held:
+  // results are unchanged bit for bit.
+  if (tn > tm) return;                                  // upper triangle (for tn == kb: rows above the block)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 5, li = lane & 31;
   const int m0 = tm * 128 + (wave >> 1) * 64, n0 = tn * 128 + (wave & 1) * 64;
@@ -278,21 +279,70 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
           v = (blockcol ? 0.f : *p) - acc[mi][ni][r];
           *p = v;
         }
-        if (mirror) tr[wave][li][8 * (r >> 2) + 4 * kk + (r & 3)] = msign * v;     // [column][row]
-      }
-      if (mirror) {
-        // the wave's 32 x 32 block, transposed through LDS: lanes run along the new rows' columns
-        __builtin_amdgcn_wave_barrier();
-        const int rr = lane & 31;
-        const int grow0 = n0 + 32 * ni, gcol = m0 + 32 * mi + rr;
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-          const int cl = 16 * (lane >> 5) + cc;
-          if (grow0 + cl < D && gcol < D) A[(int64_t)(grow0 + cl) * D + gcol] = tr[wave][cl][rr];
-        }
-        __builtin_amdgcn_wave_barrier();
       }
     }
+}
+
+// Before block step k: the entries the step reads from the (stale) upper triangle, rebuilt from the lower one with
+// the sign rule M_ij = t_i t_j M_ji (block k itself not yet processed: t_k = +1):
+//   block row, right of the diagonal block   A[k0 + r][j] =  A[j][k0 + r]   (j >= k0 + bs, unprocessed: +1)
+//   block column, above the diagonal block   A[i][k0 + c] = -A[k0 + c][i]   (i < k0, processed: -1)
+// grid: ceil(D / 64) tiles of 64 matrix rows / columns outside the block   block: 256
+__global__ __launch_bounds__(256) void gj_symm_kernel(float* __restrict__ A, int D, int k0, int bs) {
+  __shared__ float tile[64][GJ_NB + 1];
+  const int o0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (o0 + 64 <= k0) {
+    // columns i = o0 .. o0+63 left of the block: read A[k0 + c][i] (coalesced along i), write A[i][k0 + c] = -that
+    for (int it = 0; it < 32; ++it) {
+      const int c = 4 * it + (tid >> 6), x = tid & 63;
+      tile[x][c] = (c < bs) ? A[(int64_t)(k0 + c) * D + o0 + x] : 0.f;
+    }
+    __syncthreads();
+    for (int it = 0; it < 32; ++it) {
+      const int x = 2 * it + (tid >> 7), c = tid & 127;
+      if (c < bs) A[(int64_t)(o0 + x) * D + k0 + c] = -tile[x][c];
+    }
+  } else if (o0 >= k0 + bs) {
+    // rows j = o0 .. o0+63 below the block: read A[j][k0 + r] (coalesced along r), write A[k0 + r][j] = that
+    for (int it = 0; it < 32; ++it) {
+      const int x = 2 * it + (tid >> 7), r = tid & 127;
+      tile[x][r] = (o0 + x < D && r < bs) ? A[(int64_t)(o0 + x) * D + k0 + r] : 0.f;
+    }
+    __syncthreads();
+    for (int it = 0; it < 32; ++it) {
+      const int r = 4 * it + (tid >> 6), x = tid & 63;
+      if (r < bs && o0 + x < D) A[(int64_t)(k0 + r) * D + o0 + x] = tile[x][r];
+    }
+  } else {
+    // the 64-wide tile straddles the block's edges (k0 is a multiple of 128, so only its far edge when bs < 128, or
+    // nothing at all): element-wise, both rules
+    for (int e = tid; e < 64 * GJ_NB; e += 256) {
+      const int x = e / GJ_NB, c = e % GJ_NB, o = o0 + x;
+      if (c >= bs || o >= D) continue;
+      if (o < k0) A[(int64_t)o * D + k0 + c] = -A[(int64_t)(k0 + c) * D + o];
+      else if (o >= k0 + bs) A[(int64_t)(k0 + c) * D + o] = A[(int64_t)o * D + k0 + c];
+    }
+  }
+}
+
+// After the last block step every block is processed (t = -1 everywhere: t_i t_j = +1): upper = lower, transposed.
+// grid: (nt, nt) 64 x 64 tiles, only those above the diagonal act   block: 256
+__global__ __launch_bounds__(256) void gj_mirror_kernel(float* __restrict__ A, int D) {
+  const int ti = blockIdx.y, tj = blockIdx.x;          // destination tile (rows ti, columns tj), tj >= ti
+  if (tj < ti) return;
+  __shared__ float tile[64][65];
+  const int tid = threadIdx.x;
+  for (int it = 0; it < 16; ++it) {                    // source tile (rows tj, columns ti): coalesced along its columns
+    const int r = 4 * it + (tid >> 6), c = tid & 63;
+    const int gr = tj * 64 + r, gc = ti * 64 + c;
+    tile[r][c] = (gr < D && gc < D) ? A[(int64_t)gr * D + gc] : 0.f;
+  }
+  __syncthreads();
+  for (int it = 0; it < 16; ++it) {
+    const int r = 4 * it + (tid >> 6), c = tid & 63;
+    const int gr = ti * 64 + r, gc = tj * 64 + c;
+    if (gr < D && gc < D && gc > gr) A[(int64_t)gr * D + gc] = tile[c][r];
+  }
 }
 
 // A_k,: = R (outside the block), A_kk = P
@@ -317,6 +367,10 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
   float4* RT = reinterpret_cast<float4*>(c->gj_rt);
   for (int k0 = blk_lo * GJ_NB; k0 < D && k0 < blk_hi * GJ_NB; k0 += GJ_NB) {
     const int bs = std::min(GJ_NB, D - k0);
+    if (k0 > 0 || k0 + bs < D) {
+      hipLaunchKernelGGL(gj_symm_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, A, D, k0, bs);
+      DMP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(256), 0, s, A, D, k0, bs, P);
     DMP_LAUNCH_CHECK();
     GemmArgs g{};
@@ -334,6 +388,11 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
     hipLaunchKernelGGL(gj_writeback_kernel, dim3(cdiv(D, 256), bs), dim3(256), 0, s, A, D, k0, bs,
                        R, P);
     DMP_LAUNCH_CHECK();
+    if (k0 + bs >= D && D > GJ_NB) {                   // the last block step: rebuild the upper triangle
+      const int nt = cdiv(D, 64);
+      hipLaunchKernelGGL(gj_mirror_kernel, dim3(nt, nt), dim3(256), 0, s, A, D);
+      DMP_LAUNCH_CHECK();
+    }
   }
   return DMP_OK;
 }
