@@ -313,6 +313,8 @@ def main():
             capture_case(name, *a, report=report, **kw)
 
     case("pf10963_n0_m0_lapack", pf, 0, 0, wfile, wsum, sign="lapack")
+    # the LAPACK sign flavour through recycling (4 trunk passes): pins the host-signs mode of the HIP path end to end
+    case("pf10963_n3_m0_lapack", pf, 3, 0, wfile, wsum, sign="lapack", stages=False, noise_threads=(1, 2, 3, 5))
     case("pf10963_n0_m0", pf, 0, 0, wfile, wsum)
     case("pf10963_n3_m0", pf, 3, 0, wfile, wsum, stages=False)
     case("pf10963_n2_m5", pf, 2, 5, wfile, wsum, stages=False)
