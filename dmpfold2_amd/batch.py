@@ -254,12 +254,18 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     # 4 x (0.6 + 1.5) ms of host work in front of the next group's first launches is GPU idle time.
     while True:
         if pipe is None or not pipe.busy():
+            # nothing left to issue: refill from the queue, else write what has completed, else wait for the GPU
             while room() and (pipe is None or pipe.backlog() < max(1, int(streams))):
                 if not take_one():
                     break
             if pipe is None or not pipe.busy():
+                if pipe is not None:
+                    done += pipe.poll()
                 if done:
                     finish(done.pop(0))
+                    continue
+                if len(parsed) > len(faulted):          # issued to the end, not yet completed on the GPU
+                    time.sleep(0.0002)
                     continue
                 if exhausted or not room():
                     break

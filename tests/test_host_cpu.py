@@ -375,7 +375,7 @@ class _FakePipeline:
     def __init__(self, device, max_L, max_N, state_dict, streams=2, stagger=False):
         _FakePipeline.made += 1
         self.jobs, self.max_L, self.max_N = [], max_L, max_N
-        self.age, self.ready, self.max_backlog = {}, {}, 0
+        self.age, self.ready, self.late, self.max_backlog = {}, {}, {}, 0
 
     def submit(self, d_msa, iterations, minsteps, template_ca=None):
         if d_msa.shape[1] > self.max_L or d_msa.shape[0] > self.max_N:
@@ -397,7 +397,7 @@ class _FakePipeline:
             self.age[t] += 1
             if self.age[t] >= 2:
                 del self.age[t]
-                self.ready[t] = self._value(t)
+                self.late[t] = 3                  # issued to the end: completes on the "GPU" three polls later
         return True
 
     def backlog(self):
@@ -407,6 +407,11 @@ class _FakePipeline:
         return bool(self.age)
 
     def poll(self):
+        for t in list(self.late):
+            self.late[t] -= 1
+            if self.late[t] <= 0:
+                del self.late[t]
+                self.ready[t] = self._value(t)
         done = [t for t in self.ready if t not in getattr(self, "_polled", set())]
         self._polled = getattr(self, "_polled", set()) | set(done)
         return done
