@@ -196,32 +196,67 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     max_L = max(8, max(L for L, _ in mine_scans))
     max_N = MAX_SEQS if any_a3m else max(1, min(MAX_SEQS, max(N for _, N in mine_scans)))
     t0 = time.perf_counter()
-    pipe, dev = None, None
+    pipe, dev, copy_stream = None, None, None
     failed, outputs, parsed, faulted = [], [], {}, []
     n_taken = 0
 
     def ensure_pipe():
-        nonlocal pipe, dev
+        nonlocal pipe, dev, copy_stream
         if pipe is None:
             dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
             sd = state_dict if state_dict is not None else load_state_dict(weights_file)
             pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
+            if dev.type == "cuda" and os.environ.get("DMP_BATCH_COPY_STREAM", "1") != "0":
+                # every copy of this front end goes through its own (non-blocking) stream: nothing is ever enqueued on
+                # the process's default stream while the engines run
+                copy_stream = torch.cuda.Stream(device=dev)
+            if os.environ.get("DMP_BATCH_LANE_TRACE"):      # developer diagnostic: HIP-event interval of every convolution
+                from . import _lib
+                for e in pipe.engines:
+                    _lib.check(pipe.lib.dmp_profile_enable(e.ctx, 1, 176 * (len(targets) // max(1, int(streams)) + 8)))
         return pipe
 
-    done = []                                           # completed on the GPU, not yet written
+    done = []                                           # completed on the GPU AND copied to the host, not yet written
+    copying = []                                        # (ticket, host coords, host confs, event): D2H in flight
 
-    def finish(t):
-        aln_path, alnmat = parsed.pop(t)
+    # The scheduler's thread must never block on the GPU: a synchronous copy on the default stream can queue behind an
+    # engine's kernels (streams share hardware queues) and stall the thread - and with it every engine - for
+    # milliseconds (kernel trace of round 3: 120 ms per round of four, 6.0 against 7.1 structures/s).  Alignments go
+    # up from pinned memory and results come back into pinned memory, both asynchronously; completion is polled.
+    def start_copy_back(t):
         coords, confs = pipe.peek(t)
+        if coords.is_cuda:
+            import contextlib
+            hc = torch.empty(coords.shape, dtype=coords.dtype, pin_memory=True)
+            hf = torch.empty(confs.shape, dtype=confs.dtype, pin_memory=True)
+            with (torch.cuda.stream(copy_stream) if copy_stream is not None else contextlib.nullcontext()):
+                hc.copy_(coords, non_blocking=True)   # the prediction has completed (polled): no ordering needed
+                hf.copy_(confs, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+        else:
+            hc, hf, ev = coords, confs, None
+        copying.append((t, hc, hf, ev))
+
+    def reap_copies():
+        while copying and (copying[0][3] is None or copying[0][3].query()):
+            done.append(copying.pop(0)[:3])
+
+    def finish(item):
+        t, coords, confs = item
+        aln_path, alnmat, _ = parsed.pop(t)
         if bool(torch.isnan(confs[:1]).any()):          # a device-side fault poisoned it: repeated alone at the end
-            parsed[t] = (aln_path, alnmat)
+            parsed[t] = (aln_path, alnmat, None)
             faulted.append(t)
             return
         pipe.result(t)
         outputs.append(write_result(out_dir, aln_path, coords, confs, alnmat, fmt))
 
     exhausted = False
-    cap = 2 * max(1, int(streams))                      # started + queued per rank
+    cap = int(os.environ.get("DMP_BATCH_CAP", 2 * max(1, int(streams))))      # started + queued per rank
+    backlog_cap = int(os.environ.get("DMP_BATCH_BACKLOG", max(1, int(streams))))
+    poll_every = max(1, int(os.environ.get("DMP_BATCH_POLL_EVERY", "1")))
+    idle_count = 0
 
     def take_one():
         """Read, encode and submit the next target of the queue; False when the queue is empty."""
@@ -237,30 +272,52 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             tpl = read_template_ca(tpl_path) if tpl_path else None
             alnmat = encode_aln(rows)
             p = ensure_pipe()
-            d_msa = torch.from_numpy(np.ascontiguousarray(alnmat)).to(dev)
-            parsed[p.submit(d_msa, iterations, minsteps, template_ca=tpl)] = (aln_path, alnmat)
+            h_msa = torch.from_numpy(np.ascontiguousarray(alnmat))
+            import contextlib
+            with (torch.cuda.stream(copy_stream) if copy_stream is not None else contextlib.nullcontext()):
+                if dev.type == "cuda":
+                    h_msa = h_msa.pin_memory()
+                    d_msa = h_msa.to(dev, non_blocking=True)
+                else:
+                    d_msa = h_msa
+                # the pinned source stays alive in `parsed` until the target is written; the engine that takes the
+                # target orders its stream behind the stream that is current at submission (the copy stream)
+                parsed[p.submit(d_msa, iterations, minsteps, template_ca=tpl)] = (aln_path, alnmat, h_msa)
         except (IndexError, ValueError, OSError, UnicodeDecodeError, RuntimeError) as exc:
             # unknown residue letter / ragged rows / unreadable file / larger than the scan said: this target only
             failed.append((aln_path, exc))
         return True
 
     def room():
-        return (not exhausted and (pipe is None or pipe.backlog() < max(1, int(streams)))
-                and len(parsed) - len(faulted) - len(done) < cap)
+        return (not exhausted and (pipe is None or pipe.backlog() < backlog_cap)
+                and len(parsed) - len(faulted) - len(done) - len(copying) < cap)
 
     # Host work - reading / encoding / uploading the next alignment, bringing a finished structure back, formatting
     # and writing it - is done ONE item per scheduling round in which nothing could be issued (the GPU has work
     # queued), never while units are waiting to be issued: the targets of a group finish and start together, and
     # 4 x (0.6 + 1.5) ms of host work in front of the next group's first launches is GPU idle time.
+    trace = {"take": 0.0, "finish": 0.0, "step": 0.0, "rounds": 0, "idle_rounds": 0} if os.environ.get("DMP_BATCH_TRACE") else None
+    if trace is not None:                               # developer diagnostic: where the host loop spends its time
+        def timed(fn, key):
+            def w(*a):
+                t = time.perf_counter()
+                try:
+                    return fn(*a)
+                finally:
+                    trace[key] += time.perf_counter() - t
+            return w
+        take_one, finish = timed(take_one, "take"), timed(finish, "finish")
     while True:
         if pipe is None or not pipe.busy():
             # nothing left to issue: refill from the queue, else write what has completed, else wait for the GPU
-            while room() and (pipe is None or pipe.backlog() < max(1, int(streams))):
+            while room():
                 if not take_one():
                     break
             if pipe is None or not pipe.busy():
                 if pipe is not None:
-                    done += pipe.poll()
+                    for t in pipe.poll():
+                        start_copy_back(t)
+                    reap_copies()
                 if done:
                     finish(done.pop(0))
                     continue
@@ -270,24 +327,52 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
                 if exhausted or not room():
                     break
                 continue
+        if trace is not None:
+            t_s = time.perf_counter()
         progressed = pipe.step()
-        done += pipe.poll()
+        if trace is not None:
+            trace["step"] += time.perf_counter() - t_s
+            trace["rounds"] += 1
+            trace["idle_rounds"] += 0 if progressed else 1
         if not progressed:
+            idle_count += 1
+            if idle_count % poll_every == 0:
+                for t in pipe.poll():
+                    start_copy_back(t)
+                reap_copies()
             if room():
                 take_one()
             elif done:
                 finish(done.pop(0))
-    for t in done:
-        finish(t)
+    if copying:
+        if copying[-1][3] is not None:
+            copying[-1][3].synchronize()
+        reap_copies()
+    for item in done:
+        finish(item)
     if faulted:
         res = pipe.collect(faulted)
         for t in faulted:
-            aln_path, alnmat = parsed.pop(t)
+            aln_path, alnmat, _ = parsed.pop(t)
             if isinstance(res[t], Exception):
                 failed.append((aln_path, res[t]))
             else:
                 outputs.append(write_result(out_dir, aln_path, res[t][0], res[t][1], alnmat, fmt))
     elapsed = time.perf_counter() - t0
+    if pipe is not None and os.environ.get("DMP_BATCH_LANE_TRACE"):
+        import ctypes as C
+        from . import _lib
+        torch.cuda.synchronize()
+        capn = 176 * (len(targets) // max(1, int(streams)) + 8)
+        rows = []
+        for k, e in enumerate(pipe.engines):
+            a, b, n = (C.c_float * capn)(), (C.c_float * capn)(), C.c_int()
+            _lib.check(pipe.lib.dmp_profile_conv_intervals(e.ctx, pipe.engines[0].ctx, a, b, capn, C.byref(n)))
+            rows += [(a[i], b[i], k) for i in range(n.value)]
+        np.save(os.environ["DMP_BATCH_LANE_TRACE"], np.array(sorted(rows), dtype=np.float64))
+    if trace is not None:
+        print("dmpfold-batch trace: %.2f s in all; take %.3f, finish %.3f, step %.3f s; %d rounds, %d idle" % (
+            elapsed, trace["take"], trace["finish"], trace["step"], trace["rounds"], trace["idle_rounds"]), file=sys.stderr)
     if pipe is not None:
         pipe.close()
     if failed:

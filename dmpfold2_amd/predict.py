@@ -353,6 +353,30 @@ def pump_timing_report():
               file=sys.stderr)
 
 
+# Engine streams are reused from one pipeline of the process to the next: which hardware queues a stream gets depends
+# on how many streams were created before it, and on this runtime the SECOND set of four costs the scheduler 15 %
+# (tools/pipeline_order.py: 5.87 structures/s on pool streams 5-8 against 6.9-7.0 on every other set).
+_STREAM_POOL = {}            # device index -> [[stream, in use]]
+
+
+def _take_stream(device):
+    pool = _STREAM_POOL.setdefault(device.index, [])
+    for item in pool:
+        if not item[1]:
+            item[1] = True
+            return item[0]
+    with torch.cuda.device(device):
+        st = torch.cuda.Stream(device=device)
+    pool.append([st, True])
+    return st
+
+
+def _release_stream(device, st):
+    for item in _STREAM_POOL.get(device.index, []):
+        if item[0] is st:
+            item[1] = False
+
+
 class Pipeline:
     """Throughput mode on one GPU: `streams` engines (each its own context and HIP stream) share a
     lane, so their machine-filling convolutions take turns while the latency-bound kernels of one
@@ -373,8 +397,7 @@ class Pipeline:
         self._lane = C.c_void_p()
         _lib.check(self.lib.dmp_lane_create(C.byref(self._lane)))
         for _ in range(max(1, int(streams))):
-            with torch.cuda.device(self.device):
-                st = torch.cuda.Stream(device=self.device)
+            st = _take_stream(self.device)
             eng = Engine(self.device, max_L, max_N, stream=st)
             if self.engines:
                 eng.share_weights(self.engines[0])       # packed once per pipeline, not once per engine
@@ -486,6 +509,8 @@ class Pipeline:
                 self._chain_pool = None
         for e in self.engines:
             e.close()
+            if e._stream is not None:
+                _release_stream(self.device, e._stream)
         self.engines = []
         if self._fe is not None:
             self._fe.close()
@@ -520,7 +545,11 @@ class Pipeline:
                                    f"alignment has {L} columns")
         t = self._tickets
         self._tickets += 1
-        job = (t, d_msa, int(max(iterations, 0)), int(max(minsteps, 0)), d_tpl)
+        # the stream that is current NOW produced d_msa (the caller's copy stream, say); the engine that takes the
+        # target later orders itself behind this point, whatever stream is current then
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        job = (t, d_msa, int(max(iterations, 0)), int(max(minsteps, 0)), d_tpl, ready)
         self._pending.append(job)
         self._jobs[t] = job
         return t
@@ -615,10 +644,11 @@ class Pipeline:
             _lib.check(self.lib.dmp_predict_issue_group_chain(lead_ctx, C.c_void_p(stream_handle)))
 
     def _begin(self, s, job):
-        t, d_msa, nloops, minsteps, d_tpl = job
+        t, d_msa, nloops, minsteps, d_tpl, ready = job
         e = self.engines[s]
         cur = torch.cuda.current_stream(self.device)
         e._stream.wait_stream(cur)
+        e._stream.wait_event(ready)
         n, L = d_msa.shape
         # The outputs belong to the caller's stream (drain() orders it after the engine); inputs and
         # outputs are used on the engine's stream, which the caching allocator has to know before it
@@ -778,13 +808,16 @@ class Pipeline:
         return self._results.pop(ticket)
 
     # ---- streaming use (dmpfold2_amd.batch): submit / step / poll, no barrier between targets ----------------
-    def step(self):
-        """One scheduling round; yields the core when nothing could be issued.  True if anything was enqueued."""
+    def step(self, rounds=32):
+        """Up to `rounds` scheduling rounds (fewer when a round finds nothing to issue: the core is yielded and the
+        call returns, so that the caller can do a piece of host work while the GPU is busy).  True if the LAST round
+        enqueued something - i.e. the scheduler may have more to issue right away."""
         with torch.cuda.device(self.device):
-            if self._pump():
-                return True
-        self._idle()
-        return False
+            for _ in range(max(1, int(rounds))):
+                if not self._pump():
+                    self._idle()
+                    return False
+        return True
 
     def backlog(self):
         """Targets queued but not yet started on an engine."""
@@ -824,7 +857,7 @@ class Pipeline:
                 job = self._jobs.get(t)
                 coords, confs = self.result(t)
                 if bits and bool(torch.isnan(confs[0])):
-                    _, d_msa, nloops, minsteps, d_tpl = job
+                    _, d_msa, nloops, minsteps, d_tpl = job[:5]
                     try:
                         coords, confs = eng.predict_device_checked(d_msa, d_tpl, nloops, minsteps)
                         if eng.last_fallback:

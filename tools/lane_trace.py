@@ -47,6 +47,8 @@ for k, e in enumerate(pipe.engines):
     iv += [(a[i], b[i], k) for i in range(n.value)]
 pipe.close()
 iv.sort()
+if os.environ.get("LT_SAVE"):
+    np.save(os.environ["LT_SAVE"], np.array(iv, dtype=np.float64))
 busy = sum(b - a for a, b, _ in iv)
 span = iv[-1][1] - iv[0][0]
 print(f"S={S}: {T} targets in {wall:.0f} ms = {T / wall * 1e3:.2f} structures/s; {len(iv)} convolutions, "
