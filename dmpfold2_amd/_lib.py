@@ -54,6 +54,7 @@ SIGNATURES = {
     "dmp_predict_group_vgru": (_i, [C.POINTER(_vp), _i]),
     "dmp_predict_detach_group_chain": (_i, [_vp]),
     "dmp_predict_issue_group_chain": (_i, [_vp, _vp]),
+    "dmp_predict_chain_on_own_stream": (_i, [_vp]),
     "dmp_predict_set_vgru_result": (_i, [_vp, _fp, _vp]),
     "dmp_predict_end_refine": (_i, [_vp, _vp]),
     "dmp_predict_issue_unit": (_i, [_vp, _vp]),

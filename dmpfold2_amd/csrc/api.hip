@@ -1092,6 +1092,12 @@ int dmp_predict_detach_group_chain(dmp_ctx* lead) {
   return DMP_OK;
 }
 
+int dmp_predict_chain_on_own_stream(dmp_ctx* lead) {
+  DMP_ARG(lead && lead->vg_leader == lead && lead->vg_detached == 1 && !vg_done(lead), "detach the chain first");
+  lead->vg_detached = 2;
+  return DMP_OK;
+}
+
 int dmp_predict_issue_group_chain(dmp_ctx* lead, void* stream) {
   DMP_ARG(lead != nullptr, "null context");
   DMP_ARG(lead->vg_leader == lead && lead->vg_detached && !vg_done(lead),
@@ -1116,6 +1122,10 @@ int dmp_predict_next_unit(const dmp_ctx* ctx) {
   if (ctx->fe_next == ctx->fe_total - 1 && ctx->vg_leader && (ctx->vg_leader != ctx || ctx->vg_detached) &&
       !vg_done(ctx->vg_leader))
     return DMP_UNIT_WAIT;      // the group's chain has not been issued to its end yet
+  // a detached chain that is being enqueued on the leader's OWN stream (vg_detached == 2): the leader's remaining
+  // front-end units wait until it has been enqueued to its end - kernels slipped between its rows would stretch it
+  if (ctx->fe_next >= 1 && ctx->fe_next < ctx->fe_total && ctx->vg_leader == ctx && ctx->vg_detached == 2 && !vg_done(ctx))
+    return DMP_UNIT_WAIT;
   if (ctx->fe_next < ctx->fe_total) return DMP_UNIT_LIGHT;
   if (ctx->passes_done > ctx->run_nloops) return DMP_UNIT_NONE;
   return (ctx->unit_next >= 1 && ctx->unit_next <= NBLOCK) ? DMP_UNIT_CONV : DMP_UNIT_LIGHT;

@@ -451,15 +451,19 @@ class Pipeline:
         # against 6.95 / 6.96: beside four inverses the chain's steps take 45 us instead of 26 (their 240 workgroups
         # wait for CU slots 2001 times), the front-end phase grows from 99 to 110 ms.  Off by default;
         # DMP_VGRU_DETACH=1 switches it on, DMP_VGRU_CHAIN_PRIO=1 gives the chain's stream the high HIP priority.
-        self._detach = os.environ.get("DMP_VGRU_DETACH", "0") == "1" and S > 1 and self._group_max > 1
+        # DMP_VGRU_DETACH=2: the helper thread enqueues the chain on the LEADER'S OWN stream (no fifth stream: on this
+        # runtime a fifth active stream shares a hardware pipe with one of the four engines').
+        self._detach_own = os.environ.get("DMP_VGRU_DETACH", "0") == "2" and S > 1 and self._group_max > 1
+        self._detach = (os.environ.get("DMP_VGRU_DETACH", "0") == "1" and S > 1 and self._group_max > 1) or self._detach_own
         self._chain_stream = None
         self._chain_pool = None
         self._chain_futures = []
         if self._detach:
             from concurrent.futures import ThreadPoolExecutor
-            with torch.cuda.device(self.device):
-                prio = -1 if os.environ.get("DMP_VGRU_CHAIN_PRIO") == "1" else 0
-                self._chain_stream = torch.cuda.Stream(device=self.device, priority=prio)
+            if not self._detach_own:
+                with torch.cuda.device(self.device):
+                    prio = -1 if os.environ.get("DMP_VGRU_CHAIN_PRIO") == "1" else 0
+                    self._chain_stream = torch.cuda.Stream(device=self.device, priority=prio)
             self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
         # Features ahead: an engine in its trunk passes is given its NEXT target early and computes that target's
         # reweighting, covariance, inverse and contacts into its own (idle) feature buffers, one unit after every
@@ -630,13 +634,17 @@ class Pipeline:
             ctxs = (C.c_void_p * len(slots))(*[self.engines[s].ctx for s in slots])
             _lib.check(self.lib.dmp_predict_group_vgru(ctxs, len(slots)))
             if self._detach:
-                cs = self._chain_stream
+                cs = lead._stream if self._detach_own else self._chain_stream
                 cs.wait_stream(torch.cuda.current_stream(self.device))
                 for s in slots:
                     for x in self._slot[s][3]:
                         if x is not None:
                             x.record_stream(cs)
                 _lib.check(self.lib.dmp_predict_detach_group_chain(lead.ctx))
+                if self._detach_own:
+                    # the leader's first unit (sequence weights + covariance) goes first, then the chain, on its stream
+                    _lib.check(self.lib.dmp_predict_issue_unit(lead.ctx, lead.stream()))
+                    _lib.check(self.lib.dmp_predict_chain_on_own_stream(lead.ctx))
                 self._chain_futures.append(self._chain_pool.submit(self._issue_chain, lead.ctx, cs.cuda_stream))
 
     def _issue_chain(self, lead_ctx, stream_handle):

@@ -269,6 +269,11 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n);
  * Results are bit-identical to ungrouped predictions. */
 int dmp_predict_detach_group_chain(dmp_ctx* lead);
 int dmp_predict_issue_group_chain(dmp_ctx* lead, void* stream);
+/* Variant: the detached chain will be enqueued (by the helper thread) on the stream the leader's units are issued on -
+ * no additional stream / hardware queue.  Call between detach and issue: the leader's units behind its first one then
+ * answer DMP_UNIT_WAIT until the chain has been enqueued to its end (kernels slipped between its rows would stretch
+ * it); the other members' units run beside the chain on their own streams. */
+int dmp_predict_chain_on_own_stream(dmp_ctx* lead);
 /* The vertical GRU of this prediction has been (or is being) computed ahead of time by dmp_gru_vertical /
  * dmp_gru_vertical_group on the same alignment: d_vout (L x 512, device) is its result, `event` (hipEvent_t or
  * NULL) was recorded behind it.  Call right after dmp_predict_begin_units, before any unit is issued: the

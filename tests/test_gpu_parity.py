@@ -459,13 +459,15 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
 
 
 @pytest.mark.parametrize("group,lookahead,detach,ahead", [(1, 0, 1, 1), (2, 0, 1, 1), (4, 0, 1, 0), (4, 0, 0, 1),
-                                                          (4, 0, 0, 0), (2, 0, 0, 1), (4, 24, 1, 1), (3, 400, 0, 1)])
+                                                          (4, 0, 0, 0), (2, 0, 0, 1), (4, 24, 1, 1), (3, 400, 0, 1),
+                                                          (4, 0, 2, 0), (3, 0, 2, 1)])
 def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead, detach,
                                                             ahead):
     """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE launch chain
     (group leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so
     groups of every size up to `group` form.  detach = 1: the chain is issued by a helper thread on
-    its own stream (dmp_predict_detach_group_chain / dmp_predict_issue_group_chain) while the scheduler's thread
+    its own stream - or, detach = 2, on the leader's stream - (dmp_predict_detach_group_chain /
+    dmp_predict_issue_group_chain / dmp_predict_chain_on_own_stream) while the scheduler's thread
     issues the members' other front-end units.  With a look-ahead the chains of the next group run beside the
     predictions in flight and are handed over (dmp_predict_set_vgru_result).  Every result equals the single
     engine's, bit for bit."""
