@@ -21,6 +21,7 @@ target count and takes the maximum elapsed time for the summary line.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -206,7 +207,7 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
             sd = state_dict if state_dict is not None else load_state_dict(weights_file)
             pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
-            if dev.type == "cuda" and os.environ.get("DMP_BATCH_COPY_STREAM", "1") != "0":
+            if dev.type == "cuda":
                 # every copy of this front end goes through its own (non-blocking) stream: nothing is ever enqueued on
                 # the process's default stream while the engines run
                 copy_stream = torch.cuda.Stream(device=dev)
@@ -219,14 +220,14 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     done = []                                           # completed on the GPU AND copied to the host, not yet written
     copying = []                                        # (ticket, host coords, host confs, event): D2H in flight
 
-    # The scheduler's thread must never block on the GPU: a synchronous copy on the default stream can queue behind an
-    # engine's kernels (streams share hardware queues) and stall the thread - and with it every engine - for
-    # milliseconds (kernel trace of round 3: 120 ms per round of four, 6.0 against 7.1 structures/s).  Alignments go
-    # up from pinned memory and results come back into pinned memory, both asynchronously; completion is polled.
+    # The scheduler's thread never blocks on the GPU: a synchronous copy on the default stream can queue behind an
+    # engine's kernels (streams share hardware queues) and would stall the thread - and with it every engine.
+    # Alignments go up from pinned memory and results come back into pinned memory, both asynchronously on the front
+    # end's own stream; completion is polled.  (Measured at the north-star size: files -> PDB files 6.2 structures/s
+    # including the pipeline's set-up against 6.7 for the same targets resident in HBM, tools/batch_throughput.py.)
     def start_copy_back(t):
         coords, confs = pipe.peek(t)
         if coords.is_cuda:
-            import contextlib
             hc = torch.empty(coords.shape, dtype=coords.dtype, pin_memory=True)
             hf = torch.empty(confs.shape, dtype=confs.dtype, pin_memory=True)
             with (torch.cuda.stream(copy_stream) if copy_stream is not None else contextlib.nullcontext()):
@@ -253,10 +254,8 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
         outputs.append(write_result(out_dir, aln_path, coords, confs, alnmat, fmt))
 
     exhausted = False
-    cap = int(os.environ.get("DMP_BATCH_CAP", 2 * max(1, int(streams))))      # started + queued per rank
-    backlog_cap = int(os.environ.get("DMP_BATCH_BACKLOG", max(1, int(streams))))
-    poll_every = max(1, int(os.environ.get("DMP_BATCH_POLL_EVERY", "1")))
-    idle_count = 0
+    cap = 2 * max(1, int(streams))                      # started + queued per rank
+    backlog_cap = max(1, int(streams))                  # queued, not yet started
 
     def take_one():
         """Read, encode and submit the next target of the queue; False when the queue is empty."""
@@ -273,7 +272,6 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             alnmat = encode_aln(rows)
             p = ensure_pipe()
             h_msa = torch.from_numpy(np.ascontiguousarray(alnmat))
-            import contextlib
             with (torch.cuda.stream(copy_stream) if copy_stream is not None else contextlib.nullcontext()):
                 if dev.type == "cuda":
                     h_msa = h_msa.pin_memory()
@@ -335,11 +333,9 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             trace["rounds"] += 1
             trace["idle_rounds"] += 0 if progressed else 1
         if not progressed:
-            idle_count += 1
-            if idle_count % poll_every == 0:
-                for t in pipe.poll():
-                    start_copy_back(t)
-                reap_copies()
+            for t in pipe.poll():
+                start_copy_back(t)
+            reap_copies()
             if room():
                 take_one()
             elif done:
