@@ -59,9 +59,23 @@ constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slo
 constexpr int CH_WCOL = 5 * CH_WSLOT;                                 // one tap column of one wave in the packed weights
 constexpr int CH_WBUF = 3 * CH_WSLOT;                                 // per-wave LDS weight buffer: 3 tap slots
 constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_WBUF * 16;       // 55296
-// number of workgroups to launch for tiles x tiles pixel tiles: XCD x (block b runs on XCD b % 8) works
-// on the channel splits {0,1} (x even) or {2,3} (x odd) of a contiguous quarter of the tiles
-inline int conv_f16_grid(int tiles) { return 8 * 2 * ((tiles * tiles + 3) / 4); }
+// number of workgroups to launch for tiles x tiles pixel tiles (XCD-aware block map, see CH_MAP)
+// block -> (tile, channel split) map (round 3, tools/r03_map.sh, profiles/r03_conv_block_maps.txt; block b runs on XCD
+// b % 8).  Sustained ms per launch at L = 300 (one stream / two launches in flight), L2-fabric bytes per launch
+// (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included; 98.7 MB algorithmic), scheduler throughput:
+//   0  XCD x: splits {0,1} or {2,3} of a contiguous quarter of the tiles (rounds 1-2)   0.686 / 0.652   306 MB   7.22
+//   1  XCD x: all four splits of an eighth of the tiles (a tile read by ONE XCD)         0.687 / 0.659   399 MB
+//   2  XCD x: ONE split of half of the tiles (1.64 MB of weight pieces per XCD)           0.675 / 0.645   339 MB   7.28
+// Fewer XCDs per tile do not lower the traffic - the weight set no longer fits the L2 beside the activations and comes
+// back from the Infinity Cache - and the map with the MOST fabric bytes is the fastest: its weights stay in the L2, and
+// what the kernel waits for is the weight stream, not the bytes.  Map 2 is the default.
+#ifndef CH_MAP
+#define CH_MAP 2
+#endif
+inline int conv_f16_grid(int tiles) {
+  const int nt = tiles * tiles;
+  return CH_MAP == 1 ? 8 * 4 * ((nt + 7) / 8) : (CH_MAP == 2 ? 8 * ((nt + 1) / 2) : 8 * 2 * ((nt + 3) / 4));
+}
 
 __host__ __device__ inline uint16_t ch_f16_bits(float f) {
   const _Float16 h = (_Float16)f;                                     // round to nearest even
@@ -244,10 +258,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
   // XCD x works on the channel splits {0,1} (x even) or {2,3} (x odd) only: its share of the weight
   // pieces is 3.3 MB, which fits the 4 MB L2; a tile's input is then read by two XCDs
   const int xcd = id & 7, slot = id >> 3;
-  const int ntiles = tiles * tiles, tper = (ntiles + 3) >> 2;
+  const int ntiles = tiles * tiles;
+#if CH_MAP == 1
+  // experiment: XCD x works on all four channel splits of a contiguous eighth of the tiles (a tile's input is read
+  // by ONE XCD; its share of the weight pieces is all 6.6 MB)
+  const int tper = (ntiles + 7) >> 3;
+  const int tile = xcd * tper + (slot >> 2);
+  const int split = slot & 3;
+  if ((slot >> 2) >= tper || tile >= ntiles) return;
+#elif CH_MAP == 2
+  // XCD x works on ONE channel split (x & 3) of a contiguous half of the tiles: its 1.64 MB of weight pieces stay in
+  // its 4 MB L2; a tile's input is read by four XCDs at about the same time (Infinity-Cache hits)
+  const int tper = (ntiles + 1) >> 1;
+  const int tile = (xcd >> 2) * tper + slot;
+  const int split = xcd & 3;
+  if (slot >= tper || tile >= ntiles) return;
+#else
+  const int tper = (ntiles + 3) >> 2;
   const int tile = (xcd >> 1) * tper + (slot >> 1);
   const int split = 2 * (xcd & 1) + (slot & 1);
   if ((slot >> 1) >= tper || tile >= ntiles) return;
+#endif
   const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
