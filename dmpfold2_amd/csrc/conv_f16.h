@@ -57,7 +57,10 @@ constexpr int CH_IN_SLOTS = 2 * 2 * CH_HALO * CH_PITCH;               // 1920 16
 constexpr int CH_IN_BYTES = CH_IN_SLOTS * 16;                         // 30720
 constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slots = 2 KB per wave and tap
 constexpr int CH_WCOL = 5 * CH_WSLOT;                                 // one tap column of one wave in the packed weights
-constexpr int CH_WBUF = 3 * CH_WSLOT;                                 // per-wave LDS weight buffer: 3 tap slots
+#ifndef CH_WRING
+#define CH_WRING 0   // 1: five tap slots per wave (even pass 0-2, odd pass 3-4): every weight DMA flies two passes, not one
+#endif
+constexpr int CH_WBUF = (CH_WRING ? 5 : 3) * CH_WSLOT;                // per-wave LDS weight buffer: 3 (5) tap slots
 constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_WBUF * 16;       // 55296
 // number of workgroups to launch for tiles x tiles pixel tiles (XCD-aware block map, see CH_MAP)
 // block -> (tile, channel split) map (round 3, tools/r03_map.sh, profiles/r03_conv_block_maps.txt; block b runs on XCD
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
     const uint4* src = wq4 + (int64_t)(h >> 1) * 4 * CH_WCOL + odd * 3 * CH_WSLOT;
     if (odd) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ch_dma16(src + 64 * i, w_lds_addr + 1024 * i);
+      for (int i = 0; i < 4; ++i) ch_dma16(src + 64 * i, w_lds_addr + (CH_WRING ? 3 * CH_WSLOT * 16 : 0) + 1024 * i);
     } else {
 #pragma unroll
       for (int i = 0; i < 6; ++i) ch_dma16(src + 64 * i, w_lds_addr + 1024 * i);
@@ -402,6 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
   }
 #else
   wdma(0);
+  if (CH_WRING) wdma(1);
 
   for (int g = 0; g < 8; ++g) {
     __syncthreads();                                   // every wave is done with the previous tile
@@ -421,7 +425,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
       const uint4* il = in_l + b_base + dx;
       const int h0 = 2 * (g * 5 + dx);
       {
-        ch_wait_vm<0>();                               // this pass's weights (issued one pass ago)
+        // this pass's weights: issued one pass ago - or, with the five-slot ring, two passes ago with the odd pass's
+        // four DMAs behind them (at the head of a stage everything was drained with the tile)
+        if (CH_WRING) ch_wait_vm<4>(); else ch_wait_vm<0>();
         uint4 a[3][2];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -429,19 +435,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
           a[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wdma(h0 + 1);                                  // the buffer is free: stream the next pass
+        if (CH_WRING) { if (h0 + 2 < 80) wdma(h0 + 2); }   // the even slots are free: the next EVEN pass
+        else wdma(h0 + 1);                             // the buffer is free: stream the next pass
         ch_column_pass<3, 0>(a, il, acc);
       }
       {
-        ch_wait_vm<0>();
+        // ring: behind the odd weights only the next even pass's six DMAs may be outstanding (none after the last)
+        if (CH_WRING) { if (h0 + 2 < 80) ch_wait_vm<6>(); else ch_wait_vm<0>(); } else ch_wait_vm<0>();
         uint4 a[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          a[t][0] = w_l[t * CH_WSLOT + a_off];
-          a[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
+          a[t][0] = w_l[(CH_WRING ? 3 : 0) * CH_WSLOT + t * CH_WSLOT + a_off];
+          a[t][1] = w_l[(CH_WRING ? 3 : 0) * CH_WSLOT + t * CH_WSLOT + 64 + a_off];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (h0 + 2 < 80) wdma(h0 + 2);
+        if (CH_WRING) { if (h0 + 3 < 80) wdma(h0 + 3); }   // the odd slots are free: the next ODD pass
+        else if (h0 + 2 < 80) wdma(h0 + 2);
         ch_column_pass<2, 1>(a, il, acc);
       }
     }
