@@ -58,17 +58,26 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
   if (tid == 0) sh_abort = 0;
   __syncthreads();
   u64* hx_dir = a.hx + (int64_t)dir * 2 * HID2;
+  float gin[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  auto load_gi = [&](int step) {
+    if (kg == 0 && step < a.T) {
+      const int tn = dir ? (a.T - 1 - step) : step;
+      const float* gp = a.G + (int64_t)tn * 1536 + dir * 768 + u0;
+#pragma unroll
+      for (int gate = 0; gate < 3; ++gate) { gin[gate][0] = gp[gate * HID2]; gin[gate][1] = gp[gate * HID2 + 1]; }
+    }
+  };
+  load_gi(0);
   for (int step = 0; step < a.T; ++step) {
     const int t = dir ? (a.T - 1 - step) : step;
     const unsigned epoch = (unsigned)step + 1u;
     u64* hx = hx_dir + (step & 1) * HID2;
-    // input projections of this step for the two units (needed by lanes kg == 0 only)
+    // input projections of this step for the two units (needed by lanes kg == 0 only): loaded one step ahead - behind
+    // the previous step's publication, while that step's granules were being awaited - so that their L2 latency
+    // is off the step's critical path (round 3)
     float gi[3][2];
-    if (kg == 0) {
-      const float* gp = a.G + (int64_t)t * 1536 + dir * 768 + u0;
 #pragma unroll
-      for (int gate = 0; gate < 3; ++gate) { gi[gate][0] = gp[gate * HID2]; gi[gate][1] = gp[gate * HID2 + 1]; }
-    }
+    for (int gate = 0; gate < 3; ++gate) { gi[gate][0] = gin[gate][0]; gi[gate][1] = gin[gate][1]; }
     float hv[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -105,6 +114,7 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    load_gi(step + 1);               // next step's input projections fly while this step's granules are gathered
     __syncthreads();                 // every wave has read h for this step
     if (wave == 0) {
       // sweep the 256 granules of this step (4 per lane) until all carry this epoch
