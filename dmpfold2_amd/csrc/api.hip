@@ -801,7 +801,7 @@ int dmp_pair_distances(dmp_ctx* ctx, const float* d_ca, int L, int clamp, float*
 }
 
 int dmp_refine_coords(dmp_ctx* ctx, float* d_ca, int L, int steps, void* stream) {
-  DMP_ARG(ctx && d_ca && L >= 2 && L <= 1280 && steps >= 0, "bad argument");
+  DMP_ARG(ctx && d_ca && L >= 2 && L <= DMP_MAX_L && steps >= 0, "bad argument");
   DMP_ARG(L >= 2 && L <= ctx->max_L, "L = %d outside 2..max_L", L);
   return refine_coords(ctx, d_ca, L, steps, STREAM);
 }

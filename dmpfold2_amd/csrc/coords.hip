@@ -318,7 +318,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_cluster_kernel(RefineArgs a
 
 int refine_coords(dmp_ctx* c, float* d_ca, int L, int steps, hipStream_t s) {
   if (steps <= 0) return DMP_OK;
-  if (c->refine_single || L < 2 * RF_G) {
+  if ((c->refine_single && L <= 1280) || L < 2 * RF_G) {      // one workgroup: (6 + 3 T) L floats of LDS
     const int T = L >= 1024 ? 1 : (1024 / L > 8 ? 8 : 1024 / L);
     hipLaunchKernelGGL(refine_kernel, dim3(1), dim3(1024), sizeof(float) * (6 + 3 * T) * L, s, d_ca, L,
                        steps);

@@ -6,7 +6,15 @@
 
 namespace dmp {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gates on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each), as in the vertical GRU
+// (vgru.hip): absolute error below 2e-7, saturating correctly.  The device library's expf / tanhf are two dependent
+// chains of 40-100 instructions on ONE wave's critical path in every step of a latency-bound recurrence.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.442695040888963f));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
+}
 
 // Weight-stationary cluster: each direction is run by SEQ_G workgroups; workgroup g keeps the
 // 96 rows of W_hh that produce hidden units [32g, 32g+32) in registers (96 floats per lane)
@@ -15,6 +23,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // the flag) and gathers the other 224 by sweeping the granule array until every tag equals
 // the step's epoch.  The protocol does not depend on where the workgroups run; putting the
 // 8 workgroups of a direction on one XCD (block id % 8) only shortens the hand-off.
+// Every wave gathers the state for itself into its own LDS copy (LDS operations of one wave execute in
+// order): no workgroup barrier anywhere in the step loop.
 constexpr int SEQ_G = 8;
 typedef unsigned long long u64;
 
@@ -30,8 +40,7 @@ struct SeqArgs {
 
 // grid: 8 * SEQ_G blocks (only ids with id % 8 < 2 work: direction = id % 8)   block: 256
 __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
-  __shared__ __attribute__((aligned(16))) float h[HID2];
-  __shared__ int sh_abort;
+  __shared__ __attribute__((aligned(16))) float hs[4][HID2];
   const int dir = blockIdx.x & 7, g = blockIdx.x >> 3;
   if (dir >= 2) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,9 +63,9 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
       }
       bh[gate][uu] = a.bhh[dir][row];
     }
-  if (tid < HID2) h[tid] = 0.f;
-  if (tid == 0) sh_abort = 0;
-  __syncthreads();
+  float* h = hs[wave];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h[lane + 64 * q] = 0.f;
   u64* hx_dir = a.hx + (int64_t)dir * 2 * HID2;
   float gin[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   auto load_gi = [&](int step) {
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
       for (int uu = 0; uu < 2; ++uu) {
         const float rg = sigmoidf_(gi[0][uu] + (acc[0][uu] + bh[0][uu]));
         const float zg = sigmoidf_(gi[1][uu] + (acc[1][uu] + bh[1][uu]));
-        const float ng = tanhf(gi[2][uu] + rg * (acc[2][uu] + bh[2][uu]));
+        const float ng = tanhf_(gi[2][uu] + rg * (acc[2][uu] + bh[2][uu]));
         const float hp = uu ? hp1 : hp0;
         const float hn = (hp - ng) * zg + ng;
         a.out[(int64_t)t * 512 + dir * HID2 + u0 + uu] = hn;
@@ -115,8 +124,7 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
       }
     }
     load_gi(step + 1);               // next step's input projections fly while this step's granules are gathered
-    __syncthreads();                 // every wave has read h for this step
-    if (wave == 0) {
+    {
       // sweep the 256 granules of this step (4 per lane) until all carry this epoch
       unsigned vals[4];
       bool dead = false;
@@ -132,15 +140,15 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
         if (spins > 2000000u) { dead = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
-      if (dead) {
-        if (lane == 0) { sh_abort = 1; atomicOr(a.abort_flag, 1); }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) h[lane + 64 * q] = __uint_as_float(vals[q]);
+      if (dead) {                    // every wave of the cluster waits for the same granules: all of them leave
+        if (lane == 0) atomicOr(a.abort_flag, 1);
+        break;
       }
+      __builtin_amdgcn_wave_barrier();   // every lane has read this step's h before it is overwritten
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[lane + 64 * q] = __uint_as_float(vals[q]);
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();                 // h holds the new state
-    if (sh_abort) break;
   }
 }
 

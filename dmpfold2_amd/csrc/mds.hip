@@ -190,6 +190,8 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 // grid: G workgroups   block: 256   dynamic LDS: 4 n doubles
 // All global loads a step needs (previous reflector and product, pivot row, the wave's first row)
 // are issued before the first reduction, so a launch pays one memory round trip, not four.
+// NI = rows of the pivot column per thread: 256 NI >= n (5 up to order 1280, 8 up to DMP_MAX_L = 2048).
+template <int NI>
 __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ A, const TriRun* __restrict__ run,
                                                            int idx, double* __restrict__ d,
                                                            double* __restrict__ e, double* __restrict__ tau,
@@ -205,7 +207,6 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mp = n - k;                                   // order of the block A[k.., k..]
   double* A22p = A + (int64_t)k * n + k;
-  constexpr int NI = 5;                                   // 256 * 5 >= 1280 = largest order
   constexpr int NJ = 5;                                   // prefetched columns of the first row: 64 * 5
   const int kp = k > 0 ? k - 1 : 0;
   const double* pp = P + (int64_t)(kp & 1) * n;
@@ -333,8 +334,14 @@ __device__ __forceinline__ int sturm_count(const double* d, const double* e2, in
 }
 
 // Bisection + inverse iteration on the tridiagonal matrix.  block: 512 (8 waves: one eigenvalue each).
-// dynamic LDS: dd[n], e2[n], x[n][8], ee[n] doubles.  Global scratch F: 5 arrays [n][8].
+// dynamic LDS: dd[n], e2[n], ee[n] doubles, then by MODE (chosen by the order, tri_eig_lds_bytes):
+//   0 (n <= 384): x[n][8] and the five LU factor arrays [n][8] (408 n bytes): the two triangular solves of an
+//                 iteration read nothing but LDS (from L2 every 8 steps of the recurrence paid a round trip:
+//                 0.3 of the kernel's 0.66 ms at n = 300);
+//   1 (n <= 1280): x[n][8] in LDS, the factors in the global scratch F (5 arrays [n][8]);
+//   2 (larger): x is Z itself (global), only the 3 n doubles the Sturm counts read stay in LDS.
 // Outputs: lam[8] (ascending), Z[n][8] (unit eigenvectors of T).
+template <int MODE>
 __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__ d,
                                                       const double* __restrict__ e, int n,
                                                       double* __restrict__ F,
@@ -343,8 +350,9 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* dd = sm;
   double* e2 = sm + n;
-  double* x = sm + 2 * n;              // [n][8]
-  double* ee = sm + (2 + NEV) * n;     // off-diagonal (the LU recurrence reads it n times per lane)
+  double* ee = sm + 2 * n;             // off-diagonal (the LU recurrence reads it n times per lane)
+  double* x = MODE == 2 ? Z : sm + 3 * n;   // [n][8]
+  if (MODE == 0) F = sm + (3 + NEV) * n;
   __shared__ double lam[NEV];
   __shared__ double sh_scal[4];
   __shared__ double red[8][NEV];
@@ -475,6 +483,7 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
     }
     (void)tiny;
   }
+  if (MODE == 2) __threadfence();      // x lives in global memory: lanes read what other lanes wrote
   __syncthreads();
   // From here on only wave 0 works (lanes 0..7 solve, then all 64 lanes orthonormalise with wave
   // shuffles): no workgroup barrier inside the iteration loop.
@@ -533,6 +542,7 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
           }
         }
       }
+      if (MODE == 2) __threadfence();
       __builtin_amdgcn_wave_barrier();
       // modified Gram-Schmidt inside clusters + normalisation
       for (int j = 0; j < NEV; ++j) {
@@ -549,12 +559,14 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
         const double nrm = sqrt(nn);
         const double sc = nrm > 0.0 ? 1.0 / nrm : 0.0;
         for (int r = lane; r < n; r += 64) x[r * NEV + j] *= sc;
+        if (MODE == 2) __threadfence();                    // the next column's dot products read this one
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
-  for (int r = tid; r < n * NEV; r += 512) Z[r] = x[r];
+  if (MODE != 2)
+    for (int r = tid; r < n * NEV; r += 512) Z[r] = x[r];
   if (tid < NEV) lam_out[tid] = lam[tid];
 }
 
@@ -648,7 +660,7 @@ static int tridiag_graph(dmp_ctx* c, int n, double* A, TriRun* run, double* d, d
     void* params[8] = {(void*)&A, (void*)&crun, (void*)&idx_arg, (void*)&d, (void*)&e, (void*)&tau, (void*)&V,
                        (void*)&P};
     hipKernelNodeParams kp{};
-    kp.func = (void*)tridiag_step_kernel;
+    kp.func = n <= 1280 ? (void*)tridiag_step_kernel<5> : (void*)tridiag_step_kernel<8>;
     kp.gridDim = dim3(grid);
     kp.blockDim = dim3(256);
     kp.sharedMemBytes = (unsigned)(sizeof(double) * 4 * n);
@@ -668,14 +680,27 @@ static int tridiag_graph(dmp_ctx* c, int n, double* A, TriRun* run, double* d, d
   return DMP_OK;
 }
 
-// tri_eig_kernel keeps 11 n doubles in dynamic LDS: 112 640 bytes at the largest order (1280), above the
-// 64 KB a kernel may use without the opt-in.  Set once per device at context creation (see
-// trunk_kernel_attrs for why never between launches).
+// Dynamic LDS of tri_eig_kernel by order: see its MODE comment.
+static int tri_eig_mode(int n) { return n <= 384 ? 0 : (n <= 1280 ? 1 : 2); }
+static size_t tri_eig_lds_bytes(int n) {
+  const int mode = tri_eig_mode(n);
+  return sizeof(double) * (size_t)n * (mode == 0 ? 3 + 6 * NEV : (mode == 1 ? 3 + NEV : 3));
+}
+
+// Above the 64 KB a kernel may use without the opt-in: tri_eig_kernel (157 KB at order 384 in mode 0, 113 KB at 1280
+// in mode 1) and the step kernel of the large orders (4 n doubles = 64 KB at 2048).  Set once per device at context
+// creation (see trunk_kernel_attrs for why never between launches).
 int mds_kernel_attrs(dmp_ctx* c) {
   static bool done[64] = {};
   if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
-  DMP_HIP(hipFuncSetAttribute((const void*)tri_eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(double) * (3 + NEV) * 1280)));
+  DMP_HIP(hipFuncSetAttribute((const void*)tri_eig_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)tri_eig_lds_bytes(384)));
+  DMP_HIP(hipFuncSetAttribute((const void*)tri_eig_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)tri_eig_lds_bytes(1280)));
+  DMP_HIP(hipFuncSetAttribute((const void*)tri_eig_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)tri_eig_lds_bytes(DMP_MAX_L)));
+  DMP_HIP(hipFuncSetAttribute((const void*)tridiag_step_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double) * 4 * DMP_MAX_L)));
   if (c->device >= 0 && c->device < 64) done[c->device] = true;
   return DMP_OK;
 }
@@ -709,8 +734,12 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
     }
     DMP_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(512), sizeof(double) * (3 + NEV) * n, s, d, e, n,
-                     F, lam, Z);
+  static_assert(DMP_MAX_L <= 2048, "tridiag_step_kernel<8> / backtransform_kernel<32, 1> cover orders up to 2048");
+  switch (tri_eig_mode(n)) {
+    case 0: hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(512), tri_eig_lds_bytes(n), s, d, e, n, F, lam, Z); break;
+    case 1: hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(512), tri_eig_lds_bytes(n), s, d, e, n, F, lam, Z); break;
+    default: hipLaunchKernelGGL(tri_eig_kernel<2>, dim3(1), dim3(512), tri_eig_lds_bytes(n), s, d, e, n, F, lam, Z);
+  }
   DMP_LAUNCH_CHECK();
   if (n <= 320)
     hipLaunchKernelGGL((backtransform_kernel<5, 4>), dim3(1), dim3(512), 0, s, V, tau, lam, Z, n, d_mds);
@@ -718,7 +747,9 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
     hipLaunchKernelGGL((backtransform_kernel<10, 2>), dim3(1), dim3(512), 0, s, V, tau, lam, Z, n, d_mds);
   else if (n <= 1280)
     hipLaunchKernelGGL((backtransform_kernel<20, 1>), dim3(1), dim3(512), 0, s, V, tau, lam, Z, n, d_mds);
-  else { set_error("eigh_top8: order %d exceeds 1280", n); return DMP_ERR_CAPACITY; }
+  else if (n <= 2048)
+    hipLaunchKernelGGL((backtransform_kernel<32, 1>), dim3(1), dim3(512), 0, s, V, tau, lam, Z, n, d_mds);
+  else { set_error("eigh_top8: order %d exceeds %d", n, DMP_MAX_L); return DMP_ERR_CAPACITY; }
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

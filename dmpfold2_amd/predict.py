@@ -34,7 +34,7 @@ default_iterations = 10
 default_minsteps = 100
 
 MAX_SEQS = 3000     # predict.py:130-132
-MAX_L = 1280        # include/dmpfold_hip.h DMP_MAX_L (the reference has no limit)
+MAX_L = 2048        # include/dmpfold_hip.h DMP_MAX_L (the reference has no limit)
 
 _RESNAMES = {0: "ALA", 1: "ARG", 2: "ASN", 3: "ASP", 4: "CYS", 5: "GLN", 6: "GLU", 7: "GLY",
              8: "HIS", 9: "ILE", 10: "LEU", 11: "LYS", 12: "MET", 13: "PHE", 14: "PRO",

@@ -58,11 +58,13 @@ const char* dmp_last_error(void);
  * Allocates every device buffer the path needs for alignments up to max_N x max_L
  * (max_N is clamped to DMP_MAX_SEQS).  No allocation happens after this call.
  * DEVIATION from the reference, which has no length limit (network.py:218-221): 8 <= max_L <= DMP_MAX_L.
- * The eigensolver keeps 11 vectors of length L in one workgroup's LDS (112 KB at 1280) and its row kernels hold
- * 5 x 256 columns per thread block; dmp_ctx_create answers DMP_ERR_ARG ("max_L must be in [8, 1280]") for more,
- * and the Python front end raises RuntimeError naming the alignment's length before anything is computed.  The
- * largest configuration of BASELINE.json (L = 1000) needs 8.5 GB of the 288. */
-#define DMP_MAX_L 1280
+ * The eigensolver's kernels are instantiated per range of the order (<= 384: everything of the inverse iteration in
+ * one workgroup's LDS; <= 1280: the vectors in LDS; <= 2048: in global memory; 8 x 256 rows per thread block of the
+ * Householder step); every element count up to 442 L^2 and (21 L)^2 stays below 2^31 at 2048.  dmp_ctx_create answers
+ * DMP_ERR_ARG ("max_L must be in [8, 2048]") for more, and the Python front end raises RuntimeError naming the
+ * alignment's length before anything is computed.  The largest configuration of BASELINE.json (L = 1000) needs
+ * 8.5 GB of the 288; L = 2048 with 3000 rows about 60 GB. */
+#define DMP_MAX_L 2048
 int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out);
 void dmp_ctx_destroy(dmp_ctx* ctx);
 /* bytes of device memory held by the context */

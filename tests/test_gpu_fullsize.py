@@ -210,14 +210,16 @@ def test_embedding_is_folded_into_the_input_weights(synth_sd, oracle_weights):
 
 
 def test_eigensolver_at_the_largest_order(synth_sd):
-    """max_L = 1280: the bisection / inverse-iteration kernel keeps 11 n doubles in LDS (112 640 bytes,
-    needs the dynamic-LDS opt-in set at context creation).  A distance-geometry Gram matrix of a 3-D
-    random walk plus noise against the float64 solution."""
+    """max_L = DMP_MAX_L = 2048.  The eigensolver's kernels are instantiated per range of the order: up to 384 the
+    inverse iteration's vectors AND LU factors live in LDS (157 KB at 384), up to 1280 the vectors (112 640 bytes), above
+    that the vectors are in global memory (all need the dynamic-LDS opt-in set at context creation); the Householder
+    step holds 5 x 256 rows per thread block up to 1280 and 8 x 256 above.  Both sides of every boundary.  A
+    distance-geometry Gram matrix of a 3-D random walk plus noise against the float64 solution."""
     from abi import Stages
-    st = Stages(synth_sd, max_L=1280, max_N=4)
+    st = Stages(synth_sd, max_L=2048, max_N=4)
     try:
         rng = np.random.default_rng(17)
-        for L in (1280, 1000, 640, 513):      # 640 and 513: the cluster tridiagonalisation with its largest LDS image
+        for L in (2048, 1537, 1281, 1280, 1000, 640, 513, 385, 384, 300):
             P = np.cumsum(rng.standard_normal((L, 3)) * 2.2, axis=0)
             D = np.linalg.norm(P[:, None] - P[None], axis=2) + np.abs(rng.standard_normal((L, L))) * 0.3
             D = 0.5 * (D + D.T)

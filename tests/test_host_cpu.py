@@ -520,17 +520,17 @@ def test_bench_stub_world_8_over_gloo():
 
 
 def test_length_limit_is_reported_before_anything_runs(tmp_path):
-    """The reference has no length cap; this build's is DMP_MAX_L = 1280 (include/dmpfold_hip.h): the drop-in raises
+    """The reference has no length cap; this build's is DMP_MAX_L = 2048 (include/dmpfold_hip.h): the drop-in raises
     RuntimeError naming the length before touching the device, and dmp_ctx_create refuses the size."""
     import ctypes as C
     from dmpfold2_amd import _lib, predict
-    assert predict.MAX_L == 1280
-    with pytest.raises(RuntimeError, match="1281 columns"):
-        predict.get_engine("cuda:0", 1281, 4, state_dict={})
+    assert predict.MAX_L == 2048
+    with pytest.raises(RuntimeError, match="2049 columns"):
+        predict.get_engine("cuda:0", 2049, 4, state_dict={})
     lib = _lib.load()
     ctx = C.c_void_p()
-    assert lib.dmp_ctx_create(0, 1281, 4, C.byref(ctx)) != 0
-    assert b"1280" in lib.dmp_last_error()
+    assert lib.dmp_ctx_create(0, 2049, 4, C.byref(ctx)) != 0
+    assert b"2048" in lib.dmp_last_error()
 
 
 _QUEUE_WORKER = r"""
