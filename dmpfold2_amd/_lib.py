@@ -52,6 +52,8 @@ SIGNATURES = {
     "dmp_predict_end": (_i, [_vp, _fp, _fp, _vp]),
     "dmp_predict_next_unit": (_i, [_vp]),
     "dmp_predict_group_vgru": (_i, [C.POINTER(_vp), _i]),
+    "dmp_predict_group_riders": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
+    "dmp_predict_chain_issued": (_i, [_vp]),
     "dmp_predict_detach_group_chain": (_i, [_vp]),
     "dmp_predict_issue_group_chain": (_i, [_vp, _vp]),
     "dmp_predict_chain_on_own_stream": (_i, [_vp]),

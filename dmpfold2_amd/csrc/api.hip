@@ -399,8 +399,9 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   c->max_N = max_N;
   c->max_passes = 128;
   const int64_t L = max_L, N = max_N, D = NS * L, LL = L * L;
-  // vertical-GRU state: the members of a group side by side (up to 4 alignments of max_L columns, 32-column tiles)
-  c->vg_cap_cols = 4 * round_up(max_L, 64);
+  // vertical-GRU state: the members and riders of a group side by side (up to 8 alignments of max_L columns,
+  // 32-column tiles)
+  c->vg_cap_cols = 8 * round_up(max_L, 64);
   const int64_t Lb = c->vg_cap_cols, P = act_pitch(max_L), T = act_tiles(max_L);
   int rc = 0;
 #define A_(field, count) if (!rc) rc = dev_alloc(c->allocs, c->bytes, &c->field, (count))
@@ -849,18 +850,26 @@ static bool side_stream_enabled() {
 static bool vg_done(const dmp_ctx* lead) { return __atomic_load_n(&lead->vg_done_issued, __ATOMIC_ACQUIRE); }
 
 static int issue_group_chain(dmp_ctx* c, int j, hipStream_t s) {
-  const int n = (int)c->vg_members.size();
+  const int n = (int)c->vg_members.size(), nr = (int)c->vg_riders.size();
   int rc = DMP_OK;
   if (j == 0) {
     const uint8_t* msas[8];
+    dmp_ctx* owners[8];
     int Ns[8], Ls[8];
-    for (int i = 0; i < n; ++i) { msas[i] = c->vg_members[i]->run_msa; Ns[i] = c->vg_members[i]->last_N; Ls[i] = c->vg_members[i]->last_L; }
-    rc = vgru_group_setup(c, c->vg_members.data(), msas, Ns, Ls, n, s);
+    for (int i = 0; i < n; ++i) {
+      owners[i] = c->vg_members[i];
+      msas[i] = c->vg_members[i]->run_msa; Ns[i] = c->vg_members[i]->last_N; Ls[i] = c->vg_members[i]->last_L;
+    }
+    for (int i = 0; i < nr; ++i) {           // riders: state in the leader's buffers like the members', no context
+      owners[n + i] = c;
+      msas[n + i] = c->vg_riders[i].msa; Ns[n + i] = c->vg_riders[i].N; Ls[n + i] = c->vg_riders[i].L;
+    }
+    rc = vgru_group_setup(c, owners, msas, Ns, Ls, n + nr, s);
   }
   // a real group's chain is ONE unit (every member waits for its end, and nothing else wants this stream
   // meanwhile): chunked, the chain stood still for 2-3 ms between chunks whenever the scheduler thread was busy
   // issuing the members' inverse units (kernel trace: 40 ms of a 97 ms front-end phase)
-  const bool whole = n > 1;
+  const bool whole = n + nr > 1;
   const int chunks = whole ? 1 : cdiv(c->vg_maxN + 1, FE_VGRU_STEPS);
   if (!rc) rc = whole ? vgru_group_steps(c, 0, c->vg_maxN + 1, s)
                       : vgru_group_steps(c, j * FE_VGRU_STEPS, (j + 1) * FE_VGRU_STEPS, s);
@@ -869,6 +878,8 @@ static int issue_group_chain(dmp_ctx* c, int j, hipStream_t s) {
       dmp_ctx* m = c->vg_members[i];
       rc = vgru_group_output(c, i, m->last_N, m->last_L, m->vout, s);
     }
+    for (int i = 0; !rc && i < nr; ++i)
+      rc = vgru_group_output(c, n + i, c->vg_riders[i].N, c->vg_riders[i].L, c->vg_riders[i].out, s);
     if (!rc) {
       DMP_HIP(hipEventRecord((hipEvent_t)c->vg_done_ev, s));
       __atomic_store_n(&c->vg_done_issued, true, __ATOMIC_RELEASE);
@@ -970,6 +981,7 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   DMP_ARG(c->vg_leader == nullptr || c->vg_leader == c, "this context still waits for the vertical GRU of its group");
   c->vg_leader = nullptr;
   c->vg_members.clear();
+  c->vg_riders.clear();
   c->vg_done_issued = false;
   c->vg_detached = 0;
   c->ext_vout = nullptr;
@@ -1079,6 +1091,39 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n) {
     c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
   }
   return DMP_OK;
+}
+
+int dmp_predict_group_riders(dmp_ctx* lead, int n, const uint8_t* const* d_msas, const int* Ns, const int* Ls,
+                             float* const* d_outs) {
+  DMP_ARG(lead && d_msas && Ns && Ls && d_outs && n >= 1, "bad argument");
+  DMP_ARG(lead->vg_leader == lead && lead->fe_next == 0 && !lead->vg_detached && lead->vg_riders.empty(),
+          "add riders right after dmp_predict_group_vgru, once, before the leader issues a unit or its chain is detached");
+  DMP_ARG((int)lead->vg_members.size() + n <= 8, "a chain serves at most 8 alignments (%d members + %d riders)",
+          (int)lead->vg_members.size(), n);
+  int cols = 0, maxN = 0;
+  for (dmp_ctx* m : lead->vg_members) { cols += round_up(m->last_L, 32); maxN = std::max(maxN, m->last_N); }
+  for (int i = 0; i < n; ++i) {
+    DMP_ARG(d_msas[i] && d_outs[i] && Ns[i] >= 1 && Ls[i] >= 8, "bad argument for rider %d", i);
+    if (Ls[i] > lead->max_L || Ns[i] > lead->max_N) {
+      set_error("rider %d: alignment %d x %d exceeds the context capacity %d x %d", i, Ns[i], Ls[i], lead->max_N, lead->max_L);
+      return DMP_ERR_CAPACITY;
+    }
+    cols += round_up(Ls[i], 32);
+    maxN = std::max(maxN, Ns[i]);
+  }
+  if (cols > lead->vg_cap_cols) {
+    set_error("the chain's %d alignment columns exceed the leader's capacity %d", cols, lead->vg_cap_cols);
+    return DMP_ERR_CAPACITY;
+  }
+  for (int i = 0; i < n; ++i) lead->vg_riders.push_back({d_msas[i], Ns[i], Ls[i], d_outs[i]});
+  // with riders even a group of one runs its chain as one unit (issue_group_chain)
+  lead->fe_vgru = 1;
+  lead->fe_total = 1 + lead->fe_inv + lead->fe_vgru + 1;
+  return DMP_OK;
+}
+
+int dmp_predict_chain_issued(const dmp_ctx* ctx) {
+  return ctx && ctx->vg_leader == ctx && vg_done(ctx) ? 1 : 0;
 }
 
 int dmp_predict_detach_group_chain(dmp_ctx* lead) {

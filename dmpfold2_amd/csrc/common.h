@@ -146,6 +146,8 @@ struct dmp_ctx {
   // dmp_predict_group_vgru: the vertical GRUs of several predictions in flight as one launch chain
   dmp_ctx* vg_leader = nullptr;            // the context whose units run the chain (itself for the leader; null: no group)
   std::vector<dmp_ctx*> vg_members;        // leader: the members, itself first
+  struct VgRider { const uint8_t* msa; int N, L; float* out; };
+  std::vector<VgRider> vg_riders;          // leader: alignments of LATER predictions whose vertical GRU rides in this chain
   int vg_index = 0;                        // this context's index among its leader's members
   bool vg_done_issued = false;             // leader: the chain's last unit (and the members' outputs) has been enqueued
                                            // (written by the thread that issues a detached chain: atomic accesses)

@@ -434,6 +434,14 @@ class Pipeline:
         # starts together with them, up to DMP_VGRU_GROUP members (1 = every prediction runs its own chain).
         self._group_max = max(1, min(4, int(os.environ.get("DMP_VGRU_GROUP", "4"))))   # state buffers hold 4 x max_L columns
         self._group_patience = int(os.environ.get("DMP_GROUP_PATIENCE", "40"))
+        # Riders: a group's chain also serves the NEXT targets in the queue (dmp_predict_group_riders; members + riders
+        # <= 8), whose results are handed over when those targets start (dmp_predict_set_vgru_result): a chain costs
+        # 10.5 us per alignment row whatever it serves (launch boundary, cold L2s), so one chain of eight every second
+        # round replaces two chains of four.  The chain still runs in a front-end phase - beside no convolution.
+        # DMP_VGRU_RIDERS=0 switches it off.
+        self._riders_max = max(0, min(7, int(os.environ.get("DMP_VGRU_RIDERS", "4")))) if S > 1 else 0
+        self._riding = {}             # ticket -> True: a rider whose chain has not been issued to its end yet
+        self._rider_wait = [None] * S  # per leading engine: (jobs, outs) of the riders in the chain it has yet to issue
         # Look-ahead: the chain of the NEXT group touches none of the buffers the trunk passes use, so it is run
         # beside the last DMP_VGRU_LOOKAHEAD residual blocks of the predictions in flight (on its own stream, in the
         # state buffers of a context that predicts nothing itself) and handed to the engines when they start those
@@ -633,6 +641,25 @@ class Pipeline:
                         x.record_stream(lead._stream)
             ctxs = (C.c_void_p * len(slots))(*[self.engines[s].ctx for s in slots])
             _lib.check(self.lib.dmp_predict_group_vgru(ctxs, len(slots)))
+            if self._riders_max and not self._detach and self._fe is None and not self._features_ahead:
+                room = min(self._riders_max, 8 - len(slots))
+                jobs = [j for j in self._pending[:room] if j[0] not in self._ahead and j[0] not in self._riding]
+                if jobs:
+                    k = len(jobs)
+                    with torch.cuda.device(self.device):
+                        outs = [torch.empty((j[1].shape[1], 512), dtype=torch.float32, device=self.device) for j in jobs]
+                    for j, o in zip(jobs, outs):
+                        lead._stream.wait_event(j[5])             # the rider's alignment is ready
+                        j[1].record_stream(lead._stream)
+                        o.record_stream(lead._stream)
+                    mp = (C.c_void_p * k)(*[j[1].data_ptr() for j in jobs])
+                    op = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
+                    Ns = (C.c_int * k)(*[j[1].shape[0] for j in jobs])
+                    Ls = (C.c_int * k)(*[j[1].shape[1] for j in jobs])
+                    _lib.check(self.lib.dmp_predict_group_riders(lead.ctx, k, mp, Ns, Ls, op))
+                    self._rider_wait[slots[0]] = (jobs, outs)
+                    for j in jobs:
+                        self._riding[j[0]] = True
             if self._detach:
                 cs = lead._stream if self._detach_own else self._chain_stream
                 cs.wait_stream(torch.cuda.current_stream(self.device))
@@ -695,6 +722,8 @@ class Pipeline:
         with_job = [r for r in free if self._reserved[r] is not None]
         without = [r for r in free if self._reserved[r] is None][:len(self._pending)]
         startable = with_job + without
+        if self._riding and any(j[0] in self._riding for j in self._pending[:len(without)]):
+            startable = []            # the chain these targets ride in has not been issued to its end yet
         if startable and self._ahead_ready():
             # engines about to finish: wait for them and start together (one vertical-GRU chain for the group)
             soon = [r for r in range(len(self.engines)) if self._slot[r] is not None
@@ -777,6 +806,15 @@ class Pipeline:
                 else:
                     _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
                 progressed = True
+                if self._rider_wait[s] is not None and lib.dmp_predict_chain_issued(e.ctx):
+                    # the riders' results are behind this point of the leader's stream
+                    jobs, outs = self._rider_wait[s]
+                    self._rider_wait[s] = None
+                    ev = torch.cuda.Event()
+                    ev.record(e._stream)
+                    for j, o in zip(jobs, outs):
+                        self._ahead[j[0]] = (o, ev)
+                        self._riding.pop(j[0], None)
                 if kind == 2:
                     self._done[s] += 1
                 if gated:

@@ -258,6 +258,17 @@ int dmp_predict_ahead_issue(dmp_ctx* ctx, void* stream);
  * until that unit has been issued.  Results are bit-identical to ungrouped predictions.  The members must hold
  * the same weights; the leader cannot begin another prediction before every member has issued that unit. */
 int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n);
+/* Riders: the vertical GRUs of n alignments that are NOT being predicted yet (the scheduler's next targets) are
+ * computed in the same launch chain as the group led by `lead` (members + riders <= 8; the chain's fixed cost per
+ * alignment row - launch boundary, cold L2s - is shared by twice as many columns), their results (L_i x 512 each)
+ * written to d_outs[i].  Call once, right after dmp_predict_group_vgru (a group of one is allowed), before the
+ * leader issues a unit; not combinable with dmp_predict_detach_group_chain.  dmp_predict_chain_issued(lead) answers
+ * 1 once the chain has been enqueued to its end on the stream of the leader's units: an event recorded on that
+ * stream from then on is behind the riders' results, which go to their predictions through
+ * dmp_predict_set_vgru_result.  Every result is bit-identical to the alignment's own chain. */
+int dmp_predict_group_riders(dmp_ctx* lead, int n, const uint8_t* const* d_msas, const int* Ns, const int* Ls,
+                             float* const* d_outs);
+int dmp_predict_chain_issued(const dmp_ctx* ctx);
 /* Take the chain of a group of two or more out of the leader's units (call right after dmp_predict_group_vgru,
  * before the leader issues a unit): the leader then has no vertical-GRU units either, and the whole chain - group
  * record, every alignment row, the members' results, the event - is enqueued by ONE call of

@@ -458,35 +458,57 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
     pipe.close()
 
 
-@pytest.mark.parametrize("group,lookahead,detach,ahead", [(1, 0, 1, 1), (2, 0, 1, 1), (4, 0, 1, 0), (4, 0, 0, 1),
-                                                          (4, 0, 0, 0), (2, 0, 0, 1), (4, 24, 1, 1), (3, 400, 0, 1),
-                                                          (4, 0, 2, 0), (3, 0, 2, 1)])
+@pytest.mark.parametrize("group,lookahead,detach,ahead,riders",
+                         [(1, 0, 1, 1, 4), (2, 0, 1, 1, 4), (4, 0, 1, 0, 4), (4, 0, 0, 1, 4), (4, 0, 0, 0, 4),
+                          (2, 0, 0, 1, 4), (4, 24, 1, 1, 4), (3, 400, 0, 1, 4), (4, 0, 2, 0, 4), (3, 0, 2, 1, 4),
+                          (4, 0, 0, 0, 0), (2, 0, 0, 0, 6), (3, 0, 0, 0, 2), (4, 0, 0, 0, 7)])
 def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead, detach,
-                                                            ahead):
+                                                            ahead, riders):
     """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE launch chain
     (group leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so
     groups of every size up to `group` form.  detach = 1: the chain is issued by a helper thread on
     its own stream - or, detach = 2, on the leader's stream - (dmp_predict_detach_group_chain /
     dmp_predict_issue_group_chain / dmp_predict_chain_on_own_stream) while the scheduler's thread
     issues the members' other front-end units.  With a look-ahead the chains of the next group run beside the
-    predictions in flight and are handed over (dmp_predict_set_vgru_result).  Every result equals the single
-    engine's, bit for bit."""
+    predictions in flight and are handed over (dmp_predict_set_vgru_result).  riders: a group's chain also serves
+    up to that many of the NEXT targets in the queue (dmp_predict_group_riders; members + riders <= 8; the default of
+    the scheduler when the chain is neither detached nor run ahead), handed over the same way.  Every result equals
+    the single engine's, bit for bit."""
     from dmpfold2_amd import synth
     from dmpfold2_amd.predict import Pipeline, encode_aln
     monkeypatch.setenv("DMP_VGRU_GROUP", str(group))
     monkeypatch.setenv("DMP_VGRU_LOOKAHEAD", str(lookahead))
     monkeypatch.setenv("DMP_VGRU_DETACH", str(detach))
     monkeypatch.setenv("DMP_FEATURES_AHEAD", str(ahead))       # features of an engine's next target computed ahead
+    monkeypatch.setenv("DMP_VGRU_RIDERS", str(riders))
     shapes = [(82, 200), (33, 64), (128, 300), (40, 1), (64, 257), (96, 31), (120, 129), (50, 64), (128, 17)]
     msas = [encode_aln(synth.synth_msa(L, N, 40 + i)) for i, (L, N) in enumerate(shapes)]
     dev = torch.device("cuda:0")
     pipe = Pipeline(dev, 128, 512, synth_sd, streams=4)
     assert pipe._group_max == group and (pipe._fe is not None) == (lookahead > 0)
     assert pipe._detach == bool(detach and group > 1) and pipe._features_ahead == bool(ahead)
+    assert pipe._riders_max == riders
+    rode = []
+    if riders and not detach and not lookahead and not ahead and group > 1:
+        pipe_lib = pipe.lib                               # count the chains that carried riders
+
+        class Counting:
+            def __getattr__(self, name):
+                fn = getattr(pipe_lib, name)
+                if name != "dmp_predict_group_riders":
+                    return fn
+
+                def counted(*a):
+                    rode.append(a[1])
+                    return fn(*a)
+                return counted
+        pipe.lib = Counting()
     msas = msas + msas[:5]                       # more targets than engines: reservations and ahead units happen
     tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 3) for m in msas]
     pipe.drain()
     pipe.sync_check()
+    if riders and not detach and not lookahead and not ahead and group > 1:
+        assert rode and max(rode) == min(riders, 8 - group) and not pipe._riding and not pipe._ahead
     for m, t in zip(msas, tickets):
         coords, confs = pipe.result(t)
         ref_c, ref_f = st_engine.eng.predict(m, None, 1, 3)
