@@ -431,9 +431,9 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(seq_b, L * WIDTH);
   A_(emb, L * (WIDTH + 8));
   A_(mat1d, L * WIDTH);
-  A_(seq_hx, 2 * 2 * HID2);
+  A_(seq_hx, 2 * 2 * HID2 + 4);
   A_(seq_abort, 2);      // [0] fault word of the prediction in flight, [1] faults latched by finished ones
-  A_(refine_gx, 2 * 3 * L);
+  A_(refine_gx, 2 * 3 * L + 2);
   A_(z0, (int64_t)STEM_OUT * LL);
   A_(planes, (int64_t)(NS * NS + 1) * LL);
   A_(dmap, LL);
@@ -463,6 +463,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   if (hipMemset(c->seq_abort, 0, 2 * sizeof(int)) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
   if ((rc = trunk_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
   if ((rc = mds_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
+  if ((rc = gj_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
   if ((rc = vgru_kernel_attrs(c))) { dmp_ctx_destroy(c); return rc; }
   for (int i = 0; i < 2; ++i) {
     hipEvent_t e;
@@ -493,6 +494,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "tridiag_single") { ctx->tridiag_single = value ? 1 : 0; return DMP_OK; }
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_legacy") { ctx->vgru_legacy = value ? 1 : 0; return DMP_OK; }
+  if (k == "gj_lds") { DMP_ARG(value >= 0 && value <= 2, "gj_lds must be 0, 1 or 2"); ctx->gj_lds = value; return DMP_OK; }
   if (k == "conv_mode") {
     DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
     ctx->conv_mode = value;
@@ -510,6 +512,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "tridiag_single") { *h_value = ctx->tridiag_single; return DMP_OK; }
   if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
   if (k == "vgru_legacy") { *h_value = ctx->vgru_legacy; return DMP_OK; }
+  if (k == "gj_lds") { *h_value = ctx->gj_lds; return DMP_OK; }
   set_error("unknown option %s", name);
   return DMP_ERR_ARG;
 }

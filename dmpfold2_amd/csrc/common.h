@@ -161,15 +161,16 @@ struct dmp_ctx {
   std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain
   int tridiag_single = 0;                  // option: 1 = single-workgroup tridiagonalisation
   int refine_single = 0;                   // option: 1 = single-workgroup minimiser
+  int gj_lds = 0;                          // option: trailing update of the inverse: 0 = operands from L2, 1 = panels staged in LDS, 2 = + tile fetched first
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions
   float* seq_a = nullptr;   // [L][512]
   float* seq_b = nullptr;   // [L][512]
   float* emb = nullptr;     // [L][520]
   float* mat1d = nullptr;   // [512][L]
-  unsigned long long* seq_hx = nullptr;  // [2][2][256] hand-off granules of the sequence GRU
+  unsigned long long* seq_hx = nullptr;  // [2][2][256] hand-off granules of the sequence GRU + [2 dir][2] placement header
   int* seq_abort = nullptr;              // [2] DMP_FAULT_* bits: [0] of the prediction in flight, [1] latched by finished ones
-  unsigned long long* refine_gx = nullptr;  // [2][3 max_L] hand-off granules of the minimiser cluster
+  unsigned long long* refine_gx = nullptr;  // [2][3 max_L] hand-off granules of the minimiser cluster + [2] placement header
   int refine_xcd = 0;                    // XCD the minimiser cluster of this context runs on
   // pair trunk
   float* z0 = nullptr;      // [384][L][L]
@@ -282,7 +283,39 @@ int act_unpad(const float* d_xpad, int L, float* d_dense, hipStream_t s);
 int act_clear(float* d_xpad, int L, hipStream_t s);
 int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s);
 // mds.hip
+// ---- hand-off between the workgroups of a cluster kernel (seq_gru_kernel, refine_cluster_kernel) -------------------
+// Granules {epoch, value} are published with a store and gathered with sc1 loads (agent scope: past the L1, served by
+// the L2).  An agent-scope STORE is written through to the memory side so that every XCD can see it: measured
+// (tools/ubench_handoff.hip) 450 ns one way, and 2.78 us per step of the sequence GRU with 256 granules per step.  A
+// PLAIN store stops in the L2 of the XCD its workgroup runs on, where the sc1 loads of workgroups on THAT XCD find it:
+// 284 ns one way, 1.29 us per step, the same bits - and never seen from another XCD.  The block id -> XCD round robin
+// puts a cluster on one XCD, but nothing guarantees it, so the cluster checks where it actually runs: every workgroup
+// ORs the bit of its XCC id (hardware register) into a mask word and counts itself in (agent-scope atomics, zeroed
+// by the host before the launch); when all `members` have arrived, a mask with one bit set means plain stores are safe.
+// Returns true for "one XCD" (call from one thread per workgroup; bounded wait: false on a timeout, the slow path
+// then still works wherever the members run).
+__device__ __forceinline__ bool cluster_on_one_xcd(unsigned long long* hdr, int members) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  __hip_atomic_fetch_or(&hdr[0], 1ull << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(&hdr[1], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned spins = 0; spins < 2000000u; ++spins) {
+    if (__hip_atomic_load(&hdr[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)members) {
+      const unsigned long long mask = __hip_atomic_load(&hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return (mask & (mask - 1)) == 0;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+// publication of a granule: `local` = cluster_on_one_xcd
+__device__ __forceinline__ void cluster_publish(unsigned long long* p, unsigned long long v, bool local) {
+  if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 int mds_kernel_attrs(dmp_ctx* c);     // once per device, at context creation
+int gj_kernel_attrs(dmp_ctx* c);      // ditto (dca.hip)
 int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s);
 // coords.hip
 int coord_fc(dmp_ctx* c, const float* d_g, int L, float* d_ca, hipStream_t s);

@@ -215,7 +215,7 @@ typedef unsigned long long u64;
 struct RefineArgs {
   float* ca;
   int L, steps, xcd;
-  u64* gx;             // [2][3L] granules, zeroed before the launch
+  u64* gx;             // [2][3L] granules + [2] placement header, zeroed before the launch
   int* abort_flag;     // bit 2 is set if a hand-off ever times out
 };
 
@@ -240,8 +240,14 @@ __global__ __launch_bounds__(RF_THREADS) void refine_cluster_kernel(RefineArgs a
   float* cur = sm;
   float* part = sm + 3 * L;
   for (int i = tid; i < 3 * L; i += RF_THREADS) cur[i] = a.ca[i];
-  if (tid == 0) sh_abort = 0;
+  __shared__ int sh_local;
+  if (tid == 0) {
+    sh_abort = 0;
+    // the workgroups that own residues: all on one XCD (common.h)?  Then plain stores publish the granules
+    sh_local = cluster_on_one_xcd(a.gx + (int64_t)2 * 3 * L, (L + Lg - 1) / Lg) ? 1 : 0;
+  }
   __syncthreads();
+  const bool local = sh_local != 0;
   for (int step = 0; step < a.steps; ++step) {
     const unsigned epoch = (unsigned)step + 1u;
     u64* gx = a.gx + (int64_t)(step & 1) * 3 * L;
@@ -294,9 +300,9 @@ __global__ __launch_bounds__(RF_THREADS) void refine_cluster_kernel(RefineArgs a
       const float ny = yj + fminf(fmaxf(ay, -100.0f), 100.0f) * 0.001f;
       const float nz = zj + fminf(fmaxf(az, -100.0f), 100.0f) * 0.001f;
       const u64 tag = (u64)epoch << 32;
-      __hip_atomic_store(&gx[3 * j], tag | (u64)__float_as_uint(nx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&gx[3 * j + 1], tag | (u64)__float_as_uint(ny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&gx[3 * j + 2], tag | (u64)__float_as_uint(nz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cluster_publish(&gx[3 * j], tag | (u64)__float_as_uint(nx), local);
+      cluster_publish(&gx[3 * j + 1], tag | (u64)__float_as_uint(ny), local);
+      cluster_publish(&gx[3 * j + 2], tag | (u64)__float_as_uint(nz), local);
     }
     __syncthreads();                     // every thread has read the old coordinates
     for (int i = tid; i < 3 * L; i += RF_THREADS) {
@@ -330,7 +336,7 @@ int refine_coords(dmp_ctx* c, float* d_ca, int L, int steps, hipStream_t s) {
   a.gx = (u64*)c->refine_gx;
   a.abort_flag = c->seq_abort;
   const int Lg = (L + RF_G - 1) / RF_G;
-  DMP_HIP(hipMemsetAsync(c->refine_gx, 0, sizeof(u64) * 2 * 3 * L, s));
+  DMP_HIP(hipMemsetAsync(c->refine_gx, 0, sizeof(u64) * (2 * 3 * L + 2), s));
   hipLaunchKernelGGL(refine_cluster_kernel, dim3(8 * RF_G), dim3(RF_THREADS),
                      sizeof(float) * (3 * L + 3 * refine_slices(L) * Lg), s, a);
   DMP_LAUNCH_CHECK();

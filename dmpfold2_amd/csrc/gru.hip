@@ -21,19 +21,23 @@ __device__ __forceinline__ float tanhf_(float x) {
 // for the whole sequence.  Per time step a workgroup computes its 32 new state values,
 // publishes them as 8-byte {epoch, value} granules (one agent-scope store each, the data is
 // the flag) and gathers the other 224 by sweeping the granule array until every tag equals
-// the step's epoch.  The protocol does not depend on where the workgroups run; putting the
-// 8 workgroups of a direction on one XCD (block id % 8) only shortens the hand-off.
+// the step's epoch.  The protocol does not depend on where the workgroups run; the 8 workgroups of a
+// direction are put on one XCD (block id % 8), and when they find themselves there (cluster_on_one_xcd,
+// common.h) they publish with plain stores that stop in that XCD's L2: 1.29 instead of 2.78 us per step.
 // Every wave gathers the state for itself into its own LDS copy (LDS operations of one wave execute in
 // order): no workgroup barrier anywhere in the step loop.
 constexpr int SEQ_G = 8;
 typedef unsigned long long u64;
+#ifndef SEQ_SHFL
+#define SEQ_SHFL 0
+#endif
 
 struct SeqArgs {
   const float* G;        // [T][1536] input projections incl. b_ih (fwd | rev)
   const float* whh[2];   // [768][256]
   const float* bhh[2];   // [768]
   float* out;            // [T][512]
-  u64* hx;               // [2 dir][2 parity][256] granules, zeroed before every launch
+  u64* hx;               // [2 dir][2 parity][256] granules + [2 dir][2] placement header, zeroed before every launch
   int* abort_flag;       // set if a hand-off ever times out
   int T;
 };
@@ -41,6 +45,7 @@ struct SeqArgs {
 // grid: 8 * SEQ_G blocks (only ids with id % 8 < 2 work: direction = id % 8)   block: 256
 __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
   __shared__ __attribute__((aligned(16))) float hs[4][HID2];
+  __shared__ int sh_local;
   const int dir = blockIdx.x & 7, g = blockIdx.x >> 3;
   if (dir >= 2) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,6 +71,10 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
   float* h = hs[wave];
 #pragma unroll
   for (int q = 0; q < 4; ++q) h[lane + 64 * q] = 0.f;
+  // do the SEQ_G workgroups of this direction share an XCD (common.h)?  Then granules are published with plain stores
+  if (tid == 0) sh_local = cluster_on_one_xcd(a.hx + 4 * HID2 + 2 * dir, SEQ_G) ? 1 : 0;
+  __syncthreads();
+  const bool local = sh_local != 0;
   u64* hx_dir = a.hx + (int64_t)dir * 2 * HID2;
   float gin[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   auto load_gi = [&](int step) {
@@ -77,6 +86,14 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
     }
   };
   load_gi(0);
+#ifdef SEQ_PROFILE
+  long long pt[5] = {0, 0, 0, 0, 0};
+  unsigned pspins = 0;
+#define SEQ_T(i) { const long long now = clock64(); pt[i] += now - plast; plast = now; }
+  long long plast = clock64();
+#else
+#define SEQ_T(i)
+#endif
   for (int step = 0; step < a.T; ++step) {
     const int t = dir ? (a.T - 1 - step) : step;
     const unsigned epoch = (unsigned)step + 1u;
@@ -94,6 +111,7 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
       hv[q * 4 + 0] = v.x; hv[q * 4 + 1] = v.y; hv[q * 4 + 2] = v.z; hv[q * 4 + 3] = v.w;
     }
     const float hp0 = h[u0], hp1 = h[u0 + 1];
+    SEQ_T(0)
     float acc[3][2];
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate)
@@ -104,12 +122,25 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
         for (int q = 0; q < 16; ++q) sacc = fmaf(wreg[gate][uu][q], hv[q], sacc);
         acc[gate][uu] = sacc;
       }
+    // sum over the 16 lanes of a row: the xor butterfly 8, 4, 2, 1 - as DPP row rotations (after the xor-8 step lanes
+    // i and i ^ 8 agree, so "lane i + 4 mod 16" holds what lane i ^ 4 holds, and so on down: same operands, same sums
+    // as __shfl_xor, without four dependent ds_bpermute round trips through the LDS pipeline per step)
+#if SEQ_SHFL
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1)
 #pragma unroll
       for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
         for (int uu = 0; uu < 2; ++uu) acc[gate][uu] += __shfl_xor(acc[gate][uu], off, 16);
+#else
+#define SEQ_ROR(n)                                                                                                   \
+    _Pragma("unroll") for (int gate = 0; gate < 3; ++gate) _Pragma("unroll") for (int uu = 0; uu < 2; ++uu)          \
+        acc[gate][uu] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[gate][uu]), \
+                                                                              0x120 + (n), 0xf, 0xf, false));
+    SEQ_ROR(8) SEQ_ROR(4) SEQ_ROR(2) SEQ_ROR(1)
+#undef SEQ_ROR
+#endif
+    SEQ_T(1)
     if (kg == 0) {
 #pragma unroll
       for (int uu = 0; uu < 2; ++uu) {
@@ -119,11 +150,11 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
         const float hp = uu ? hp1 : hp0;
         const float hn = (hp - ng) * zg + ng;
         a.out[(int64_t)t * 512 + dir * HID2 + u0 + uu] = hn;
-        __hip_atomic_store(&hx[u0 + uu], ((u64)epoch << 32) | (u64)__float_as_uint(hn),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_publish(&hx[u0 + uu], ((u64)epoch << 32) | (u64)__float_as_uint(hn), local);
       }
     }
     load_gi(step + 1);               // next step's input projections fly while this step's granules are gathered
+    SEQ_T(2)
     {
       // sweep the 256 granules of this step (4 per lane) until all carry this epoch
       unsigned vals[4];
@@ -137,6 +168,9 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
           ok = ok && ((unsigned)(x >> 32) == epoch);
         }
         if (__all(ok)) break;
+#ifdef SEQ_PROFILE
+        ++pspins;
+#endif
         if (spins > 2000000u) { dead = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -148,8 +182,14 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) h[lane + 64 * q] = __uint_as_float(vals[q]);
       __builtin_amdgcn_wave_barrier();
+      SEQ_T(3)
     }
   }
+#ifdef SEQ_PROFILE
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 57))
+    printf("seq_gru block %d T=%d cycles per step: read h %lld, matvec+reduce %lld, gates+publish %lld, gather %lld; failed sweeps per step %.2f\n",
+           (int)blockIdx.x, a.T, pt[0] / a.T, pt[1] / a.T, pt[2] / a.T, pt[3] / a.T, (double)pspins / a.T);
+#endif
 }
 
 int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hipStream_t s) {
@@ -176,7 +216,7 @@ int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hip
     a.out = out; a.T = T;
     a.hx = (u64*)c->seq_hx;
     a.abort_flag = c->seq_abort;
-    DMP_HIP(hipMemsetAsync(c->seq_hx, 0, sizeof(u64) * 2 * 2 * HID2, s));
+    DMP_HIP(hipMemsetAsync(c->seq_hx, 0, sizeof(u64) * (2 * 2 * HID2 + 4), s));
     hipLaunchKernelGGL(seq_gru_kernel, dim3(8 * SEQ_G), dim3(256), 0, s, a);
     DMP_LAUNCH_CHECK();
     in = out;

@@ -142,10 +142,11 @@ def eig_precision_floor(cap, weights):
 
 def capture_case(name, aln_rows, n, m, wfile, wsum, template=None, sign="canonical",
                  stages=True, report=None, with_cli=False, extra=None, store_aln=True,
-                 noise_threads=1):
+                 noise_threads=1, oracle=True):
     """`store_aln=False` keeps only a SHA-256 of the residue codes (large synthetic alignments are
     regenerated from their seed by the tests); `noise_threads` is the thread count of the second
-    oracle run that measures the noise floor (1 is unaffordable at the north-star size)."""
+    oracle run that measures the noise floor (1 is unaffordable at the north-star size); `oracle=False` stores the
+    reference's outputs only (a case where one CPU run takes half an hour: the oracle is pinned by all the others)."""
     aln_path = os.path.join("/tmp", f"golden_{name}.aln")
     synth.write_aln(aln_path, aln_rows)
     coords, confs, alnmat, tap = run_reference(aln_path, wfile, n, m, template, sign)
@@ -197,6 +198,14 @@ def capture_case(name, aln_rows, n, m, wfile, wsum, template=None, sign="canonic
     # `noise_threads` (an int or a tuple; the floor is the LARGEST deviation - two runs alone
     # underestimate the spread of a sensitive case)
     counts = tuple(noise_threads) if isinstance(noise_threads, (tuple, list)) else (noise_threads,)
+    if not oracle:
+        line = (f"{name:24s} L={L:4d} N={alnmat.shape[0]:5d} n={n:3d} m={m:4d} sign={sign:9s} "
+                f"passes={npass:3d} reference only (no oracle run at this size)")
+        print(line, flush=True)
+        if report is not None:
+            report.append(line)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        return
     oc, of, oa, cap8 = run_oracle(aln_path, wfile, n, m, template, sign, 8)
     dev = rmsd(oc[:, 1], coords[:, 1])
     devc = float((of - confs).abs().max())
@@ -417,6 +426,17 @@ def main():
         capture_case(name, synth.synth_msa(1000, 2000, seed1000), 1, 0, wfile, wsum, stages=False, report=report,
                      store_aln=False, noise_threads=(4,),
                      extra={"msa_seed": np.int64(seed1000), "msa_rows": np.int64(2000)})
+
+    # above the round-2 length limit (DMP_MAX_L was 1280): L = 1344, first pass, a seed with a well-separated MDS
+    # spectrum (tools/screen_eig_gaps.py --L 1344 --N 1000: seed 4 has 3.0e-3 as its smallest relative gap among the top
+    # nine eigenvalues, 1.8e-2 between the 8th and the 9th).  One reference run takes half an hour of this container's
+    # 8 cores: reference only.
+    seed1344 = int(os.environ.get("DMP_L1344_SEED", "-1"))
+    name = "synth_L1344_N1000_n0_m0_sep"
+    if want(name) and seed1344 >= 0:
+        capture_case(name, synth.synth_msa(1344, 1000, seed1344), 0, 0, wfile, wsum, stages=False, report=report,
+                     store_aln=False, oracle=False,
+                     extra={"msa_seed": np.int64(seed1344), "msa_rows": np.int64(1000)})
 
     # known-answer vectors for the minimiser and the backbone builder on a real CA trace
     if want("kat_refine_backbone"):
