@@ -398,6 +398,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   }
   c->max_N = max_N;
   c->max_passes = 128;
+  if (const char* e = getenv("DMP_TRIDIAG_CLUSTER")) c->tridiag_cluster = e[0] != '0';     // default of the option
   const int64_t L = max_L, N = max_N, D = NS * L, LL = L * L;
   // vertical-GRU state: the members and riders of a group side by side (up to 8 alignments of max_L columns,
   // 32-column tiles)
@@ -434,6 +435,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(seq_hx, 2 * 2 * HID2 + 4);
   A_(seq_abort, 2);      // [0] fault word of the prediction in flight, [1] faults latched by finished ones
   A_(refine_gx, 2 * 3 * L + 2);
+  A_(tri_gx, 8 * std::min<int64_t>(L, 640) + 2);
   A_(z0, (int64_t)STEM_OUT * LL);
   A_(planes, (int64_t)(NS * NS + 1) * LL);
   A_(dmap, LL);
@@ -492,6 +494,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   const std::string k(name);
   if (k == "conv_f32_exact") { ctx->conv_mode = value ? 1 : 0; return DMP_OK; }
   if (k == "tridiag_single") { ctx->tridiag_single = value ? 1 : 0; return DMP_OK; }
+  if (k == "tridiag_cluster") { ctx->tridiag_cluster = value ? 1 : 0; return DMP_OK; }
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_legacy") { ctx->vgru_legacy = value ? 1 : 0; return DMP_OK; }
   if (k == "gj_lds") { DMP_ARG(value >= 0 && value <= 2, "gj_lds must be 0, 1 or 2"); ctx->gj_lds = value; return DMP_OK; }
@@ -510,6 +513,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "conv_mode") { *h_value = ctx->conv_mode; return DMP_OK; }
   if (k == "conv_f32_exact") { *h_value = ctx->conv_mode == 1; return DMP_OK; }
   if (k == "tridiag_single") { *h_value = ctx->tridiag_single; return DMP_OK; }
+  if (k == "tridiag_cluster") { *h_value = ctx->tridiag_cluster; return DMP_OK; }
   if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
   if (k == "vgru_legacy") { *h_value = ctx->vgru_legacy; return DMP_OK; }
   if (k == "gj_lds") { *h_value = ctx->gj_lds; return DMP_OK; }

@@ -160,6 +160,8 @@ struct dmp_ctx {
   std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
   std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain
   int tridiag_single = 0;                  // option: 1 = single-workgroup tridiagonalisation
+  int tridiag_cluster = 1;                 // option: 1 = all Householder steps in one cluster launch (orders <= 640); 0 = one launch per step
+  unsigned long long* tri_gx = nullptr;    // [2][4][min(max_L, 640)] hand-off granules of the tridiagonalisation cluster + [2] placement header
   int refine_single = 0;                   // option: 1 = single-workgroup minimiser
   int gj_lds = 0;                          // option: trailing update of the inverse: 0 = operands from L2, 1 = panels staged in LDS, 2 = + tile fetched first
   float* vout = nullptr;    // [L][512]
@@ -283,6 +285,41 @@ int act_unpad(const float* d_xpad, int L, float* d_dense, hipStream_t s);
 int act_clear(float* d_xpad, int L, hipStream_t s);
 int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s);
 // mds.hip
+// ---- sum over the 64 lanes of a wave, float64, every lane gets the total ----------------------------------------
+// The xor butterfly 32, 16, 8, 4, 2, 1 of `v += __shfl_xor(v, off, 64)` - the same operands in the same order, so
+// the same bits - without going through the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) pair lane i
+// with i ^ 32 / i ^ 16, DPP row rotations do the four steps inside a row of 16 (after the xor-8 step lanes i and i ^ 8
+// agree, so "lane i + 4 mod 16" holds what lane i ^ 4 holds, and so on down).  Twelve dependent ds_bpermute round
+// trips (about 0.7 us) become twelve register moves: the Householder steps, the back-transformation and the
+// eigenvector orthogonalisation are chains of such sums.
+typedef unsigned dmp_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  {
+    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+    const dmp_u32x2 l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const dmp_u32x2 h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __longlong_as_double((long long)(((unsigned long long)h[0] << 32) | l[0])) +
+        __longlong_as_double((long long)(((unsigned long long)h[1] << 32) | l[1]));
+  }
+  {
+    const unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)(__double_as_longlong(v) >> 32);
+    const dmp_u32x2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const dmp_u32x2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __longlong_as_double((long long)(((unsigned long long)h[0] << 32) | l[0])) +
+        __longlong_as_double((long long)(((unsigned long long)h[1] << 32) | l[1]));
+  }
+#define DMP_ROR_F64(n)                                                                                          \
+  {                                                                                                             \
+    const int lo = (int)__double_as_longlong(v), hi = (int)(__double_as_longlong(v) >> 32);                     \
+    const unsigned l = (unsigned)__builtin_amdgcn_update_dpp(0, lo, 0x120 + (n), 0xf, 0xf, false);              \
+    const unsigned h = (unsigned)__builtin_amdgcn_update_dpp(0, hi, 0x120 + (n), 0xf, 0xf, false);              \
+    v += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));                                  \
+  }
+  DMP_ROR_F64(8) DMP_ROR_F64(4) DMP_ROR_F64(2) DMP_ROR_F64(1)
+#undef DMP_ROR_F64
+  return v;
+}
+
 // ---- hand-off between the workgroups of a cluster kernel (seq_gru_kernel, refine_cluster_kernel) -------------------
 // Granules {epoch, value} are published with a store and gathered with sc1 loads (agent scope: past the L1, served by
 // the L2).  An agent-scope STORE is written through to the memory side so that every XCD can see it: measured

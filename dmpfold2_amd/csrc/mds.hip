@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void eig_load_kernel(const float* __restrict__
 
 __device__ __forceinline__ double block_sum_1024(double v, double* red) {
   // red: 16 doubles of LDS
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = wave_sum_f64(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) red[wave] = v;
@@ -179,12 +179,20 @@ struct TriRun { int k0, n; };
 __global__ void tri_set_run_kernel(TriRun* run, int k0, int n) { run->k0 = k0; run->n = n; }
 
 __device__ __forceinline__ double block_sum_256(double v, double* red) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = wave_sum_f64(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) red[wave] = v;
   __syncthreads();
   return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the same sum with ONE barrier: `red4` must be a slot that no other sum touches until another barrier has passed
+__device__ __forceinline__ double block_sum_256_once(double v, double* red4) {
+  v = wave_sum_f64(v);
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
 }
 
 // grid: G workgroups   block: 256   dynamic LDS: 4 n doubles
@@ -304,9 +312,248 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ 
       }
       acc += a * vn[j - 1];
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    acc = wave_sum_f64(acc);
     if (lane == 0) pn[r - 1] = tk * acc;
   }
+}
+
+// ---- cluster tridiagonalisation: every Householder step in ONE launch ------------------------------------------
+// TC_G workgroups of one XCD (block id % 8 == xcd); workgroup g owns the matrix rows i with i % TC_G == g and keeps
+// them in LDS for the whole reduction (n / TC_G rows of n doubles); row i belongs to wave (i / TC_G) % 4.  Step k is
+// the step of tridiag_step_kernel, operation for operation - the O(n) part (w_{k-1}, the updated pivot row, v_k, beta,
+// tau) redundantly in every workgroup, then each wave updates its rows with (v_{k-1}, w_{k-1}) and forms their
+// products with v_k, the lanes along the row with the SAME lane -> column map - so d, e, tau and the reflectors are
+// the per-step launches' bit for bit.  What a launch boundary carried is handed over per step: the products
+// p_k[r] by their rows' owners and the next pivot row by its owner, as 8-byte {epoch, half of a double} granules
+// (parity-alternating arrays, epoch = step + 1), published with cluster_publish (plain stores that stop in the
+// XCD's L2 when the cluster finds itself on one XCD - common.h) and gathered with sc1 loads.
+// Round 2 measured this form at 5.8 us per step against 4.5 for the launches - with agent-scope (written-through)
+// stores; the XCD-local publication is what makes it pay.
+constexpr int TC_G = 32;
+constexpr int TC_MAX_N = 640;      // (n / 32 rows + 4 vectors) of n doubles: 123 KB of LDS at 640
+static size_t tri_cluster_lds_bytes(int n) { return sizeof(double) * ((size_t)cdiv(n, TC_G) + 4) * (size_t)n; }
+typedef unsigned long long tc_u64;
+struct TriClusterArgs {
+  const double* A;     // [n][n] symmetric, read once
+  double *d, *e, *tau, *V;
+  tc_u64* gx;          // [2 parity][2 vectors: p, pivot row][2 halves][n] granules + [2] placement header; zeroed before the launch
+  int* abort_flag;     // DMP_FAULT_EIG_HANDOFF is set if a hand-off times out
+  int n, xcd;
+};
+
+__device__ __forceinline__ void tc_publish(tc_u64* lo, tc_u64* hi, int idx, double v, unsigned epoch, bool local) {
+  const tc_u64 bits = (tc_u64)__double_as_longlong(v), tag = (tc_u64)epoch << 32;
+  cluster_publish(&lo[idx], tag | (bits & 0xffffffffull), local);
+  cluster_publish(&hi[idx], tag | (bits >> 32), local);
+}
+
+// A workgroup leaves when it owns no row below the pivot any more (nobody waits for a pure consumer, so it could
+// fall behind by more than the one step the two granule parities cover); d[k], e[k], tau[k] and reflector k are
+// written by the owner of row k + 1, which is always still there; the owner of the last row also runs the last step.
+// grid: 8 * TC_G blocks   block: 256   dynamic LDS: (rows_per_wg * n + 4 n) doubles
+__global__ __launch_bounds__(256) void tridiag_cluster_kernel(TriClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ double red[8];
+  __shared__ int sh_local, sh_abort;
+  __shared__ double sh_p0;
+  if ((int)(blockIdx.x & 7) != a.xcd) return;
+  const int g = blockIdx.x >> 3, n = a.n;
+  if (g >= n) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nrows = (n - g + TC_G - 1) / TC_G;            // rows g, g + TC_G, ...
+  const int last_row = g + TC_G * (nrows - 1);
+  double* vbuf[2] = {sm, sm + n};                         // v_{k-1} / v_k, alternating (indexed from global row k / k+1)
+  double* w = sm + 2 * n;
+  double* x = sm + 3 * n;
+  double* rows = sm + 4 * n;                              // row slot t = global row g + TC_G t
+  for (int t = 0; t < nrows; ++t) {
+    const double* src = a.A + (int64_t)(g + TC_G * t) * n;
+    for (int j = tid; j < n; j += 256) rows[(int64_t)t * n + j] = src[j];
+  }
+  if (tid == 0) {
+    sh_abort = 0;
+    sh_local = cluster_on_one_xcd(a.gx + (int64_t)8 * n, TC_G < n ? TC_G : n) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool local = sh_local != 0;
+  constexpr int NI = 3;                                   // 256 * 3 >= 640 = largest order of this kernel
+  double tkprev = 0.0;                                    // tau_{k-1}
+#ifdef TC_PROFILE
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
+  long long plast = clock64();
+  int psteps = 0;
+#define TC_T(i) { const long long now = clock64(); pt[i] += now - plast; plast = now; }
+#else
+#define TC_T(i)
+#endif
+  for (int k = 0; k < n; ++k) {
+    if (k >= last_row && !(k == n - 1 && last_row == n - 1)) break;
+    const int mp = n - k;
+    double* vp = vbuf[k & 1];                             // v_{k-1}: written as v_k by the previous step
+    double* vn = vbuf[(k + 1) & 1];
+    // ---- p_{k-1} and the pivot row as step k-1 published them (row 0 of the matrix at the start)
+    double vi[NI], pi[NI], xi[NI];
+    {
+      tc_u64* gp = a.gx + (int64_t)((k + 1) & 1) * 4 * n;  // parity of step k-1: [p lo][p hi][row lo][row hi]
+      const unsigned epoch = (unsigned)k;                 // step k-1 published with epoch (k-1) + 1
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int i = tid + 256 * u;
+        const bool in = i < mp;
+        vi[u] = (in && k > 0) ? vp[i] : 0.0;
+        pi[u] = 0.0;
+        xi[u] = (in && k == 0) ? a.A[i] : 0.0;
+      }
+      if (k > 0) {
+        // all of this thread's granules in one sweep (a sweep costs an L2 round trip whatever it loads)
+        tc_u64 q[NI][4];
+        for (unsigned spins = 0;; ++spins) {
+          bool ok = true;
+#pragma unroll
+          for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u;
+            if (i < mp) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                q[u][c] = __hip_atomic_load(&gp[(int64_t)c * n + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(q[u][c] >> 32) == epoch;
+              }
+            }
+          }
+          if (ok) break;
+          if (spins > 2000000u || sh_abort) { sh_abort = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+          if (tid + 256 * u < mp) {
+            pi[u] = __longlong_as_double((long long)((q[u][0] & 0xffffffffull) | (q[u][1] << 32)));
+            xi[u] = __longlong_as_double((long long)((q[u][2] & 0xffffffffull) | (q[u][3] << 32)));
+          }
+        }
+      }
+    }
+    TC_T(0)
+    __syncthreads();                                      // also: every wave has left the previous step's row pass
+    TC_T(1)
+    if (sh_abort) break;
+    const bool upd = tkprev != 0.0;
+    double pv = 0.0;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) pv += pi[u] * vi[u];
+    if (tid == 0) sh_p0 = pi[0];                          // w[0] = p[0] + a2 v[0] is needed by every thread
+    const double a2 = upd ? -0.5 * tkprev * block_sum_256_once(pv, red) : 0.0;
+    if (!upd) __syncthreads();                            // sh_p0 (the sum's barrier otherwise)
+    // w_{k-1} for this thread's indices, the updated pivot row x from it - one pass, no barrier in between
+    const double v0 = upd ? vp[0] : 0.0;
+    const double w0 = upd ? sh_p0 + a2 * v0 : 0.0;
+    TC_T(2)
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int j = tid + 256 * u;
+      if (j < mp) {
+        const double vj = upd ? vi[u] : 0.0;              // as the launches: a step with tau = 0 contributes nothing
+        const double wj = upd ? pi[u] + a2 * vi[u] : 0.0;
+        if (!upd) vp[j] = 0.0;
+        w[j] = wj;
+        const double xj = xi[u] - (v0 * wj + w0 * vj);
+        x[j] = xj;
+        if (j > 1) ss += xj * xj;
+      }
+    }
+    const double xnorm2 = block_sum_256_once(ss, red + 4);
+    const int m = mp - 1;
+    if (m == 0) {
+      if (tid == 0) { a.d[k] = x[0]; a.e[k] = 0.0; }
+      break;
+    }
+    const bool writer = ((k + 1) % TC_G) == g;            // the owner of row k + 1
+    const double alpha = x[1];
+    double beta, tk;
+    if (xnorm2 == 0.0) {
+      beta = alpha;
+      tk = 0.0;
+    } else {
+      const double nrm = sqrt(alpha * alpha + xnorm2);
+      beta = alpha >= 0.0 ? -nrm : nrm;
+      tk = (beta - alpha) / beta;
+    }
+    const double sc = tk != 0.0 ? 1.0 / (alpha - beta) : 0.0;
+    for (int i = tid; i < m; i += 256) vn[i] = (i == 0) ? 1.0 : x[1 + i] * sc;
+    if (writer) {
+      if (tid == 0) { a.d[k] = x[0]; a.e[k] = beta; a.tau[k] = tk; }
+      for (int i = tid; i < m; i += 256) a.V[(int64_t)k * n + i] = (i == 0) ? 1.0 : x[1 + i] * sc;
+    }
+    __syncthreads();
+    tkprev = tk;
+    TC_T(3)
+    // ---- this workgroup's rows of the trailing block: update with (v_{k-1}, w_{k-1}), product with v_k, publish
+    tc_u64* gq = a.gx + (int64_t)(k & 1) * 4 * n;
+    const unsigned epoch = (unsigned)k + 1u;
+    const int t_lo = k >= g ? (k - g) / TC_G + 1 : 0;     // first slot whose row lies below the pivot
+    const int t_w = t_lo + ((wave - t_lo) & 3);           // this wave's first one (slot t belongs to wave t % 4)
+    constexpr int RW = 3, CH = 5;                         // rows at a time, 64-column chunks loaded ahead
+    for (int tb = t_w; tb < nrows; tb += 4 * RW) {
+      int rr[RW];
+      double* rw[RW];
+      double vr[RW], wr[RW], acc[RW];
+      bool on[RW];
+#pragma unroll
+      for (int q = 0; q < RW; ++q) {
+        on[q] = tb + 4 * q < nrows;
+        const int t = on[q] ? tb + 4 * q : tb;
+        rr[q] = g + TC_G * t - k;                         // local row index, >= 1
+        rw[q] = rows + (int64_t)t * n + k;                // local column j at rw[q][j]
+        vr[q] = vp[rr[q]];
+        wr[q] = w[rr[q]];
+        acc[q] = 0.0;
+      }
+      for (int j0 = 1 + lane; j0 < mp; j0 += 64 * CH) {
+        double wj[CH], vj[CH], vnj[CH], av[RW][CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int j = j0 + 64 * c < mp ? j0 + 64 * c : mp - 1;       // clamped: the loads stay inside the row
+          wj[c] = w[j]; vj[c] = vp[j]; vnj[c] = vn[j - 1];
+#pragma unroll
+          for (int q = 0; q < RW; ++q) av[q][c] = rw[q][j];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int j = j0 + 64 * c;
+          if (j < mp) {
+#pragma unroll
+            for (int q = 0; q < RW; ++q) {
+              double a0 = av[q][c];
+              if (upd) {
+                a0 -= vr[q] * wj[c] + wr[q] * vj[c];
+                if (on[q]) rw[q][j] = a0;
+              }
+              acc[q] += a0 * vnj[c];
+              if (q == 0 && rr[0] == 1) tc_publish(gq + 2 * n, gq + 3 * n, j - 1, a0, epoch, local);   // the next pivot row
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RW; ++q) acc[q] = wave_sum_f64(acc[q]);
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < RW; ++q)
+          if (on[q]) tc_publish(gq, gq + n, rr[q] - 1, tk * acc[q], epoch, local);
+      }
+    }
+    TC_T(4)
+#ifdef TC_PROFILE
+    ++psteps;
+#endif
+  }
+#ifdef TC_PROFILE
+  if ((tid == 0 || tid == 192) && (g == 0 || g == 13 || g == 31) && psteps > 0)
+    printf("tridiag cluster wg %d tid %d n=%d steps %d local %d, cycles per step: gather %lld, barrier %lld, w %lld, x+norm+v %lld, rows %lld\n",
+           g, tid, n, psteps, (int)local, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps);
+#endif
+  if (sh_abort && tid == 0) atomicOr(a.abort_flag, DMP_FAULT_EIG_HANDOFF);
 }
 
 // 1/b to float64 rounding error without the IEEE division sequence (v_div_scale/fmas/fixup is a
@@ -550,12 +797,12 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
           if (lam[i + 1] - lam[i] > ortol) break;          // cluster chain ends
           double dot = 0.0;
           for (int r = lane; r < n; r += 64) dot += x[r * NEV + i] * x[r * NEV + j];
-          for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+          dot = wave_sum_f64(dot);
           for (int r = lane; r < n; r += 64) x[r * NEV + j] -= dot * x[r * NEV + i];
         }
         double nn = 0.0;
         for (int r = lane; r < n; r += 64) nn += x[r * NEV + j] * x[r * NEV + j];
-        for (int off = 32; off > 0; off >>= 1) nn += __shfl_xor(nn, off, 64);
+        nn = wave_sum_f64(nn);
         const double nrm = sqrt(nn);
         const double sc = nrm > 0.0 ? 1.0 / nrm : 0.0;
         for (int r = lane; r < n; r += 64) x[r * NEV + j] *= sc;
@@ -608,7 +855,7 @@ __global__ __launch_bounds__(512) void backtransform_kernel(const double* __rest
       double part = 0.0;
 #pragma unroll
       for (int t = 0; t < T; ++t) part += vv[g][t] * z[t];
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      part = wave_sum_f64(part);
       const double s = tk[g] * part;
 #pragma unroll
       for (int t = 0; t < T; ++t) z[t] -= s * vv[g][t];
@@ -701,6 +948,8 @@ int mds_kernel_attrs(dmp_ctx* c) {
                               (int)tri_eig_lds_bytes(DMP_MAX_L)));
   DMP_HIP(hipFuncSetAttribute((const void*)tridiag_step_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(double) * 4 * DMP_MAX_L)));
+  DMP_HIP(hipFuncSetAttribute((const void*)tridiag_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)tri_cluster_lds_bytes(TC_MAX_N)));
   if (c->device >= 0 && c->device < 64) done[c->device] = true;
   return DMP_OK;
 }
@@ -723,6 +972,13 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
   if (c->tridiag_single) {
     hipLaunchKernelGGL(tridiag_kernel, dim3(1), dim3(1024), sizeof(double) * (2 * n + 1024), s, A, n, d,
                        e, tau, V);
+    DMP_LAUNCH_CHECK();
+  } else if (c->tridiag_cluster && n <= TC_MAX_N) {
+    TriClusterArgs ta{};
+    ta.A = A; ta.d = d; ta.e = e; ta.tau = tau; ta.V = V;
+    ta.gx = (tc_u64*)c->tri_gx; ta.abort_flag = c->seq_abort; ta.n = n; ta.xcd = (c->refine_xcd + 4) & 7;
+    DMP_HIP(hipMemsetAsync(c->tri_gx, 0, sizeof(tc_u64) * (8 * (size_t)n + 2), s));
+    hipLaunchKernelGGL(tridiag_cluster_kernel, dim3(8 * TC_G), dim3(256), tri_cluster_lds_bytes(n), s, ta);
     DMP_LAUNCH_CHECK();
   } else {
     hipGraphExec_t ge;

@@ -131,7 +131,7 @@ def load_state_dict(weights_file=None):
 
 
 # device-side fault bits (include/dmpfold_hip.h, DMP_FAULT_*)
-FAULT_SEQ_HANDOFF, FAULT_F16_RANGE, FAULT_REFINE_HANDOFF, FAULT_BAD_CODE = 1, 2, 4, 8
+FAULT_SEQ_HANDOFF, FAULT_F16_RANGE, FAULT_REFINE_HANDOFF, FAULT_BAD_CODE, FAULT_EIG_HANDOFF = 1, 2, 4, 8, 16
 
 
 class DeviceFault(_lib.DmpError):
@@ -141,6 +141,7 @@ class DeviceFault(_lib.DmpError):
         self.bits = int(bits)
         what = [txt for bit, txt in ((FAULT_SEQ_HANDOFF, "sequence-GRU workgroup hand-off timed out"),
                                      (FAULT_REFINE_HANDOFF, "minimiser workgroup hand-off timed out"),
+                                     (FAULT_EIG_HANDOFF, "tridiagonalisation workgroup hand-off timed out"),
                                      (FAULT_F16_RANGE, "an activation left the f16 range of the "
                                       "split-product convolution (conv_mode 2 has no range limit)"))
                 if bits & bit]
@@ -405,6 +406,12 @@ class Pipeline:
                 eng.set_weights(state_dict)
             if streams > 1:
                 _lib.check(self.lib.dmp_ctx_set_lane(eng.ctx, self._lane))
+                # Several engines: the eigensolver's Householder steps as one launch each, not as the cluster kernel
+                # (same bits).  The cluster is the faster form for ONE prediction (0.9 against 1.9 ms at L = 300), but
+                # its 32 resident workgroups poll beside the other engines' convolutions for that long: measured
+                # 7.39 / 7.32 structures/s with the launches against 7.29 / 7.30 (bench.py, alternating, one box).
+                if "DMP_TRIDIAG_CLUSTER" not in os.environ:
+                    eng.set_option("tridiag_cluster", 0)
             self.engines.append(eng)
         S = len(self.engines)
         self._pending = []            # (ticket, d_msa, iterations, minsteps)

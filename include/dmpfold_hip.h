@@ -48,6 +48,7 @@ typedef enum dmp_status {
 #define DMP_FAULT_SEQ_HANDOFF 1    /* sequence-GRU workgroup hand-off timed out */
 #define DMP_FAULT_F16_RANGE 2      /* conv_mode 0: an activation reached |x| >= 6e4 (re-run in conv_mode 2) */
 #define DMP_FAULT_REFINE_HANDOFF 4 /* minimiser workgroup hand-off timed out */
+#define DMP_FAULT_EIG_HANDOFF 16   /* tridiagonalisation cluster: workgroup hand-off timed out */
 #define DMP_FAULT_BAD_CODE 8       /* residue code > 21: the reference's embedding raises IndexError
                                       (network.py:223); dmp_sync_check returns DMP_ERR_ARG for it */
 

@@ -235,6 +235,30 @@ def test_eigensolver_at_the_largest_order(synth_sd):
         st.eng.close()
 
 
+def test_cluster_tridiagonalisation_is_bitwise_the_per_step_launches(synth_sd):
+    """Orders up to 640 run every Householder step in ONE launch on a cluster of 32 workgroups of one XCD (rows in LDS,
+    products and pivot row handed over per step as granules; option tridiag_cluster, default 1).  It repeats the
+    per-step launches operation for operation: the MDS coordinates must be the same bits.  Orders below, at and
+    above the cluster size, partial last row slots, the largest order."""
+    from abi import Stages
+    st = Stages(synth_sd, max_L=640, max_N=4)
+    try:
+        rng = np.random.default_rng(23)
+        for L in (8, 31, 32, 33, 82, 255, 300, 513, 640):
+            P = np.cumsum(rng.standard_normal((L, 3)) * 2.2, axis=0)
+            D = np.linalg.norm(P[:, None] - P[None], axis=2) + np.abs(rng.standard_normal((L, L))) * 0.3
+            D = 0.5 * (D + D.T)
+            M = st.to((0.5 * (D[0:1, :] ** 2 + D[:, 0:1] ** 2 - D ** 2)).astype(np.float32))
+            outs = []
+            for mode in (0, 1, 1):
+                st.eng.set_option("tridiag_cluster", mode)
+                outs.append(st.eigh_top8(M).clone())
+                st.eng.sync_check()
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), L
+    finally:
+        st.eng.close()
+
+
 @pytest.mark.parametrize("name", ["synth_L200_N1000_n10_m0", "synth_L500_N5000_n1_m0", "synth_L1000_N2000_n0_m0"])
 def test_baseline_config_sizes_vs_reference(synth_sd, name):
     """The single-target configurations of BASELINE.json at their own sizes against outputs of the reference
@@ -315,5 +339,44 @@ def test_config4_L1000_well_separated_spectrum_vs_reference(synth_sd):
             assert np.abs(means - g["conf_mean_pass"]).max() < 1e-4
             assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= 1e-3
             assert np.abs(confs.cpu().numpy() - g["confs"]).max() < 1e-4
+    finally:
+        eng.close()
+
+
+def test_above_the_former_length_limit_vs_reference(synth_sd):
+    """L = 1344 > 1280 (the round-2 DMP_MAX_L): one trunk pass through the reference itself on an alignment whose top
+    MDS eigenvalues are well separated (seed 4 of tools/screen_eig_gaps.py --L 1344 --N 1000: smallest relative gap
+    among the top nine 3.0e-3; tests/golden/make_goldens.py).  Every kernel runs with 37 % more rows / columns than
+    any other reference-pinned case: D = 28 224 in the covariance inverse (3.2 GB per matrix), the eigensolver's
+    large-order instantiations (tridiag_step_kernel<8>, tri_eig_kernel<2>, backtransform_kernel<32, 1>).  PLAIN
+    tolerances; default and exact-f32 convolution."""
+    import hashlib
+    import os
+    from conftest import GOLDEN, load_golden
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    name = "synth_L1344_N1000_n0_m0_sep"
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated: " + name)
+    g = load_golden(name)
+    L = 1344
+    alnmat = encode_aln(synth.synth_msa(L, int(g["msa_rows"]), int(g["msa_seed"])))
+    assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+    eng = Engine("cuda:0", L, alnmat.shape[0])
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+    try:
+        for mode in (0, 1):
+            eng.set_option("conv_mode", mode)
+            coords, confs = eng.predict(alnmat, None, 0, 0)
+            eng.sync_check()
+            ca = eng.fetch("ca_pass", L * 3).cpu().numpy().reshape(L, 3)
+            dev = ca_rmsd(ca, g["ca_pass"][0])
+            means = eng.fetch("conf_means", 1).cpu().numpy()
+            final = ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1])
+            dconf = float(np.abs(confs.cpu().numpy() - g["confs"]).max())
+            print("L=1344, conv_mode", mode, "CA-RMSD pass 0", dev, "final", final, "max|dconf|", dconf)
+            assert dev <= 1e-3 and final <= 1e-3, (mode, dev, final)
+            assert np.abs(means - g["conf_mean_pass"]).max() < 1e-4
+            assert dconf < 1e-4
     finally:
         eng.close()
