@@ -6,15 +6,20 @@
 
 namespace dmp {
 
-// Gates on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each), as in the vertical GRU
-// (vgru.hip): absolute error below 2e-7, saturating correctly.  The device library's expf / tanhf are two dependent
-// chains of 40-100 instructions on ONE wave's critical path in every step of a latency-bound recurrence.
-__device__ __forceinline__ float sigmoidf_(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.442695040888963f));
-}
-__device__ __forceinline__ float tanhf_(float x) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
-}
+// Gates: gate_sigmoid / gate_tanh (common.h): the hardware exponential and reciprocal with the product's rounding
+// error recovered and a polynomial for small tanh arguments - float32-accurate, a dozen instructions.  The device
+// library's expf / tanhf are two dependent chains of 40-100 instructions on ONE wave's critical path in every step
+// of a latency-bound recurrence (SEQ_LIBM_GATES=1 builds them in for comparison).
+#ifndef SEQ_LIBM_GATES
+#define SEQ_LIBM_GATES 0
+#endif
+#if SEQ_LIBM_GATES
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float sigmoidf_(float x) { return gate_sigmoid(x); }
+__device__ __forceinline__ float tanhf_(float x) { return gate_tanh(x); }
+#endif
 
 // Weight-stationary cluster: each direction is run by SEQ_G workgroups; workgroup g keeps the
 // 96 rows of W_hh that produce hidden units [32g, 32g+32) in registers (96 floats per lane)

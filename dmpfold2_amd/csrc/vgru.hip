@@ -309,12 +309,20 @@ typedef unsigned vg_u32x4 __attribute__((ext_vector_type(4)));
 // correctly at +-1 / 0 / 1), a tenth of the float32 rounding of the 1024-term sums they are fed with; the device
 // library's expf / tanhf cost 4.8 us per step (8 evaluations per lane, dependent chains) - measured, more than
 // the matrix products.
+#ifndef VG_ACC_GATES
+#define VG_ACC_GATES 0
+#endif
+#if VG_ACC_GATES
+__device__ __forceinline__ float vg_sigmoid(float x) { return gate_sigmoid(x); }
+__device__ __forceinline__ float vg_tanh(float x) { return gate_tanh(x); }
+#else
 __device__ __forceinline__ float vg_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.442695040888963f));
 }
 __device__ __forceinline__ float vg_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
 }
+#endif
 
 __device__ __forceinline__ void vg_dma16(const void* gsrc, unsigned lds_byte_addr) {
   unsigned keep;
