@@ -82,6 +82,13 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * "tridiag_single" = 1 runs the Householder tridiagonalisation of the MDS eigensolver in a single
  * workgroup (one launch) instead of one multi-workgroup launch per step; same algorithm, different
  * summation order (results agree to float64 rounding).
+ * "tridiag_cluster" (default 1; the environment variable DMP_TRIDIAG_CLUSTER presets it): orders up to 640 run
+ * every Householder step in ONE launch on a cluster of 32 workgroups of one XCD; 0 = one launch per step (hipGraph
+ * chain).  The two forms produce the same bits; the cluster is faster for one prediction (0.9 against 1.9 ms at
+ * order 300), the launches disturb the convolutions of other contexts less (the multi-engine scheduler sets 0).
+ * "gj_lds" = 1 / 2 stages the panels of the Gauss-Jordan trailing update through LDS (2: and fetches the tile before
+ * the MFMA chain); same bits, measured slower than 0 at D = 6300 (12.1 / 11.1 against 10.8 ms), faster at
+ * D = 10500 (30.4 against 32.6 ms with 2): an experiment knob.
  * "vgru_legacy" = 1 runs the vertical GRU with the round-2 step kernel (one target per launch, K split over the
  * waves of a workgroup; different summation order, results agree to float32 rounding; no group form).
  * "refine_single" = 1 runs the minimiser (dmp_refine_coords, dmp_predict*) in one workgroup instead
