@@ -495,6 +495,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "conv_f32_exact") { ctx->conv_mode = value ? 1 : 0; return DMP_OK; }
   if (k == "tridiag_single") { ctx->tridiag_single = value ? 1 : 0; return DMP_OK; }
   if (k == "tridiag_cluster") { ctx->tridiag_cluster = value ? 1 : 0; return DMP_OK; }
+  if (k == "cluster_local") { ctx->cluster_local = value ? 1 : 0; return DMP_OK; }
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_legacy") { ctx->vgru_legacy = value ? 1 : 0; return DMP_OK; }
   if (k == "gj_lds") { DMP_ARG(value >= 0 && value <= 2, "gj_lds must be 0, 1 or 2"); ctx->gj_lds = value; return DMP_OK; }
@@ -514,6 +515,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "conv_f32_exact") { *h_value = ctx->conv_mode == 1; return DMP_OK; }
   if (k == "tridiag_single") { *h_value = ctx->tridiag_single; return DMP_OK; }
   if (k == "tridiag_cluster") { *h_value = ctx->tridiag_cluster; return DMP_OK; }
+  if (k == "cluster_local") { *h_value = ctx->cluster_local; return DMP_OK; }
   if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
   if (k == "vgru_legacy") { *h_value = ctx->vgru_legacy; return DMP_OK; }
   if (k == "gj_lds") { *h_value = ctx->gj_lds; return DMP_OK; }

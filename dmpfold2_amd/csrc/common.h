@@ -159,6 +159,7 @@ struct dmp_ctx {
   int vgru_legacy = 0;                     // option: 1 = the round-2 step kernel (one target per launch, K split over waves)
   std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
   std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain
+  int cluster_local = 1;                   // option: 0 = the cluster kernels always publish with agent-scope stores (no XCD-local fast path)
   int tridiag_single = 0;                  // option: 1 = single-workgroup tridiagonalisation
   int tridiag_cluster = 1;                 // option: 1 = all Householder steps in one cluster launch (orders <= 640); 0 = one launch per step
   unsigned long long* tri_gx = nullptr;    // [2][4][min(max_L, 640)] hand-off granules of the tridiagonalisation cluster + [2] placement header
@@ -364,7 +365,9 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // by the host before the launch); when all `members` have arrived, a mask with one bit set means plain stores are safe.
 // Returns true for "one XCD" (call from one thread per workgroup; bounded wait: false on a timeout, the slow path
 // then still works wherever the members run).
-__device__ __forceinline__ bool cluster_on_one_xcd(unsigned long long* hdr, int members) {
+// `allow` = false (option "cluster_local" = 0) answers false at once: the agent-scope protocol, for tests of that path.
+__device__ __forceinline__ bool cluster_on_one_xcd(unsigned long long* hdr, int members, bool allow = true) {
+  if (!allow) return false;
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   __hip_atomic_fetch_or(&hdr[0], 1ull << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -217,6 +217,7 @@ struct RefineArgs {
   int L, steps, xcd;
   u64* gx;             // [2][3L] granules + [2] placement header, zeroed before the launch
   int* abort_flag;     // bit 2 is set if a hand-off ever times out
+  int allow_local;     // 0: never the XCD-local publication
 };
 
 __host__ __device__ inline int refine_slices(int L) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_cluster_kernel(RefineArgs a
   if (tid == 0) {
     sh_abort = 0;
     // the workgroups that own residues: all on one XCD (common.h)?  Then plain stores publish the granules
-    sh_local = cluster_on_one_xcd(a.gx + (int64_t)2 * 3 * L, (L + Lg - 1) / Lg) ? 1 : 0;
+    sh_local = cluster_on_one_xcd(a.gx + (int64_t)2 * 3 * L, (L + Lg - 1) / Lg, a.allow_local != 0) ? 1 : 0;
   }
   __syncthreads();
   const bool local = sh_local != 0;
@@ -335,6 +336,7 @@ int refine_coords(dmp_ctx* c, float* d_ca, int L, int steps, hipStream_t s) {
   a.ca = d_ca; a.L = L; a.steps = steps; a.xcd = c->refine_xcd;
   a.gx = (u64*)c->refine_gx;
   a.abort_flag = c->seq_abort;
+  a.allow_local = c->cluster_local;
   const int Lg = (L + RF_G - 1) / RF_G;
   DMP_HIP(hipMemsetAsync(c->refine_gx, 0, sizeof(u64) * (2 * 3 * L + 2), s));
   hipLaunchKernelGGL(refine_cluster_kernel, dim3(8 * RF_G), dim3(RF_THREADS),

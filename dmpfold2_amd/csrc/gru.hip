@@ -50,6 +50,7 @@ struct SeqArgs {
   u64* hx;               // [2 dir][2 parity][256] granules + [2 dir][2] placement header, zeroed before every launch
   int* abort_flag;       // set if a hand-off ever times out
   int T;
+  int allow_local;       // 0: never the XCD-local publication
 };
 
 // grid: 8 * SEQ_G blocks (only ids with id % 8 < 2 work: direction = id % 8)   block: 256
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) h[lane + 64 * q] = 0.f;
   // do the SEQ_G workgroups of this direction share an XCD (common.h)?  Then granules are published with plain stores
-  if (tid == 0) sh_local = cluster_on_one_xcd(a.hx + 4 * HID2 + 2 * dir, SEQ_G) ? 1 : 0;
+  if (tid == 0) sh_local = cluster_on_one_xcd(a.hx + 4 * HID2 + 2 * dir, SEQ_G, a.allow_local != 0) ? 1 : 0;
   __syncthreads();
   const bool local = sh_local != 0;
   u64* hx_dir = a.hx + (int64_t)dir * 2 * HID2;
@@ -226,6 +227,7 @@ int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hip
     a.out = out; a.T = T;
     a.hx = (u64*)c->seq_hx;
     a.abort_flag = c->seq_abort;
+    a.allow_local = c->cluster_local;
     DMP_HIP(hipMemsetAsync(c->seq_hx, 0, sizeof(u64) * (2 * 2 * HID2 + 4), s));
     hipLaunchKernelGGL(seq_gru_kernel, dim3(8 * SEQ_G), dim3(256), 0, s, a);
     DMP_LAUNCH_CHECK();

@@ -339,6 +339,7 @@ struct TriClusterArgs {
   tc_u64* gx;          // [2 parity][2 vectors: p, pivot row][2 halves][n] granules + [2] placement header; zeroed before the launch
   int* abort_flag;     // DMP_FAULT_EIG_HANDOFF is set if a hand-off times out
   int n, xcd;
+  int allow_local;     // 0: never the XCD-local publication
 };
 
 __device__ __forceinline__ void tc_publish(tc_u64* lo, tc_u64* hi, int idx, double v, unsigned epoch, bool local) {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void tridiag_cluster_kernel(TriClusterArgs a) 
   }
   if (tid == 0) {
     sh_abort = 0;
-    sh_local = cluster_on_one_xcd(a.gx + (int64_t)8 * n, TC_G < n ? TC_G : n) ? 1 : 0;
+    sh_local = cluster_on_one_xcd(a.gx + (int64_t)8 * n, TC_G < n ? TC_G : n, a.allow_local != 0) ? 1 : 0;
   }
   __syncthreads();
   const bool local = sh_local != 0;
@@ -584,6 +585,13 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   __shared__ double sh_scal[4];
   __shared__ double red[8][NEV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef TE_PROFILE
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long plast = clock64();
+#define TE_T(i) { const long long now = clock64(); pt[i] += now - plast; plast = now; }
+#else
+#define TE_T(i)
+#endif
 
   // Gershgorin interval and norms
   double lo = 1e300, hi = -1e300, emax = 0.0, nrm1 = 0.0;
@@ -622,6 +630,7 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   __syncthreads();
   const double glo = sh_scal[0], ghi = sh_scal[1], pivmin = sh_scal[2], tnorm = sh_scal[3];
 
+  TE_T(0)
   // ---- bisection: wave w finds eigenvalue w of the top 8 (ascending order); a Sturm count is a
   // chain of n float64 divisions, so the eight counts run side by side
   {
@@ -644,6 +653,7 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   }
   __syncthreads();
 
+  TE_T(1)
   // ---- inverse iteration: lanes 0..7 of wave 0, one eigenvalue each, in lockstep
   const double eps = 2.220446049250313e-16;
   const double ortol = 1e-3 * tnorm;
@@ -712,6 +722,7 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   }
   if (MODE == 2) __threadfence();      // x lives in global memory: lanes read what other lanes wrote
   __syncthreads();
+  TE_T(2)
   // From here on only wave 0 works (lanes 0..7 solve, then all 64 lanes orthonormalise with wave
   // shuffles): no workgroup barrier inside the iteration loop.
   if (wave == 0) {
@@ -771,6 +782,7 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
       }
       if (MODE == 2) __threadfence();
       __builtin_amdgcn_wave_barrier();
+      TE_T(3)
       // modified Gram-Schmidt inside clusters + normalisation
       for (int j = 0; j < NEV; ++j) {
         for (int i = j - 1; i >= 0; --i) {
@@ -789,12 +801,19 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
         if (MODE == 2) __threadfence();                    // the next column's dot products read this one
       }
       __builtin_amdgcn_wave_barrier();
+      TE_T(4)
     }
   }
   __syncthreads();
   if (MODE != 2)
     for (int r = tid; r < n * NEV; r += 512) Z[r] = x[r];
   if (tid < NEV) lam_out[tid] = lam[tid];
+#ifdef TE_PROFILE
+  TE_T(5)
+  if (tid == 0)
+    printf("tri_eig n=%d cycles: setup %lld, bisection %lld, LU + start vectors %lld, triangular solves (5 iterations) %lld, Gram-Schmidt %lld, write-back %lld\n",
+           n, pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
+#endif
 }
 
 // Z <- Q Z with Q = H_0 H_1 ... H_{n-2}; then sign rule and scaling.
@@ -956,7 +975,7 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
   } else if (c->tridiag_cluster && n <= TC_MAX_N) {
     TriClusterArgs ta{};
     ta.A = A; ta.d = d; ta.e = e; ta.tau = tau; ta.V = V;
-    ta.gx = (tc_u64*)c->tri_gx; ta.abort_flag = c->seq_abort; ta.n = n; ta.xcd = (c->refine_xcd + 4) & 7;
+    ta.gx = (tc_u64*)c->tri_gx; ta.abort_flag = c->seq_abort; ta.n = n; ta.xcd = (c->refine_xcd + 4) & 7; ta.allow_local = c->cluster_local;
     DMP_HIP(hipMemsetAsync(c->tri_gx, 0, sizeof(tc_u64) * (8 * (size_t)n + 2), s));
     hipLaunchKernelGGL(tridiag_cluster_kernel, dim3(8 * TC_G), dim3(256), tri_cluster_lds_bytes(n), s, ta);
     DMP_LAUNCH_CHECK();

@@ -86,6 +86,9 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * every Householder step in ONE launch on a cluster of 32 workgroups of one XCD; 0 = one launch per step (hipGraph
  * chain).  The two forms produce the same bits; the cluster is faster for one prediction (0.9 against 1.9 ms at
  * order 300), the launches disturb the convolutions of other contexts less (the multi-engine scheduler sets 0).
+ * "cluster_local" (default 1): the cluster kernels (sequence GRU, minimiser, tridiagonalisation) publish their
+ * hand-off granules with plain stores when they find all their workgroups on one XCD (run-time check); 0 = always
+ * agent-scope stores, the protocol that does not depend on placement.  Same bits, 1.84 against 2.8 us per GRU step.
  * "gj_lds" = 1 / 2 stages the panels of the Gauss-Jordan trailing update through LDS (2: and fetches the tile before
  * the MFMA chain); same bits, measured slower than 0 at D = 6300 (12.1 / 11.1 against 10.8 ms), faster at
  * D = 10500 (30.4 against 32.6 ms with 2): an experiment knob.

@@ -763,3 +763,30 @@ def test_errors(st, weights_file, tmp_path):
         aln_to_coords(str(short), device="cpu", weights_file=weights_file)
     with pytest.raises(FileNotFoundError):
         aln_to_coords(str(tmp_path / "missing.aln"), device="cuda:0", weights_file=weights_file)
+
+
+def test_cluster_kernels_agree_with_and_without_the_xcd_local_handoff(synth_sd):
+    """The cluster kernels (sequence GRU, minimiser, tridiagonalisation) publish their hand-off granules with plain
+    stores when a run-time check finds the cluster on one XCD, and with agent-scope stores otherwise (option
+    cluster_local = 0 forces that path, which no longer runs by default on a healthy box).  The two protocols carry
+    the same values: a whole prediction with the minimiser is the same bits either way, and no hand-off timed out."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    eng = Engine("cuda:0", 128, 300)
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+    try:
+        outs = []
+        for local in (1, 0, 1):
+            eng.set_option("cluster_local", local)
+            assert eng.get_option("cluster_local") == local
+            res = []
+            for L, N, seed in ((82, 120, 3), (128, 300, 4), (33, 17, 5)):
+                c, f = eng.predict(encode_aln(synth.synth_msa(L, N, seed)), None, 2, 20)
+                eng.sync_check()                      # raises DeviceFault on a hand-off time-out
+                res.append((c.clone(), f.clone()))
+            outs.append(res)
+        for a, b, c in zip(*outs):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    finally:
+        eng.close()

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/s4h; mkdir -p $O; cd $R
-DMPFOLD_HIP_LIB=$R/tools/_bin/libtc_prof.so timeout 300 python - > $O/tc_prof.txt 2>&1 <<'PY'
+DMPFOLD_HIP_LIB=$R/tools/_bin/${PROFLIB:-libtc_prof.so} timeout 300 python - > $O/tc_prof.txt 2>&1 <<'PY'
 import sys, numpy as np, torch
 sys.path.insert(0, "tests")
 from dmpfold2_amd import synth
