@@ -395,6 +395,10 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   {
     static std::atomic<int> next_xcd{0};             // spread the minimiser clusters of the contexts over the XCDs
     c->refine_xcd = next_xcd.fetch_add(1) & 7;
+    // the contexts of a process spread their sequence-GRU clusters over the XCD pairs (four engines: 0-1, 2-3, 4-5, 6-7)
+    // instead of all sitting on XCDs 0 and 1; DMP_SEQ_XCD_SPREAD=0 restores that
+    static const bool spread = !(getenv("DMP_SEQ_XCD_SPREAD") && getenv("DMP_SEQ_XCD_SPREAD")[0] == '0');
+    c->seq_xcd0 = spread ? (2 * c->refine_xcd) & 7 : 0;
   }
   c->max_N = max_N;
   c->max_passes = 128;

@@ -175,6 +175,7 @@ struct dmp_ctx {
   int* seq_abort = nullptr;              // [2] DMP_FAULT_* bits: [0] of the prediction in flight, [1] latched by finished ones
   unsigned long long* refine_gx = nullptr;  // [2][3 max_L] hand-off granules of the minimiser cluster + [2] placement header
   int refine_xcd = 0;                    // XCD the minimiser cluster of this context runs on
+  int seq_xcd0 = 0;                      // XCDs seq_xcd0, seq_xcd0 + 1: the two directions of this context's sequence GRUs
   // pair trunk
   float* z0 = nullptr;      // [384][L][L]
   float* planes = nullptr;  // [442][L][L]: the coupling channels 21a+b and the contact channel as planes (stem_static's B operand)

@@ -51,13 +51,14 @@ struct SeqArgs {
   int* abort_flag;       // set if a hand-off ever times out
   int T;
   int allow_local;       // 0: never the XCD-local publication
+  int xcd0;              // the two directions run on XCDs xcd0, xcd0 + 1 (block id % 8)
 };
 
-// grid: 8 * SEQ_G blocks (only ids with id % 8 < 2 work: direction = id % 8)   block: 256
+// grid: 8 * SEQ_G blocks (only ids with (id % 8 - xcd0) % 8 < 2 work: that is the direction)   block: 256
 __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
   __shared__ __attribute__((aligned(16))) float hs[4][HID2];
   __shared__ int sh_local;
-  const int dir = blockIdx.x & 7, g = blockIdx.x >> 3;
+  const int dir = ((int)(blockIdx.x & 7) - a.xcd0) & 7, g = blockIdx.x >> 3;
   if (dir >= 2) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rgp = lane >> 4, kg = lane & 15;
@@ -228,6 +229,7 @@ int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hip
     a.hx = (u64*)c->seq_hx;
     a.abort_flag = c->seq_abort;
     a.allow_local = c->cluster_local;
+    a.xcd0 = c->seq_xcd0;
     DMP_HIP(hipMemsetAsync(c->seq_hx, 0, sizeof(u64) * (2 * 2 * HID2 + 4), s));
     hipLaunchKernelGGL(seq_gru_kernel, dim3(8 * SEQ_G), dim3(256), 0, s, a);
     DMP_LAUNCH_CHECK();
