@@ -466,6 +466,29 @@ def main(argv=None):
                 "note": "host work of one target (file -> codes in HBM, result -> PDB text), single thread, "
                         "outside the timed region; the batch front end overlaps it with the GPU"}
 
+    # ---- latency of ONE prediction of the same configuration on an engine of its own (the reference's use case: one
+    #      CLI call; the scheduler above is the throughput mode).  Reported beside `value`, never part of it.
+    single = None
+    if rank == 0 and timed_outs:
+        from dmpfold2_amd.predict import Engine
+        es = Engine(device, L_NS, N_NS)
+        try:
+            es.share_weights(pipe.engines[0])
+            ts = []
+            for _ in range(4):
+                torch.cuda.synchronize(device)
+                t = time.perf_counter()
+                cs, fs = es.predict_device(targets[first], None, ITERS, MINSTEPS)
+                es.sync_check()
+                ts.append((time.perf_counter() - t) * 1e3)
+            single = {"ms": min(ts[1:]), "runs_ms": ts,
+                      "bitwise_equals_the_scheduler": bool(torch.equal(cs, timed_outs[0][0]) and torch.equal(fs, timed_outs[0][1])),
+                      "note": "one target alone on one engine (single stream, cluster tridiagonalisation; the first run "
+                              "builds the launch graphs), same target and bits as the scheduler's first timed result"}
+            ok = ok and single["bitwise_equals_the_scheduler"]
+        finally:
+            es.close()
+
     # ---- the same workload with the exact-f32 convolution (conv_mode 1), EXACT_STEPS steps ------------
     exact = None
     exact_steps = max(1, min(EXACT_STEPS, args.steps))
@@ -576,6 +599,8 @@ def main(argv=None):
         }
         if host is not None:
             line["host_ms_per_target"] = host
+        if single is not None:
+            line["single_target"] = single
         if exact is not None:
             v = world * exact_steps * B / exact
             line["exact_f32"] = {
