@@ -380,3 +380,53 @@ def test_above_the_former_length_limit_vs_reference(synth_sd):
             assert dconf < 1e-4
     finally:
         eng.close()
+
+
+def test_largest_length_end_to_end(synth_sd, oracle_weights):
+    """L = DMP_MAX_L = 2048 (D = 43 008 in the covariance inverse: 7.4 GB per matrix, (21 L)^2 and 442 L^2 just below
+    2^31 elements).  What the CPU oracle can afford at this length is checked against it - sequence weights bit-exact,
+    covariance samples, the vertical GRU - the inverse against the identity on sampled rows, and a whole prediction
+    (2 trunk passes, 10 minimiser steps) for finite, normalised outputs and the exact symmetry of the Gram matrix."""
+    from abi import Stages
+    from dmpfold2_amd import predict
+    L, N = predict.MAX_L, 96
+    msa = _msa(L, N, 31)
+    st = Stages(synth_sd, max_L=L, max_N=N)
+    try:
+        w = st.msa_weights(msa)
+        assert np.array_equal(w.cpu().numpy(), np.asarray(O.reweight(msa)))
+        cov = st.cov_build(msa, w)
+        # sampled entries of the oracle's cov_reg (predict.py:44-52 / oracle fast_dca) without its D x D matrices
+        D = 21 * L
+        wt = torch.from_numpy(np.asarray(O.reweight(msa)))
+        x = F.one_hot(torch.from_numpy(np.minimum(msa, 20).astype(np.int64)), 21).float().reshape(N, D)
+        neff = wt.sum()
+        num_points = neff - torch.sqrt(wt.mean())
+        mean = (x * wt[:, None]).sum(dim=0, keepdim=True) / num_points
+        xc = (x - mean) * torch.sqrt(wt[:, None])
+        g = torch.Generator().manual_seed(3)
+        idx = torch.randint(0, D, (4096, 2), generator=g)
+        idx[:64, 1] = idx[:64, 0]                                          # some diagonal entries (the ridge)
+        want = (xc[:, idx[:, 0]] * xc[:, idx[:, 1]]).sum(dim=0) / num_points \
+            + (idx[:, 0] == idx[:, 1]).float() * 4.5 / torch.sqrt(neff)
+        got = cov[idx[:, 0].cuda(), idx[:, 1].cuda()].cpu()
+        assert (got - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
+        inv = st.spd_inverse(cov)
+        rows = torch.tensor([0, 1, 777, 21 * 1280 + 5, D // 2, D - 2, D - 1], device="cuda")
+        prod = (cov[rows] @ inv).double()                  # float32 products of 43 008 terms: 5e-5 is their rounding
+        eye = torch.zeros_like(prod)
+        eye[torch.arange(len(rows)), rows] = 1.0
+        assert (prod - eye).abs().max() < 5e-4              # the bound of the D = 6300 identity test (measured here: 2e-4)
+        del cov, inv, prod, eye
+        v = st.gru_vertical(msa).cpu().numpy()
+        idxm = torch.from_numpy(msa.astype(np.int64))
+        vr = O._gru(oracle_weights, "vgru", oracle_weights["embed.weight"][idxm], 22, 512, 2, False, False)[-1].numpy()
+        assert np.abs(v - vr).max() < 1e-5
+        coords, confs = st.eng.predict(msa, None, 1, 10)
+        st.eng.sync_check()
+        c, f = coords.cpu().numpy(), confs.cpu().numpy()
+        assert np.isfinite(c).all() and np.isfinite(f).all() and (f > 0).all() and (f < 1).all()
+        gram = st.eng.fetch("gram", L * L).cpu().numpy().reshape(L, L)
+        assert np.array_equal(gram, gram.T)
+    finally:
+        st.eng.close()
