@@ -246,8 +246,13 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#if defined(GJ_DBG_NOMFMA)
+#define GJ_C_END 1
+#else
+#define GJ_C_END (16 / PF)
+#endif
 #pragma unroll
-  for (int c = 0; c < 16 / PF; ++c) {
+  for (int c = 0; c < GJ_C_END; ++c) {
     if (c + 1 < 16 / PF) load((c + 1) & 1, c + 1);
 #pragma unroll
     for (int u = 0; u < PF; ++u)
@@ -276,8 +281,16 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
         float v = 0.f;
         if (row < D && col < D) {
           float* p = A + (int64_t)row * D + col;
+#if defined(GJ_DBG_NOREAD)
+          v = -acc[mi][ni][r];
+          *p = v;
+#elif defined(GJ_DBG_NOSTORE)
+          v = (blockcol ? 0.f : *p) - acc[mi][ni][r];
+          if (v == 123.456f) *p = v;
+#else
           v = (blockcol ? 0.f : *p) - acc[mi][ni][r];
           *p = v;
+#endif
         }
       }
     }
