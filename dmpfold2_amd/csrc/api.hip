@@ -503,6 +503,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_legacy") { ctx->vgru_legacy = value ? 1 : 0; return DMP_OK; }
   if (k == "gj_lds") { DMP_ARG(value >= 0 && value <= 2, "gj_lds must be 0, 1 or 2"); ctx->gj_lds = value; return DMP_OK; }
+  if (k == "gj_diag_groups") { DMP_ARG(value == 2 || value == 4 || value == 8, "gj_diag_groups must be 2, 4 or 8"); ctx->gj_diag_groups = value; return DMP_OK; }
   if (k == "conv_mode") {
     DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
     ctx->conv_mode = value;
@@ -523,6 +524,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
   if (k == "vgru_legacy") { *h_value = ctx->vgru_legacy; return DMP_OK; }
   if (k == "gj_lds") { *h_value = ctx->gj_lds; return DMP_OK; }
+  if (k == "gj_diag_groups") { *h_value = ctx->gj_diag_groups; return DMP_OK; }
   set_error("unknown option %s", name);
   return DMP_ERR_ARG;
 }

@@ -164,6 +164,7 @@ struct dmp_ctx {
   int tridiag_cluster = 1;                 // option: 1 = all Householder steps in one cluster launch (orders <= 640); 0 = one launch per step
   unsigned long long* tri_gx = nullptr;    // [2][4][min(max_L, 640)] hand-off granules of the tridiagonalisation cluster + [2] placement header
   int refine_single = 0;                   // option: 1 = single-workgroup minimiser
+  int gj_diag_groups = 4;                  // option: row groups of the diagonal sweep (2 = 256 threads as in rounds 1-3, 4 = 512 threads)
   int gj_lds = 0;                          // option: trailing update of the inverse: 0 = operands from L2, 1 = panels staged in LDS, 2 = + tile fetched first
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions

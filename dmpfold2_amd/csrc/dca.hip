@@ -113,26 +113,30 @@ int cov_build(dmp_ctx* c, const uint8_t* d_msa, const float* d_w, int N, int L, 
 //                 C = A_:,k       (rows of block k zeroed);
 //                 A -= C R;  A_:,k = -C P;  A_k,: = R;  A_kk = P
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gj_diag_kernel(const float* __restrict__ A, int D, int k0,
-                                                      int bs, float* __restrict__ P) {
+// NH = row groups of the block (threads = 128 NH): thread (j, ih) keeps rows ih*RH .. ih*RH + RH - 1 of column j in
+// RH = 128 / NH registers.  Every element sees the same operations whatever NH (same bits); four groups (512 threads,
+// 32 registers, two waves per SIMD) halve a thread's share of a pivot step against the two of rounds 1-3.
+template <int NH>
+__global__ __launch_bounds__(128 * NH) void gj_diag_kernel(const float* __restrict__ A, int D, int k0,
+                                                          int bs, float* __restrict__ P) {
   // Symmetric sweep operator (Goodnight): sweeping every pivot of an SPD block in place gives
   // -inverse and keeps the matrix symmetric, so a step only needs the pivot ROW broadcast.
-  // Thread (j, ih) keeps rows ih*64 .. ih*64+63 of column j in 64 registers (static indexing:
-  // the pivot loop is unrolled over the row-in-half index); the pivot row goes through LDS.
+  // (static register indexing: the pivot loop is unrolled over the row-in-group index); the pivot row goes through LDS.
+  constexpr int RH = GJ_NB / NH;
   __shared__ float rowk[2][GJ_NB];
   const int tid = threadIdx.x;
   const int j = tid & 127, ih = tid >> 7;
-  float sreg[64];
+  float sreg[RH];
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    const int i = ih * 64 + r;
+  for (int r = 0; r < RH; ++r) {
+    const int i = ih * RH + r;
     sreg[r] = (i < bs && j < bs) ? A[(int64_t)(k0 + i) * D + k0 + j] : (i == j ? 1.f : 0.f);
   }
 #pragma unroll 1
-  for (int kh = 0; kh < 2; ++kh) {
+  for (int kh = 0; kh < NH; ++kh) {
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
-      const int k = kh * 64 + r;
+    for (int r = 0; r < RH; ++r) {
+      const int k = kh * RH + r;
       if (k < bs) {                                   // uniform
         float* rk = rowk[k & 1];
         if (ih == kh) rk[j] = sreg[r];                // publish row k (column j's element)
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(256) void gj_diag_kernel(const float* __restrict__ 
         const float bj = rk[j] * invd;                // new a_kj
         const float mul = jk ? -invd : bj;            // column k: a_ik/d ; elsewhere a_ij - a_ik*b_j
 #pragma unroll
-        for (int rr = 0; rr < 64; ++rr) {
-          const float aik = rk[ih * 64 + rr];         // a_ik = a_ki by symmetry
+        for (int rr = 0; rr < RH; ++rr) {
+          const float aik = rk[ih * RH + rr];         // a_ik = a_ki by symmetry
           sreg[rr] = fmaf(-aik, mul, jk ? 0.f : sreg[rr]);
         }
         if (ih == kh) sreg[r] = jk ? -invd : bj;      // the pivot row itself
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(256) void gj_diag_kernel(const float* __restrict__ 
   }
   // P = inverse = -swept matrix; padding rows/columns of a partial block become identity again
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    const int i = ih * 64 + r;
+  for (int r = 0; r < RH; ++r) {
+    const int i = ih * RH + r;
     P[i * GJ_NB + j] = (i < bs && j < bs) ? -sreg[r] : (i == j ? 1.f : 0.f);
   }
 }
@@ -509,7 +513,9 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
       hipLaunchKernelGGL(gj_symm_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, A, D, k0, bs);
       DMP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(256), 0, s, A, D, k0, bs, P);
+    if (c->gj_diag_groups == 2) hipLaunchKernelGGL(gj_diag_kernel<2>, dim3(1), dim3(256), 0, s, A, D, k0, bs, P);
+    else if (c->gj_diag_groups == 8) hipLaunchKernelGGL(gj_diag_kernel<8>, dim3(1), dim3(1024), 0, s, A, D, k0, bs, P);
+    else hipLaunchKernelGGL(gj_diag_kernel<4>, dim3(1), dim3(512), 0, s, A, D, k0, bs, P);
     DMP_LAUNCH_CHECK();
     GemmArgs g{};
     // R = P * A[k0:k0+bs, :]

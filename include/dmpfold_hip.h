@@ -89,6 +89,8 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * "cluster_local" (default 1): the cluster kernels (sequence GRU, minimiser, tridiagonalisation) publish their
  * hand-off granules with plain stores when they find all their workgroups on one XCD (run-time check); 0 = always
  * agent-scope stores, the protocol that does not depend on placement.  Same bits, 1.84 against 2.8 us per GRU step.
+ * "gj_diag_groups" = 2 / 4 / 8: threads (x 128) of the one-workgroup diagonal sweep of the inverse; same bits; 4 is the
+ * default (8.9 against 10.0 ms per inverse at D = 6300 with 2, the form of rounds 1-3).
  * "gj_lds" = 1 / 2 stages the panels of the Gauss-Jordan trailing update through LDS (2: and fetches the tile before
  * the MFMA chain); same bits, measured slower than 0 at D = 6300 (12.1 / 11.1 against 10.8 ms), faster at
  * D = 10500 (30.4 against 32.6 ms with 2): an experiment knob.

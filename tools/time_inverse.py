@@ -15,6 +15,9 @@ from abi import Stages              # noqa: E402
 st = Stages(synth.synth_weights(0, coord_scale=5.0), max_L=500, max_N=8)
 # trailing update: 0 = operands from L2, 1 = panels staged in LDS, 2 = + tile fetched first (option gj_lds)
 modes = [int(x) for x in os.environ.get("GJ_LDS", "0").split(",")]
+if os.environ.get("GJ_DIAG"):       # row groups of the diagonal sweep: 2 (256 threads), 4 (512), 8 (1024)
+    st.eng.set_option("gj_diag_groups", int(os.environ["GJ_DIAG"]))
+    print("gj_diag_groups =", os.environ["GJ_DIAG"], flush=True)
 for L in [int(x) for x in sys.argv[1:]] or [82, 200, 300, 500]:
     D = 21 * L
     g = torch.Generator(device="cuda").manual_seed(L)
