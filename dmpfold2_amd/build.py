@@ -22,7 +22,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # coords.hip: no SLP vectoriser = no packed-f32 instructions.  The vectoriser turns the cross products of the
 # backbone kernel into v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0], which returns 0 in lanes 48..63 when
 # f16 / bf16 MFMA waves share the SIMD (tools/isa_lint.py guards every kernel against it).
-PER_FILE_FLAGS = {"coords.hip": ["-fno-slp-vectorize"]}
+# gru.hip: the same for the matrix-vector loop of seq_gru_kernel (v_pk_fma_f32 ... op_sel:[0,1,0] appeared when the gate
+# evaluation was spread over the lanes).
+PER_FILE_FLAGS = {"coords.hip": ["-fno-slp-vectorize"], "gru.hip": ["-fno-slp-vectorize"]}
 
 
 def per_file_flags(src: str) -> list:

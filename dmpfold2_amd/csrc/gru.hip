@@ -6,15 +6,17 @@
 
 namespace dmp {
 
-// Gates.  Default: the device library's expf / tanhf and an IEEE division, as in rounds 1-3 - 1.84 us per step.
-// SEQ_LIBM_GATES=0 builds gate_sigmoid / gate_tanh (common.h: hardware exponential and reciprocal with the product's
-// rounding error recovered and a polynomial for small tanh arguments) - 1.51 us per step.  Measured against the same
-// recurrence in float64 (tools/seq_gru_accuracy.py) the two are EQUALLY accurate (rms error 4.9e-8 / 6.0e-8 for
-// hgru / coord_gru either way; torch's own float32 CPU GRU: 4.2e-8 / 5.3e-8; the plain hardware forms 5.8e-8 / 7.0e-8).
-// But the reference computes with a 1-ulp expf / tanhf too, so the library forms agree with it bit for bit in most
-// gate evaluations, and on the expansive fixtures that shows: L=200, N=1000, 2 iterations against the oracle
-// |dconf| 2.4e-5 (library) against 9.6e-5 .. 1.4e-4 (fast forms; the oracle's own thread-count spread: 3.9e-5);
-// headline fixture 8.6e-4 against 1.03e-3 A.  Parity first: 0.33 us x 300 steps x 35 launches = 3.4 ms per prediction.
+// Gates.  Default: the device library's expf / tanhf and an IEEE division, as in rounds 1-3.  SEQ_LIBM_GATES=0 builds
+// gate_sigmoid / gate_tanh (common.h: hardware exponential and reciprocal with the product's rounding error recovered
+// and a polynomial for small tanh arguments).  Measured against the same recurrence in float64
+// (tools/seq_gru_accuracy.py) the two are EQUALLY accurate (rms error 4.9e-8 / 6.0e-8 for hgru / coord_gru either
+// way; torch's own float32 CPU GRU: 4.2e-8 / 5.3e-8; the plain hardware forms 5.8e-8 / 7.0e-8).  But the reference
+// computes with a 1-ulp expf / tanhf too, so the library forms agree with it bit for bit in most gate evaluations,
+// and on the expansive fixtures that shows: L=200, N=1000, 2 iterations against the oracle |dconf| 2.4e-5 (library)
+// against 9.6e-5 .. 1.4e-4 (fast forms; the oracle's own thread-count spread: 3.9e-5); headline fixture 8.6e-4
+// against 1.03e-3 A.  Parity first.  With one lane evaluating all six gates of its two units the library functions
+// cost 0.55 us of a 1.84 us step (fast forms: 1.51 us); with the evaluations spread over six lanes (below) a step is
+// 1.18 us with the library functions.
 #ifndef SEQ_LIBM_GATES
 #define SEQ_LIBM_GATES 1
 #endif
@@ -88,13 +90,18 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
   __syncthreads();
   const bool local = sh_local != 0;
   u64* hx_dir = a.hx + (int64_t)dir * 2 * HID2;
-  float gin[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  // Gates, one evaluation per lane: after the row reduction all 16 lanes of a row hold the six sums of its two hidden
+  // units, so lane kg < 6 evaluates gate kg >> 1 (r, z, n) of unit kg & 1 - the four sigmoids in ONE pass of the
+  // (long) library function, then the two tanh, with the r / z / n values moved between the lanes by DPP row shifts -
+  // instead of lane 0 evaluating all six one after the other.  Same functions on the same arguments: same bits.
+  const int my_gate = kg >> 1, my_uu = kg & 1;
+  const float bhsel = my_gate == 0 ? (my_uu ? bh[0][1] : bh[0][0]) : my_gate == 1 ? (my_uu ? bh[1][1] : bh[1][0])
+                                                                                   : (my_uu ? bh[2][1] : bh[2][0]);
+  float gin1 = 0.f;                                       // the one input projection this lane needs
   auto load_gi = [&](int step) {
-    if (kg == 0 && step < a.T) {
+    if (kg < 6 && step < a.T) {
       const int tn = dir ? (a.T - 1 - step) : step;
-      const float* gp = a.G + (int64_t)tn * 1536 + dir * 768 + u0;
-#pragma unroll
-      for (int gate = 0; gate < 3; ++gate) { gin[gate][0] = gp[gate * HID2]; gin[gate][1] = gp[gate * HID2 + 1]; }
+      gin1 = a.G[(int64_t)tn * 1536 + dir * 768 + u0 + my_gate * HID2 + my_uu];
     }
   };
   load_gi(0);
@@ -110,12 +117,10 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
     const int t = dir ? (a.T - 1 - step) : step;
     const unsigned epoch = (unsigned)step + 1u;
     u64* hx = hx_dir + (step & 1) * HID2;
-    // input projections of this step for the two units (needed by lanes kg == 0 only): loaded one step ahead - behind
-    // the previous step's publication, while that step's granules were being awaited - so that their L2 latency
-    // is off the step's critical path (round 3)
-    float gi[3][2];
-#pragma unroll
-    for (int gate = 0; gate < 3; ++gate) { gi[gate][0] = gin[gate][0]; gi[gate][1] = gin[gate][1]; }
+    // input projection of this step for this lane's gate and unit (lanes kg < 6): loaded one step ahead - behind the
+    // previous step's publication, while that step's granules were being awaited - so that its L2 latency is off the
+    // step's critical path (round 3)
+    const float gi1 = gin1;
     float hv[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -153,16 +158,20 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
 #undef SEQ_ROR
 #endif
     SEQ_T(1)
-    if (kg == 0) {
-#pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {
-        const float rg = sigmoidf_(gi[0][uu] + (acc[0][uu] + bh[0][uu]));
-        const float zg = sigmoidf_(gi[1][uu] + (acc[1][uu] + bh[1][uu]));
-        const float ng = tanhf_(gi[2][uu] + rg * (acc[2][uu] + bh[2][uu]));
-        const float hp = uu ? hp1 : hp0;
-        const float hn = (hp - ng) * zg + ng;
-        a.out[(int64_t)t * 512 + dir * HID2 + u0 + uu] = hn;
-        cluster_publish(&hx[u0 + uu], ((u64)epoch << 32) | (u64)__float_as_uint(hn), local);
+    {
+      const float accsel = my_gate == 0 ? (my_uu ? acc[0][1] : acc[0][0]) : my_gate == 1 ? (my_uu ? acc[1][1] : acc[1][0])
+                                                                                         : (my_uu ? acc[2][1] : acc[2][0]);
+      const float hsum = accsel + bhsel;
+      const float sg = sigmoidf_(gi1 + hsum);                                  // lanes 0..3: r0, r1, z0, z1
+      const float r_in = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sg), 0x114, 0xf, 0xf, true));   // row_shr:4: lanes 4, 5 get r0, r1
+      const float ng = tanhf_(gi1 + r_in * hsum);                              // lanes 4, 5: n0, n1
+      const float zg = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sg), 0x102, 0xf, 0xf, true));     // row_shl:2: lanes 0, 1 get z0, z1
+      const float nn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ng), 0x104, 0xf, 0xf, true));     // row_shl:4: lanes 0, 1 get n0, n1
+      if (kg < 2) {
+        const float hp = my_uu ? hp1 : hp0;
+        const float hn = (hp - nn) * zg + nn;
+        a.out[(int64_t)t * 512 + dir * HID2 + u0 + my_uu] = hn;
+        cluster_publish(&hx[u0 + my_uu], ((u64)epoch << 32) | (u64)__float_as_uint(hn), local);
       }
     }
     load_gi(step + 1);               // next step's input projections fly while this step's granules are gathered
