@@ -329,7 +329,10 @@ __global__ __launch_bounds__(256) void tridiag_step_kernel(double* __restrict__ 
 // XCD's L2 when the cluster finds itself on one XCD - common.h) and gathered with sc1 loads.
 // Round 2 measured this form at 5.8 us per step against 4.5 for the launches - with agent-scope (written-through)
 // stores; the XCD-local publication is what makes it pay.
-constexpr int TC_G = 32;
+#ifndef TC_G_N
+#define TC_G_N 32
+#endif
+constexpr int TC_G = TC_G_N;
 constexpr int TC_MAX_N = 640;      // (n / 32 rows + 4 vectors) of n doubles: 123 KB of LDS at 640
 static size_t tri_cluster_lds_bytes(int n) { return sizeof(double) * ((size_t)cdiv(n, TC_G) + 4) * (size_t)n; }
 typedef unsigned long long tc_u64;
