@@ -23,6 +23,7 @@ from __future__ import annotations
 import argparse
 import contextlib
 import json
+import hashlib
 import os
 import sys
 import time
@@ -86,24 +87,28 @@ def check_output_stems(targets):
 
 
 def scan_target(aln_path):
-    """(L, N) estimate of an alignment WITHOUT parsing it: the length of its first sequence line and the file
-    size divided by that line length.  Every rank scans every target (a stat and one line each) so that all
-    ranks compute the same partition; only the owner of a target reads and encodes it.  An unreadable file
-    scans as (0, 0): its owner reports the error when it reads it."""
+    """(L, N) of an alignment WITHOUT parsing it: the length of its first sequence line and the number of lines that
+    do not start with '>' (the rows the reference keeps, predict.py:100-104) - counted on the raw bytes, so a missing
+    final newline or trailing blanks on the first line do not change the count (a size / line-length estimate came
+    out one or more rows short for such files, and the engines were then built too small for their deepest
+    target).  Every rank scans every target so that all ranks compute the same partition; only the owner of a target
+    decodes and encodes it.  An unreadable file scans as (0, 0): its owner reports the error when it reads it."""
     try:
-        size = os.path.getsize(aln_path)
         a3m = aln_path.endswith(".a3m")
         with open(aln_path, "rb") as fh:
-            for raw in fh:
-                if raw.startswith(b">"):
-                    continue
-                line = raw.rstrip()
-                L = sum(1 for ch in line if not (a3m and 97 <= ch <= 122))
-                per_row = len(raw) + (16 if a3m else 0)      # a3m: a header line per sequence
-                return L, max(1, size // max(per_row, 1))
+            data = fh.read()
     except OSError:
-        pass
-    return 0, 0
+        return 0, 0
+    if not data:
+        return 0, 0
+    lines = data.count(b"\n") + (0 if data.endswith(b"\n") else 1)
+    headers = data.count(b"\n>") + (1 if data.startswith(b">") else 0)
+    L = 0
+    for raw in data.split(b"\n", 64):                    # the first sequence line is within the first few lines
+        if not raw.startswith(b">"):
+            L = sum(1 for ch in raw.rstrip() if not (a3m and 97 <= ch <= 122))
+            break
+    return L, max(1, lines - headers)
 
 
 def plan_shard(targets, iterations, rank, world):
@@ -153,11 +158,24 @@ class _SharedQueue:
     in the job's torch.distributed key-value store (host side; no collective, nothing on the data path).  A rank
     that finishes early simply keeps taking targets: no tail of idle GPUs behind a mis-estimated partition."""
 
-    def __init__(self, order, store, key="dmpfold_batch_next"):
-        self._order, self._store, self._key = list(order), store, key
+    _calls = {}          # per process: how many queues were made over each target list (ranks call run_batch in step)
+
+    def __init__(self, order, store, tag=""):
+        # one counter per JOB: a second run_batch over the same store must not continue the first one's counter (it
+        # would find it exhausted and silently predict nothing), so the key carries the target list's digest and the
+        # number of earlier queues this process made over that list - the same on every rank of an SPMD job
+        nth = _SharedQueue._calls.get(tag, 0)
+        _SharedQueue._calls[tag] = nth + 1
+        self._order, self._store, self._key = list(order), store, f"dmpfold_batch_next/{tag}/{nth}"
+        self._first = True
 
     def take(self):
         k = int(self._store.add(self._key, 1)) - 1
+        if self._first:
+            self._first = False
+            if k >= len(self._order) > 0:
+                raise RuntimeError(f"shared work queue {self._key!r} was already exhausted when this rank took its "
+                                   "first target: the ranks of the job are not calling run_batch in step")
         return self._order[k] if k < len(self._order) else None
 
 
@@ -184,7 +202,8 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     # sharding needs only (L, N) estimates from a header scan: a rank parses its own targets and nobody else's
     order, scans = cost_order(targets, iterations)
     if store is not None and world > 1:
-        queue = _SharedQueue(order, store)
+        digest = hashlib.sha1("\n".join(f"{a}\t{t}" for a, t in targets).encode()).hexdigest()[:16]
+        queue = _SharedQueue(order, store, f"{digest}.{iterations}.{minsteps}")
         mine_scans = scans                              # any target may come this way
     else:
         owned = plan_shard(targets, iterations, rank, world)
@@ -192,7 +211,7 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
         mine_scans = [scans[i] for i in owned]
     if not mine_scans:
         return 0, 0.0, []
-    # capacity of the engines from the scans (L is exact; N is exact for .aln files, an estimate for .a3m)
+    # capacity of the engines from the scans (L and N are exact: scan_target counts the rows on the raw bytes)
     any_a3m = any(a.endswith(".a3m") for a, _ in targets)
     max_L = max(8, max(L for L, _ in mine_scans))
     max_N = MAX_SEQS if any_a3m else max(1, min(MAX_SEQS, max(N for _, N in mine_scans)))
@@ -402,15 +421,14 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
+        job_store = shard.job_store(rank, world)
+        dist.init_process_group("nccl", store=job_store, rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     if world > 1:
         shard.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     targets = (read_target_list(args.list) if args.list else []) + expand_inputs(args.input)
     status = 0
-    store = None
-    if world > 1 and not args.static_shards:
-        store = torch.distributed.distributed_c10d._get_default_store()
+    store = job_store if (world > 1 and not args.static_shards) else None
     try:
         n, elapsed, _ = run_batch(targets, args.out_dir, args.iterations, args.minsteps,
                                   weights_file=args.model_weights, streams=args.streams,

@@ -139,6 +139,18 @@ def headline_fixture_weights(coord_fc, mds_scale, seed: int = 0, coord_scale: fl
     return sd
 
 
+def scale_block_norms(sd, blocks, factor):
+    """A copy of `sd` with the InstanceNorm gamma and beta of the trunk blocks in `blocks` (0 = stem,
+    1..16 = residual blocks) multiplied by `factor`: a mixed activation regime (some blocks add
+    O(1) terms to the residual stream, others O(factor) ones) for the parity fixtures."""
+    out = dict(sd)
+    for k in blocks:
+        p = "resnet.0.norm" if k == 0 else f"resnet.{k}.layer1.norm"
+        for sfx in (".weight", ".bias"):
+            out[p + sfx] = np.ascontiguousarray(np.array(sd[p + sfx]) * np.float32(factor), dtype=np.float32)
+    return out
+
+
 def synth_msa(L: int, N: int, seed: int = 0):
     """Synthetic alignment as a list of N strings of length L.
 

@@ -481,9 +481,42 @@ def test_scan_target_estimates_without_parsing(tmp_path):
     assert scan_target(str(p)) == (57, 123)
     a3m = tmp_path / "y.a3m"
     a3m.write_text(">q\nACDEFGHIKL\n>h1\nACdeDEFGHIKL\n>h2\nACDEFGHIKL\n")
-    L, N = scan_target(str(a3m))
-    assert L == 10 and 1 <= N <= 4
+    assert scan_target(str(a3m)) == (10, 3)
     assert scan_target(str(tmp_path / "missing.aln")) == (0, 0)
+    # the count must not depend on a final newline or on blanks behind the first row (a size / line-length
+    # estimate came out short - 49 and 42 for 50 rows - and the engines were built too small for that target)
+    rows = synth.synth_msa(31, 50, 9)
+    q = tmp_path / "no_newline.aln"
+    q.write_text("\n".join(rows))
+    assert scan_target(str(q)) == (31, 50)
+    r = tmp_path / "blanks.aln"
+    r.write_text(rows[0] + "      \n" + "\n".join(rows[1:]) + "\n")
+    assert scan_target(str(r)) == (31, 50)
+    h = tmp_path / "headers.aln"
+    h.write_text(">first\n" + "\n>x\n".join(rows) + "\n")
+    assert scan_target(str(h)) == (31, 50)
+
+
+def test_batch_engines_are_sized_for_a_file_without_final_newline(tmp_path, monkeypatch):
+    """run_batch sizes the engines from the scans; the deepest target of a rank, written without
+    a final newline, must still fit (it was reported as failed: 'alignment exceeds the pipeline capacity')."""
+    from dmpfold2_amd import batch
+    made = {}
+
+    class Sized(_FakePipeline):                          # _FakePipeline.submit refuses what exceeds (max_L, max_N)
+        def __init__(self, device, max_L, max_N, sd, streams=4):
+            made["cap"] = (max_L, max_N)
+            super().__init__(device, max_L, max_N, sd, streams=streams)
+
+    monkeypatch.setattr(batch, "Pipeline", Sized)
+    rows = synth.synth_msa(24, 50, 3)
+    deep = tmp_path / "deep.aln"
+    deep.write_text("\n".join(rows))                    # no final newline
+    small = tmp_path / "small.aln"
+    synth.write_aln(str(small), synth.synth_msa(20, 7, 4))
+    n, _, written = batch.run_batch([(str(small), None), (str(deep), None)], str(tmp_path / "out"), 0, 0,
+                                    state_dict={}, device="cpu")
+    assert n == 2 and len(written) == 2 and made["cap"] == (24, 50)
 
 
 def test_batch_unreadable_file_fails_that_target_only(tmp_path, monkeypatch):
@@ -540,8 +573,9 @@ import torch, torch.distributed as dist
 from dmpfold2_amd import batch
 import test_host_cpu as T
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
-store = dist.distributed_c10d._get_default_store()
+from dmpfold2_amd import shard
+store = shard.job_store(rank, world)            # public constructor; the same store carries the process group
+dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
 batch.Pipeline = T._FakePipeline
 if rank == 1:                                   # a slow rank: the others take what it does not get to
     real = T._FakePipeline.step
@@ -556,6 +590,13 @@ assert names == sorted(os.path.splitext(os.path.basename(t))[0] + ".pdb" for t, 
 assert all(len(g) > 0 for g in gathered)
 if rank == 0:
     print("taken per rank:", [len(g) for g in gathered])
+# ADVICE r03: a SECOND job over the same store starts its own counter (it used to find the first one's exhausted and
+# return (0, 0.0, []) without an error)
+dist.barrier()
+n2, _, outs2 = batch.run_batch(targets, {out!r} + "_again", 1, 0, state_dict={{}}, device="cpu", rank=rank, world=world, store=store)
+again = [None] * world
+dist.all_gather_object(again, len(outs2))
+assert sum(again) == len(targets), again
 dist.destroy_process_group()
 print("rank", rank, "ok", n)
 """
@@ -581,6 +622,35 @@ def test_shared_work_queue_over_gloo_world_size_2(tmp_path):
     taken = eval(r.stdout.split("taken per rank:")[1].splitlines()[0])
     assert sum(taken) == 40 and taken[0] > taken[1]
     assert len(os.listdir(tmp_path / "out")) == 40
+
+
+def test_core_slices_follow_the_numa_node_of_each_gpu(tmp_path):
+    """shard.plan_core_slices / gpu_local_cores on a made-up sysfs tree: 8 GPUs, four per NUMA node, 2 x 16 cores -
+    every rank gets 4 cores of ITS GPU's node, disjoint; a GPU whose node is not stated (-1) is left alone."""
+    from dmpfold2_amd import shard
+    assert shard.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    root = tmp_path / "sys"
+    bdfs = ["0000:%02x:00.0" % b for b in (0x05, 0x15, 0x65, 0x75, 0x85, 0x95, 0xe5, 0xf5)]
+    for i, b in enumerate(bdfs):
+        d = root / "bus/pci/devices" / b
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % (i // 4))
+    for node, text in ((0, "0-15\n"), (1, "16-31\n")):
+        d = root / "devices/system/node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(text)
+    local = [shard.gpu_local_cores(b, str(root)) for b in bdfs]
+    assert local[0] == list(range(16)) and local[7] == list(range(16, 32))
+    plan = shard.plan_core_slices(local, range(32))
+    assert plan[0] == [0, 1, 2, 3] and plan[3] == [12, 13, 14, 15] and plan[4] == [16, 17, 18, 19] and plan[7] == [28, 29, 30, 31]
+    assert sorted(c for p in plan for c in p) == list(range(32))
+    (root / "bus/pci/devices" / bdfs[2] / "numa_node").write_text("-1\n")
+    local = [shard.gpu_local_cores(b, str(root)) for b in bdfs]
+    plan = shard.plan_core_slices(local, range(32))
+    assert plan[2] is None and plan[0] == [0, 1, 2, 3, 4] and plan[1] == [5, 6, 7, 8, 9]
+    assert shard.gpu_local_cores("0000:aa:00.0", str(root)) == []          # no such device: unknown
+    # restricted affinity: only allowed cores are dealt out; too few of them -> leave the ranks alone
+    assert shard.plan_core_slices([list(range(16))] * 4, range(4)) == [None] * 4
 
 
 def test_rank_core_slices_are_disjoint_and_cover_the_machine():
