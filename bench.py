@@ -13,11 +13,14 @@ collective, only the timing barrier.  `--gpus N` with N > 1 starts the N ranks i
 (torch.distributed.run on 127.0.0.1) unless the process already runs under a launcher
 (RANK / WORLD_SIZE in the environment, as the driver's command line does).
 
-Rank 0 prints ONE JSON line: structures/s for the whole job, the roofline of the dominant kernel
-(conv5x5_f16x3, MFMA bound) measured with HIP events around every launch inside the timed
-region, the same workload with the exact-f32 convolution (`exact_f32`), a verification of the
-outputs against the reference's golden vector for this configuration (`verify`), and (N = 1 only)
-the CPU oracle timed on this host (`cpu_baseline`).
+Two arithmetic flavours are measured, each for the full --steps with its own warm-up and its own HIP-event
+intervals around every convolution launch:
+  * `value` / `roofline`: the default convolution, float32 products formed from two f16 pieces per operand
+    (22 significand bits, float32 accumulate) on the f16 matrix cores - tolerance-qualified float32-GRADE arithmetic;
+  * `value_f32` / `roofline_f32`: the exact-f32 MFMA convolution (conv_mode 1, bitwise an fmaf chain) - the
+    reference's own arithmetic type, priced against the 157.3 TFLOP/s f32 matrix-core peak.
+Rank 0 prints ONE JSON line with both, a verification of the outputs against the reference's golden vectors for this
+configuration (`verify`), and (N = 1 only) the CPU oracle timed on this host (`cpu_baseline`).
 """
 import argparse
 import ctypes as C
@@ -40,7 +43,6 @@ L_NS, N_NS, ITERS, MINSTEPS = 300, 2000, 10, 100
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (not the 2:1 sparse figure)
 CONV_FLOP_PER_LAUNCH = 2.0 * 128 * 512 * 25 * L_NS * L_NS     # one block's 5x5 conv
-EXACT_STEPS = 3                       # steps of the exact-f32 leg (each a full batch through the scheduler)
 STUB = os.environ.get("DMP_BENCH_STUB") == "1"   # CPU test of the launch / reduction logic (gloo, no GPU work)
 
 
@@ -261,7 +263,6 @@ def main(argv=None):
     ap.add_argument("--cpu-baseline", choices=("full", "sample", "none"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-f32 convolution leg")
-    ap.add_argument("--stagger", action="store_true", help="scheduler: space the engines' phases")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -305,7 +306,7 @@ def main(argv=None):
     S = max(1, args.streams)
     sd = synth.synth_weights(0, coord_scale=5.0)
     pipe = Pipeline(device, L_NS, N_NS, {k: torch.from_numpy(np.array(v)) for k, v in sd.items()},
-                    streams=S, stagger=args.stagger)
+                    streams=S)
 
     # B synthetic targets per step and rank, all resident in HBM before the clock starts
     B = args.batch if args.batch > 0 else 2 * S
@@ -321,39 +322,50 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    outs = pipe.run(targets[:args.warmup * B], ITERS, MINSTEPS)
-    sync_all()
-    for e in pipe.engines:
-        _lib.check(lib.dmp_profile_enable(e.ctx, 1, 16 * (ITERS + 1) * (args.steps * B // S + 2)))
-    t0 = time.perf_counter()
-    # the steps are pipelined: step k+1 is queued as soon as every target of step k has started on an
-    # engine; the clock stops when all K batches have completed (sync_all)
-    tickets = []
-    for k in range(args.steps):
-        lo = (args.warmup + k) * B
-        tickets += [pipe.submit(m, ITERS, MINSTEPS) for m in targets[lo:lo + B]]
-        pipe.pump()
-    pipe.drain()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    timed_outs = [pipe.result(t) for t in tickets]
-    outs += timed_outs
-    # the lane keeps two launches in flight: besides the per-launch duration, measure the time during
-    # which at least one launch runs (union of the HIP-event intervals of all engines)
-    iv = []
-    for e in pipe.engines:
+    host_cpu = {}                                        # conv_mode -> host CPU-seconds per structure of the timed region
+
+    def timed_leg(conv_mode):
+        """W warm-up steps, then exactly K timed steps of the scheduler in the given convolution arithmetic, bracketed
+        by barrier + synchronize; HIP events around every convolution launch of the timed region (recorded on the
+        launching streams).  -> (elapsed s, warm-up outputs, timed outputs, launches, mean launch ms, union ms)"""
+        for e in pipe.engines:
+            e.set_option("conv_mode", conv_mode)
+        warm = pipe.run(targets[:args.warmup * B], ITERS, MINSTEPS)
+        sync_all()
         cap = 16 * (ITERS + 1) * (args.steps * B // S + 2)
-        a, b, n = (C.c_float * cap)(), (C.c_float * cap)(), C.c_int()
-        _lib.check(lib.dmp_profile_conv_intervals(e.ctx, pipe.engines[0].ctx, a, b, cap, C.byref(n)))
-        iv += [(a[i], b[i]) for i in range(n.value)]
-    conv_union = interval_union(iv)
-    conv_tot, conv_cnt = 0.0, 0
-    for e in pipe.engines:
-        ms, n = C.c_float(), C.c_int()
-        _lib.check(lib.dmp_profile_conv_ms(e.ctx, C.byref(ms), C.byref(n)))
-        _lib.check(lib.dmp_profile_enable(e.ctx, 0, 0))
-        conv_tot += ms.value * n.value
-        conv_cnt += n.value
+        for e in pipe.engines:
+            _lib.check(lib.dmp_profile_enable(e.ctx, 1, cap))
+        cpu0 = time.process_time()                       # CPU time of this process, all threads
+        t0 = time.perf_counter()
+        # the steps are pipelined: step k+1 is queued as soon as every target of step k has started on an
+        # engine; the clock stops when all K batches have completed (sync_all)
+        tickets = []
+        for k in range(args.steps):
+            lo = (args.warmup + k) * B
+            tickets += [pipe.submit(m, ITERS, MINSTEPS) for m in targets[lo:lo + B]]
+            pipe.pump()
+        pipe.drain()
+        sync_all()
+        el = time.perf_counter() - t0
+        host_cpu[conv_mode] = (time.process_time() - cpu0) / max(1, len(tickets))
+        timed = [pipe.result(t) for t in tickets]
+        # the lane keeps two launches in flight: besides the per-launch duration, measure the time during
+        # which at least one launch runs (union of the HIP-event intervals of all engines)
+        iv = []
+        for e in pipe.engines:
+            a, b, n = (C.c_float * cap)(), (C.c_float * cap)(), C.c_int()
+            _lib.check(lib.dmp_profile_conv_intervals(e.ctx, pipe.engines[0].ctx, a, b, cap, C.byref(n)))
+            iv += [(a[i], b[i]) for i in range(n.value)]
+            _lib.check(lib.dmp_profile_enable(e.ctx, 0, 0))
+        union = interval_union(iv)
+        tot, cnt = sum(b_ - a_ for a_, b_ in iv), len(iv)
+        pipe.sync_check()
+        for e in pipe.engines:
+            e.set_option("conv_mode", 0)
+        return el, warm, timed, cnt, tot, union
+
+    elapsed, outs, timed_outs, conv_cnt, conv_tot, conv_union = timed_leg(0)
+    outs += timed_outs
     conv_ms = conv_tot / conv_cnt if conv_cnt else 0.0
     pipe.sync_check()
     ok = all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in outs)
@@ -489,22 +501,21 @@ def main(argv=None):
         finally:
             es.close()
 
-    # ---- the same workload with the exact-f32 convolution (conv_mode 1), EXACT_STEPS steps ------------
+    # ---- the same workload, same K steps and W warm-up steps, with the exact-f32 MFMA convolution (conv_mode 1): the
+    #      reference's own arithmetic type, measured exactly like the headline leg
     exact = None
-    exact_steps = max(1, min(EXACT_STEPS, args.steps))
+    f32_leg = None
     if not args.no_exact_f32:
-        for e in pipe.engines:
-            e.set_option("conv_mode", 1)
-        pipe.run(targets[:S], ITERS, MINSTEPS)          # warm-up of the exact path
-        sync_all()
-        t1 = time.perf_counter()
-        pipe.run(targets[first:first + exact_steps * B], ITERS, MINSTEPS)
-        sync_all()
-        el1 = time.perf_counter() - t1
-        pipe.sync_check()
-        for e in pipe.engines:
-            e.set_option("conv_mode", 0)
-        exact = el1
+        exact, warm1, timed1, cnt1, tot1, union1 = timed_leg(1)
+        ok = ok and all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in warm1 + timed1)
+        f32_leg = (cnt1, tot1, union1)
+        if timed1 and timed_outs:
+            d = (timed1[0][0][:, 1].double() - timed_outs[0][0][:, 1].double())
+            verify["f32_vs_f16x3_first_timed_target"] = {
+                "ca_rmsd_A": float((d ** 2).sum(-1).mean().sqrt()),
+                "max_dconf": float((timed1[0][1] - timed_outs[0][1]).abs().max()),
+                "note": "the two arithmetic flavours on the same target (10 + 100 on random weights: the minimiser on a "
+                        "collapsed trace amplifies rounding differences; informational)"}
 
     if distributed:
         vals = [elapsed, exact if exact is not None else 0.0]
@@ -564,7 +575,10 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (2xf16 split products, f32 accumulate)",
+            # `value` / `roofline`: float32-GRADE products from two f16 pieces per operand (22 significand bits) on the f16
+            # matrix cores, float32 accumulate - NOT the f32 instruction; `value_f32` / `roofline_f32` (below) are the
+            # same workload in exact f32 MFMA arithmetic, the reference's own type
+            "dtype": "f32-grade: 2xf16 split products (22-bit operands), f32 accumulate; exact f32 = value_f32",
             "data": "synthetic",
             "finite_outputs": ok,
             "verify": verify,
@@ -578,8 +592,8 @@ def main(argv=None):
                                       f"{S} HIP streams per GPU"},
             # The convolution forms each float32 product from 2-way f16 splits of its operands: 3 f16
             # MFMA products per float32 product, so the matrix-core ceiling for the ALGORITHMIC
-            # (float32) FLOPs is the dense f16 peak / 3.  The exact-f32 MFMA path (option
-            # conv_f32_exact) is bounded by PEAK_F32_MFMA_TFLOPS; its whole-job rate is `exact_f32`.
+            # (float32) FLOPs is the dense f16 peak / 3.  The exact-f32 MFMA path (conv_mode 1) is bounded by
+            # PEAK_F32_MFMA_TFLOPS: `value_f32` / `roofline_f32`.
             "roofline": {"kernel": "conv5x5_f16x3_kernel (5x5 conv 128->512 + bias + 4-way maxout, "
                                    "float32 products from 3 f16 MFMA products, float32 accumulate)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
@@ -597,20 +611,48 @@ def main(argv=None):
                          "peak_f16_mfma_tflops": PEAK_F16_MFMA_TFLOPS,
                          "peak_f32_mfma_tflops": PEAK_F32_MFMA_TFLOPS},
         }
+        # what the scheduler costs the host: CPU time of the whole process (scheduler thread, runtime helper threads)
+        # over the timed region per structure; the scheduler sleeps on blocking-sync events when nothing can be issued
+        line["host_cpu_s_per_structure"] = host_cpu.get(0)
+        if 1 in host_cpu:
+            line["host_cpu_s_per_structure_f32"] = host_cpu.get(1)
         if host is not None:
             line["host_ms_per_target"] = host
         if single is not None:
             line["single_target"] = single
         if exact is not None:
-            v = world * exact_steps * B / exact
-            line["exact_f32"] = {
-                "value": v, "unit": "structures/s", "steps": exact_steps, "conv_mode": 1,
-                "note": "same workload and scheduler with the exact-f32 MFMA convolution "
-                        "(v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); the headline uses float32-grade "
-                        "products from two f16 pieces per operand (22 significand bits, f32 accumulate)",
-                "conv_tflops_sustained": v / world * 16 * (ITERS + 1) * CONV_FLOP_PER_LAUNCH / 1e12,
-                "frac_of_f32_mfma_peak": v / world * 16 * (ITERS + 1) * CONV_FLOP_PER_LAUNCH / 1e12
-                                         / PEAK_F32_MFMA_TFLOPS}
+            cnt1, tot1, union1 = f32_leg
+            eff1 = union1 / cnt1 if cnt1 else 0.0
+            ach1 = CONV_FLOP_PER_LAUNCH / (eff1 * 1e-3) / 1e12 if eff1 > 0 else 0.0
+            traffic1, traffic1_current = None, None
+            pmc1 = os.path.join(ROOT, "profiles", "conv5x5_f32_pmc.json")
+            if os.path.exists(pmc1):
+                try:
+                    pj = json.load(open(pmc1))
+                    traffic1 = pj.get("hbm_bytes_per_launch")
+                    if pj.get("kernel_source_sha256"):
+                        src = os.path.join(ROOT, pj.get("kernel_source", "dmpfold2_amd/csrc/trunk.hip"))
+                        traffic1_current = hashlib.sha256(open(src, "rb").read()).hexdigest() == pj["kernel_source_sha256"]
+                except Exception:
+                    traffic1 = None
+            v = world * args.steps * B / exact
+            line["value_f32"] = v
+            line["ms_per_step_f32"] = exact / args.steps * 1e3
+            line["dtype_f32"] = "f32 (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain)"
+            line["roofline_f32"] = {
+                "kernel": "conv5x5_maxout_kernel (5x5 conv 128->512 + bias + 4-way maxout on the f32 matrix cores)",
+                "bound": "mfma", "achieved": ach1, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach1 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic1,
+                "traffic_source": "profiles/conv5x5_f32_pmc.json (rocprofv3 --pmc passes of single launches; a separate "
+                                  "profiler run)",
+                "traffic_taken_from_this_kernel_source": traffic1_current,
+                "launches_timed": cnt1, "avg_launch_ms": tot1 / cnt1 if cnt1 else 0.0,
+                "launches_in_flight": tot1 / union1 if union1 > 0 else 0.0, "chip_ms_per_launch": eff1,
+                "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH,
+                "whole_job_conv_tflops": v / world * 16 * (ITERS + 1) * CONV_FLOP_PER_LAUNCH / 1e12,
+                "note": "same workload, scheduler, --steps and --warmup as `value`, convolutions in conv_mode 1; "
+                        "achieved = algorithmic FLOP per launch / chip time per launch (union of the HIP-event "
+                        "intervals / launches), as for `roofline`"}
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             line["cpu_baseline"] = cpu_baseline(mode)

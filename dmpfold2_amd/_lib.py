@@ -22,7 +22,6 @@ SIGNATURES = {
     "dmp_ctx_device_bytes": (_i64, [_vp]),
     "dmp_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dmp_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
-    "dmp_clear_faults": (_i, [_vp, _vp]),
     "dmp_weights_set": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
     "dmp_weights_finalize": (_i, [_vp]),
     "dmp_weights_share": (_i, [_vp, _vp]),
@@ -47,37 +46,23 @@ SIGNATURES = {
     "dmp_refine_coords": (_i, [_vp, _fp, _i, _i, _vp]),
     "dmp_ca_to_backbone": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_predict": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i, _fp, _fp, _vp]),
-    "dmp_predict_begin": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i, _vp]),
-    "dmp_predict_pass": (_i, [_vp, _vp]),
     "dmp_predict_end": (_i, [_vp, _fp, _fp, _vp]),
     "dmp_predict_next_unit": (_i, [_vp]),
     "dmp_predict_group_vgru": (_i, [C.POINTER(_vp), _i]),
     "dmp_predict_group_riders": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
     "dmp_predict_chain_issued": (_i, [_vp]),
-    "dmp_predict_detach_group_chain": (_i, [_vp]),
-    "dmp_predict_issue_group_chain": (_i, [_vp, _vp]),
-    "dmp_predict_chain_on_own_stream": (_i, [_vp]),
     "dmp_predict_set_vgru_result": (_i, [_vp, _fp, _vp]),
-    "dmp_predict_end_refine": (_i, [_vp, _vp]),
     "dmp_predict_issue_unit": (_i, [_vp, _vp]),
     "dmp_ctx_pending": (_i, [_vp]),
     "dmp_predict_begin_units": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i]),
-    "dmp_predict_ahead_begin": (_i, [_vp, _fp, _i, _i]),
-    "dmp_predict_ahead_left": (_i, [_vp]),
-    "dmp_predict_ahead_issue": (_i, [_vp, _vp]),
-    "dmp_lane_create": (_i, [C.POINTER(_vp)]),
-    "dmp_lane_destroy": (None, [_vp]),
-    "dmp_ctx_set_lane": (_i, [_vp, _vp]),
+    "dmp_ctx_share_lane": (_i, [_vp, _vp]),
     "dmp_sync_faults": (_i, [_vp, _vp, C.POINTER(_i)]),
-    "dmp_sync_check": (_i, [_vp, _vp]),
     "dmp_debug_fetch": (_i64, [_vp, C.c_char_p, _fp, _i64, _vp]),
     "dmp_profile_enable": (_i, [_vp, _i, _i]),
-    "dmp_profile_conv_ms": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(_i)]),
     "dmp_profile_conv_intervals": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
-    "dmp_time_conv5x5": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_float), _vp]),
 }
 
-ABI_VERSION = 2      # include/dmpfold_hip.h DMP_ABI_VERSION
+ABI_VERSION = 3      # include/dmpfold_hip.h DMP_ABI_VERSION
 
 _lib = None
 

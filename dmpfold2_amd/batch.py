@@ -230,10 +230,6 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
                 # every copy of this front end goes through its own (non-blocking) stream: nothing is ever enqueued on
                 # the process's default stream while the engines run
                 copy_stream = torch.cuda.Stream(device=dev)
-            if os.environ.get("DMP_BATCH_LANE_TRACE"):      # developer diagnostic: HIP-event interval of every convolution
-                from . import _lib
-                for e in pipe.engines:
-                    _lib.check(pipe.lib.dmp_profile_enable(e.ctx, 1, 176 * (len(targets) // max(1, int(streams)) + 8)))
         return pipe
 
     done = []                                           # completed on the GPU AND copied to the host, not yet written
@@ -313,17 +309,6 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
     # and writing it - is done ONE item per scheduling round in which nothing could be issued (the GPU has work
     # queued), never while units are waiting to be issued: the targets of a group finish and start together, and
     # 4 x (0.6 + 1.5) ms of host work in front of the next group's first launches is GPU idle time.
-    trace = {"take": 0.0, "finish": 0.0, "step": 0.0, "rounds": 0, "idle_rounds": 0} if os.environ.get("DMP_BATCH_TRACE") else None
-    if trace is not None:                               # developer diagnostic: where the host loop spends its time
-        def timed(fn, key):
-            def w(*a):
-                t = time.perf_counter()
-                try:
-                    return fn(*a)
-                finally:
-                    trace[key] += time.perf_counter() - t
-            return w
-        take_one, finish = timed(take_one, "take"), timed(finish, "finish")
     while True:
         if pipe is None or not pipe.busy():
             # nothing left to issue: refill from the queue, else write what has completed, else wait for the GPU
@@ -344,13 +329,7 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
                 if exhausted or not room():
                     break
                 continue
-        if trace is not None:
-            t_s = time.perf_counter()
         progressed = pipe.step()
-        if trace is not None:
-            trace["step"] += time.perf_counter() - t_s
-            trace["rounds"] += 1
-            trace["idle_rounds"] += 0 if progressed else 1
         if not progressed:
             for t in pipe.poll():
                 start_copy_back(t)
@@ -374,20 +353,6 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
             else:
                 outputs.append(write_result(out_dir, aln_path, res[t][0], res[t][1], alnmat, fmt))
     elapsed = time.perf_counter() - t0
-    if pipe is not None and os.environ.get("DMP_BATCH_LANE_TRACE"):
-        import ctypes as C
-        from . import _lib
-        torch.cuda.synchronize()
-        capn = 176 * (len(targets) // max(1, int(streams)) + 8)
-        rows = []
-        for k, e in enumerate(pipe.engines):
-            a, b, n = (C.c_float * capn)(), (C.c_float * capn)(), C.c_int()
-            _lib.check(pipe.lib.dmp_profile_conv_intervals(e.ctx, pipe.engines[0].ctx, a, b, capn, C.byref(n)))
-            rows += [(a[i], b[i], k) for i in range(n.value)]
-        np.save(os.environ["DMP_BATCH_LANE_TRACE"], np.array(sorted(rows), dtype=np.float64))
-    if trace is not None:
-        print("dmpfold-batch trace: %.2f s in all; take %.3f, finish %.3f, step %.3f s; %d rounds, %d idle" % (
-            elapsed, trace["take"], trace["finish"], trace["step"], trace["rounds"], trace["idle_rounds"]), file=sys.stderr)
     if pipe is not None:
         pipe.close()
     if failed:

@@ -31,13 +31,6 @@ static int dev_alloc(std::vector<void*>& pool, int64_t& bytes, T** out, int64_t 
   const size_t sz = sizeof(T) * (size_t)(count > 0 ? count : 1);
   hipError_t e = hipMalloc(&p, sz);
   if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
-  // DMP_POISON=1 (tests): fill every allocation with 0xFF bytes (NaN as float / double) so that a
-  // kernel reading workspace it has not written shows up as a result change
-  static const bool poison = getenv("DMP_POISON") && getenv("DMP_POISON")[0] == '1';
-  if (poison) {
-    e = hipMemset(p, 0xFF, sz);
-    if (e != hipSuccess) return hip_fail(e, "hipMemset", __FILE__, __LINE__);
-  }
   pool.push_back(p);
   bytes += (int64_t)sz;
   *out = (T*)p;
@@ -220,6 +213,32 @@ static int pack_weights(dmp_ctx* c) {
     if ((rc = upload(pool, bytes, &W.stem_gamma, H["resnet.0.norm.weight"]))) return rc;
     if ((rc = upload(pool, bytes, &W.stem_beta, H["resnet.0.norm.bias"]))) return rc;
   }
+  // Activation scales of the split-f16 convolution (conv_f16.h).  The input of block k is the residual stream
+  // x_{k-1} = x_{k-2} + y (cSE + sSE) with y = InstanceNorm output (per channel: mean beta, deviation |gamma|) and both
+  // gates in (0, 1), so |x_{k-1}| <= B_{k-1} = B_{k-2} + 2 max_c(|beta_c| + R |gamma_c|) as long as no normalised
+  // value exceeds R deviations (R = 16; a plane of L^2 near-Gaussian values reaches 4-6).  The pieces are taken of
+  // 2^e x with the largest e that keeps B 2^e <= 32768: the bulk of the activations then has normal low pieces
+  // whether the weights put the trunk at 1e-3 or at 1e4, the device-side range check (|2^e x| < 60000) keeps its
+  // meaning, and a trunk that would have left the f16 range unscaled is scaled DOWN instead of faulting.
+  {
+    auto reach = [&](const std::vector<float>& g, const std::vector<float>& b) {
+      float m = 0.f;
+      for (size_t q = 0; q < g.size(); ++q) m = std::fmax(m, std::fabs(b[q]) + 16.0f * std::fabs(g[q]));
+      return m;
+    };
+    float bound = reach(H["resnet.0.norm.weight"], H["resnet.0.norm.bias"]);
+    for (int k = 1; k <= NBLOCK; ++k) {
+      float sc = 1.f;
+      if (bound > 0.f && std::isfinite(bound)) {
+        int e;
+        std::frexp(bound, &e);                       // bound = f 2^e, f in [0.5, 1)
+        sc = std::ldexp(1.0f, std::max(-40, std::min(40, 15 - e)));      // bound * sc in [16384, 32768)
+      }
+      W.blk[k - 1].x_scale = sc;
+      const std::string p = "resnet." + std::to_string(k);
+      bound += 2.0f * reach(H[p + ".layer1.norm.weight"], H[p + ".layer1.norm.bias"]);
+    }
+  }
   // residual blocks
   for (int k = 1; k <= NBLOCK; ++k) {
     const std::string p = "resnet." + std::to_string(k);
@@ -297,7 +316,7 @@ static int trunk_open(dmp_ctx* c, const float* z0, const float* dmap, int L, hip
   if ((rc = stem_update_padded(c, z0, dmap, L, c->trunk_cur, s))) return rc;
   if (c->conv_mode != 1) {
     // f16 / bf16 pieces of the stem output; every block's norm kernel then emits those of its output
-    if ((rc = act_split(c, c->trunk_cur, L, s))) return rc;
+    if ((rc = act_split(c, c->trunk_cur, L, 1, s))) return rc;
     c->xsplit_current = true;
   }
   return DMP_OK;
@@ -396,13 +415,11 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
     static std::atomic<int> next_xcd{0};             // spread the minimiser clusters of the contexts over the XCDs
     c->refine_xcd = next_xcd.fetch_add(1) & 7;
     // the contexts of a process spread their sequence-GRU clusters over the XCD pairs (four engines: 0-1, 2-3, 4-5, 6-7)
-    // instead of all sitting on XCDs 0 and 1; DMP_SEQ_XCD_SPREAD=0 restores that
-    static const bool spread = !(getenv("DMP_SEQ_XCD_SPREAD") && getenv("DMP_SEQ_XCD_SPREAD")[0] == '0');
-    c->seq_xcd0 = spread ? (2 * c->refine_xcd) & 7 : 0;
+    // instead of all sitting on XCDs 0 and 1 (+0.5 % in the scheduler, round 3)
+    c->seq_xcd0 = (2 * c->refine_xcd) & 7;
   }
   c->max_N = max_N;
   c->max_passes = 128;
-  if (const char* e = getenv("DMP_TRIDIAG_CLUSTER")) c->tridiag_cluster = e[0] != '0';     // default of the option
   const int64_t L = max_L, N = max_N, D = NS * L, LL = L * L;
   // vertical-GRU state: the members and riders of a group side by side (up to 8 alignments of max_L columns,
   // 32-column tiles)
@@ -430,6 +447,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
       A_(hH[l][p], (int64_t)2 * WIDTH * Lb);
     }
   A_(vgru_run, 256);                 // VRun (legacy) / VGroupRec (vgru.hip)
+  A_(vgru_sync, 2048);               // VPSync (vgru.hip)
   A_(vout, L * WIDTH);
   A_(seq_g, L * 1536);
   A_(seq_a, L * WIDTH);
@@ -487,11 +505,6 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   return DMP_OK;
 }
 
-int dmp_clear_faults(dmp_ctx* ctx, void* stream) {
-  DMP_ARG(ctx != nullptr, "null context");
-  DMP_HIP(hipMemsetAsync(ctx->seq_abort, 0, 2 * sizeof(int), (hipStream_t)stream));
-  return DMP_OK;
-}
 
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   DMP_ARG(ctx && name, "null argument");
@@ -501,9 +514,9 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "tridiag_cluster") { ctx->tridiag_cluster = value ? 1 : 0; return DMP_OK; }
   if (k == "cluster_local") { ctx->cluster_local = value ? 1 : 0; return DMP_OK; }
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
-  if (k == "vgru_legacy") { ctx->vgru_legacy = value ? 1 : 0; return DMP_OK; }
-  if (k == "gj_lds") { DMP_ARG(value >= 0 && value <= 2, "gj_lds must be 0, 1 or 2"); ctx->gj_lds = value; return DMP_OK; }
   if (k == "gj_diag_groups") { DMP_ARG(value == 2 || value == 4 || value == 8, "gj_diag_groups must be 2, 4 or 8"); ctx->gj_diag_groups = value; return DMP_OK; }
+  if (k == "act_scaling") { ctx->act_scaling = value ? 1 : 0; return DMP_OK; }
+  if (k == "vgru_persistent") { ctx->vgru_persist = value ? 1 : 0; return DMP_OK; }
   if (k == "conv_mode") {
     DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
     ctx->conv_mode = value;
@@ -518,12 +531,20 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   const std::string k(name);
   if (k == "conv_mode") { *h_value = ctx->conv_mode; return DMP_OK; }
   if (k == "conv_f32_exact") { *h_value = ctx->conv_mode == 1; return DMP_OK; }
+  if (k == "act_scaling") { *h_value = ctx->act_scaling; return DMP_OK; }
+  if (k == "vgru_persistent") { *h_value = ctx->vgru_persist && ctx->vgru_persist_ok; return DMP_OK; }
+  if (k.rfind("act_scale_log2_block", 0) == 0) {      // read-only: log2 of the piece scale of block 1..16's input
+    const int b = atoi(k.c_str() + 20);
+    DMP_ARG(b >= 1 && b <= NBLOCK && ctx->W.ready, "act_scale_log2_block<k>: k in 1..16, weights finalized");
+    int e;
+    std::frexp(ctx->W.blk[b - 1].x_scale, &e);
+    *h_value = e - 1;
+    return DMP_OK;
+  }
   if (k == "tridiag_single") { *h_value = ctx->tridiag_single; return DMP_OK; }
   if (k == "tridiag_cluster") { *h_value = ctx->tridiag_cluster; return DMP_OK; }
   if (k == "cluster_local") { *h_value = ctx->cluster_local; return DMP_OK; }
   if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
-  if (k == "vgru_legacy") { *h_value = ctx->vgru_legacy; return DMP_OK; }
-  if (k == "gj_lds") { *h_value = ctx->gj_lds; return DMP_OK; }
   if (k == "gj_diag_groups") { *h_value = ctx->gj_diag_groups; return DMP_OK; }
   set_error("unknown option %s", name);
   return DMP_ERR_ARG;
@@ -540,25 +561,6 @@ int dmp_sync_faults(dmp_ctx* ctx, void* stream, int* h_bits) {
   return DMP_OK;
 }
 
-int dmp_sync_check(dmp_ctx* ctx, void* stream) {
-  int flag = 0;
-  const int rc = dmp_sync_faults(ctx, stream, &flag);
-  if (rc) return rc;
-  if (flag & DMP_FAULT_BAD_CODE) {
-    set_error("index out of range in self: the alignment holds a residue code above 21 "
-              "(a character outside the alignment alphabet)");
-    return DMP_ERR_ARG;
-  }
-  if (flag) {
-    set_error("device-side fault (results invalid, outputs set to NaN):%s%s%s",
-              (flag & DMP_FAULT_SEQ_HANDOFF) ? " sequence-GRU workgroup hand-off timed out;" : "",
-              (flag & DMP_FAULT_REFINE_HANDOFF) ? " minimiser workgroup hand-off timed out;" : "",
-              (flag & DMP_FAULT_F16_RANGE) ? " an activation left the f16 range of the split-product convolution "
-                                             "(use option conv_f32_exact or conv_mode=2);" : "");
-    return DMP_ERR_FAULT;
-  }
-  return DMP_OK;
-}
 
 void dmp_ctx_destroy(dmp_ctx* c) {
   if (!c) return;
@@ -828,12 +830,16 @@ int dmp_ca_to_backbone(dmp_ctx* ctx, const float* d_ca, const float* d_conf_logi
   return ca_to_backbone(d_ca, d_conf_logit, L, d_coords, d_conf_out, STREAM);
 }
 
+static int predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
+                         int Lt, int nloops, int refine_steps, void* stream);
+
 int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca, int Lt,
                 int nloops, int refine_steps, float* d_coords, float* d_conf, void* stream) {
-  int rc = dmp_predict_begin(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps, stream);
+  // begin_units + every front-end unit (the features on the context's side stream) + every unit of every pass + end
+  int rc = predict_begin(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps, stream);
   if (rc) return rc;
   while (ctx->passes_done <= ctx->run_nloops)
-    if ((rc = dmp_predict_pass(ctx, stream))) return rc;
+    if ((rc = dmp_predict_issue_unit(ctx, stream))) return rc;
   return dmp_predict_end(ctx, d_coords, d_conf, stream);
 }
 
@@ -855,10 +861,6 @@ static int record_unit(dmp_ctx* c, hipStream_t s) {
 // serial diagonal blocks) and the vertical GRU (bound by L1 misses) are independent and use different
 // units of the chip, so the features run on the context's side stream and their units alternate with
 // the GRU's: one unit of each kind is in flight at a time.  They join before the static stem.
-static bool side_stream_enabled() {
-  static const bool off = getenv("DMP_NO_SIDE_STREAM") && getenv("DMP_NO_SIDE_STREAM")[0] == '1';   // A/B timing
-  return !off;
-}
 
 // The launch chain of the vertical-GRU group `c` leads, chunk j of c->fe_vgru (a real group's chain is ONE chunk),
 // enqueued on s; behind the last chunk the members' results and the event every member's last front-end unit waits for.
@@ -909,7 +911,7 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   // Only the single-target entry (dmp_predict_begin) forks: a scheduler that drives several contexts has
   // other targets to fill the machine, and a second stream per context would push the process past the
   // hardware queues (with 4 engines the unused side streams alone cost 10 % of the throughput).
-  const bool fork = c->fe_side && c->fe_inv > 0 && side_stream_enabled();
+  const bool fork = c->fe_side && c->fe_inv > 0;
   if (fork && !c->side_stream) {
     hipStream_t st;
     DMP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -926,10 +928,8 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
       DMP_HIP(hipStreamWaitEvent(side, (hipEvent_t)c->side_ev[0], 0));
     }
     used = side;
-    if (!c->fe_have_features) {
-      rc = msa_weights(c, d_msa, N, L, c->w, side);
-      if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, side);
-    }
+    rc = msa_weights(c, d_msa, N, L, c->w, side);
+    if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, side);
   } else if (u <= c->fe_inv + c->fe_vgru) {
     // alternate GRU chunk / inverse chunk while both kinds remain
     const int k = u - 1, m = std::min(c->fe_inv, c->fe_vgru);
@@ -959,15 +959,14 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
     const float* inv = N > 1 ? c->cov : nullptr;
     const float* contacts = N > 1 ? c->contacts : nullptr;
     if (fork) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->side_ev[1], 0));
-    if (c->vg_leader && (c->vg_leader != c || c->vg_detached)) {
-      // this member's vertical GRU ran in its leader's chain, on the leader's stream - or, detached
-      // (dmp_predict_detach_group_chain), on the stream the chain was issued on, which the leader waits for too
+    if (c->vg_leader && c->vg_leader != c) {
+      // this member's vertical GRU ran in its leader's chain, on the leader's stream
       dmp_ctx* lead = c->vg_leader;
       DMP_ARG(vg_done(lead), "the vertical-GRU chain of this context's group has not been issued to its end yet "
                              "(dmp_predict_next_unit answers DMP_UNIT_WAIT until it has)");
       DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)lead->vg_done_ev, 0));
       lead->vg_waiters--;
-      if (lead != c) c->vg_leader = nullptr;
+      c->vg_leader = nullptr;
     }
     if (c->ext_vout && c->ext_vout_ev) DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->ext_vout_ev, 0));
     rc = gru_bidir(c, 0, c->ext_vout ? c->ext_vout : c->vout, L, c->seq_b, s);
@@ -998,7 +997,6 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->vg_members.clear();
   c->vg_riders.clear();
   c->vg_done_issued = false;
-  c->vg_detached = 0;
   c->ext_vout = nullptr;
   c->ext_vout_ev = nullptr;
   c->last_L = L;
@@ -1011,64 +1009,15 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->run_msa = d_msa;
   c->run_template = d_template_ca;
   c->fe_next = 0;
-  {
-    static const bool side_units = getenv("DMP_SIDE_UNITS") && getenv("DMP_SIDE_UNITS")[0] == '1';   // experiment
-    c->fe_side = side_units;
-  }
+  c->fe_side = false;
   c->fe_inv = N > 1 ? cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
   c->fe_vgru = cdiv(N + 1, FE_VGRU_STEPS);
-  // features computed ahead for exactly this alignment (dmp_predict_ahead_*): nothing of them is left to do; ahead
-  // work for another alignment, or unfinished work, is dropped (the buffers are simply recomputed)
-  c->fe_have_features = c->ahead_msa == d_msa && c->ahead_N == N && c->ahead_L == L && c->ahead_total > 0 &&
-                        c->ahead_next == c->ahead_total;
-  if (c->fe_have_features) c->fe_inv = 0;
-  c->ahead_msa = nullptr;
-  c->ahead_total = c->ahead_next = 0;
   c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
   return DMP_OK;
 }
 
-int dmp_predict_ahead_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L) {
-  CHECK_CAP(L, N);
-  DMP_ARG(d_msa != nullptr, "null argument");
-  DMP_ARG(N >= 1 && L >= 8, "need N >= 1 and L >= 8 (got N=%d L=%d)", N, L);
-  dmp_ctx* c = ctx;
-  DMP_ARG(c->fe_total > 0 && c->fe_next >= c->fe_total,
-          "features ahead need a prediction in flight that is past its front end (its static stem has consumed the "
-          "feature buffers)");
-  c->ahead_msa = d_msa;
-  c->ahead_N = N;
-  c->ahead_L = L;
-  c->ahead_next = 0;
-  c->ahead_total = N > 1 ? 1 + cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
-  return DMP_OK;
-}
-
-int dmp_predict_ahead_left(const dmp_ctx* ctx) { return ctx ? ctx->ahead_total - ctx->ahead_next : 0; }
-
-int dmp_predict_ahead_issue(dmp_ctx* ctx, void* stream) {
-  DMP_ARG(ctx != nullptr, "null context");
-  dmp_ctx* c = ctx;
-  DMP_ARG(c->ahead_msa && c->ahead_next < c->ahead_total, "no feature unit left to issue ahead");
-  DMP_ARG(c->fe_next >= c->fe_total, "the prediction in flight is still in its front end");
-  hipStream_t s = STREAM;
-  const int N = c->ahead_N, L = c->ahead_L, u = c->ahead_next;
-  int rc;
-  if (u == 0) {
-    rc = msa_weights(c, c->ahead_msa, N, L, c->w, s);
-    if (!rc) rc = cov_build(c, c->ahead_msa, c->w, N, L, c->cov, s);
-  } else {
-    const int j = u - 1;
-    rc = spd_inverse_steps(c, c->cov, NS * L, j * FE_INV_BLOCKS, (j + 1) * FE_INV_BLOCKS, s);
-    if (!rc && u == c->ahead_total - 1) rc = dca_contacts(c, c->cov, L, c->contacts, s);
-  }
-  if (rc) return rc;
-  c->ahead_next = u + 1;
-  return record_unit(c, s);
-}
-
-int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
-                      int Lt, int nloops, int refine_steps, void* stream) {
+static int predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
+                         int Lt, int nloops, int refine_steps, void* stream) {
   int rc = dmp_predict_begin_units(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps);
   if (!rc) ctx->fe_side = true;
   while (!rc && ctx->fe_next < ctx->fe_total) rc = issue_front_end_unit(ctx, STREAM);
@@ -1087,7 +1036,6 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n) {
             "member %d: group its vertical GRU right after dmp_predict_begin_units, before any unit is issued", i);
     DMP_ARG(c->device == lead->device, "the members of a group must live on one GPU");
     DMP_ARG(c->W.ready && c->W.hash == lead->W.hash, "member %d does not hold the leader's weights", i);
-    DMP_ARG(!c->vgru_legacy, "member %d runs the legacy vertical GRU (option vgru_legacy): no group form", i);
     cols += round_up(c->last_L, 32);
     maxN = std::max(maxN, c->last_N);
   }
@@ -1111,8 +1059,8 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n) {
 int dmp_predict_group_riders(dmp_ctx* lead, int n, const uint8_t* const* d_msas, const int* Ns, const int* Ls,
                              float* const* d_outs) {
   DMP_ARG(lead && d_msas && Ns && Ls && d_outs && n >= 1, "bad argument");
-  DMP_ARG(lead->vg_leader == lead && lead->fe_next == 0 && !lead->vg_detached && lead->vg_riders.empty(),
-          "add riders right after dmp_predict_group_vgru, once, before the leader issues a unit or its chain is detached");
+  DMP_ARG(lead->vg_leader == lead && lead->fe_next == 0 && lead->vg_riders.empty(),
+          "add riders right after dmp_predict_group_vgru, once, before the leader issues a unit");
   DMP_ARG((int)lead->vg_members.size() + n <= 8, "a chain serves at most 8 alignments (%d members + %d riders)",
           (int)lead->vg_members.size(), n);
   int cols = 0, maxN = 0;
@@ -1141,31 +1089,6 @@ int dmp_predict_chain_issued(const dmp_ctx* ctx) {
   return ctx && ctx->vg_leader == ctx && vg_done(ctx) ? 1 : 0;
 }
 
-int dmp_predict_detach_group_chain(dmp_ctx* lead) {
-  DMP_ARG(lead != nullptr, "null context");
-  DMP_ARG(lead->vg_leader == lead && lead->vg_members.size() > 1 && lead->fe_next == 0 && !lead->vg_detached,
-          "detach the chain right after dmp_predict_group_vgru (two or more members), before the leader issues a unit");
-  lead->vg_detached = 1;
-  lead->vg_waiters = (int)lead->vg_members.size();      // the leader waits for the chain's event like every member
-  lead->fe_vgru = 0;
-  lead->fe_total = 1 + lead->fe_inv + 1;
-  return DMP_OK;
-}
-
-int dmp_predict_chain_on_own_stream(dmp_ctx* lead) {
-  DMP_ARG(lead && lead->vg_leader == lead && lead->vg_detached == 1 && !vg_done(lead), "detach the chain first");
-  lead->vg_detached = 2;
-  return DMP_OK;
-}
-
-int dmp_predict_issue_group_chain(dmp_ctx* lead, void* stream) {
-  DMP_ARG(lead != nullptr, "null context");
-  DMP_ARG(lead->vg_leader == lead && lead->vg_detached && !vg_done(lead),
-          "no detached vertical-GRU chain to issue on this context (dmp_predict_detach_group_chain, once per group)");
-  DMP_HIP(hipSetDevice(lead->device));
-  return issue_group_chain(lead, 0, STREAM);
-}
-
 int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event) {
   DMP_ARG(ctx && d_vout, "null argument");
   DMP_ARG(ctx->fe_total > 0 && ctx->fe_next == 0 && ctx->vg_leader == nullptr,
@@ -1179,13 +1102,8 @@ int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event) 
 
 int dmp_predict_next_unit(const dmp_ctx* ctx) {
   if (!ctx) return DMP_UNIT_NONE;
-  if (ctx->fe_next == ctx->fe_total - 1 && ctx->vg_leader && (ctx->vg_leader != ctx || ctx->vg_detached) &&
-      !vg_done(ctx->vg_leader))
+  if (ctx->fe_next == ctx->fe_total - 1 && ctx->vg_leader && ctx->vg_leader != ctx && !vg_done(ctx->vg_leader))
     return DMP_UNIT_WAIT;      // the group's chain has not been issued to its end yet
-  // a detached chain that is being enqueued on the leader's OWN stream (vg_detached == 2): the leader's remaining
-  // front-end units wait until it has been enqueued to its end - kernels slipped between its rows would stretch it
-  if (ctx->fe_next >= 1 && ctx->fe_next < ctx->fe_total && ctx->vg_leader == ctx && ctx->vg_detached == 2 && !vg_done(ctx))
-    return DMP_UNIT_WAIT;
   if (ctx->fe_next < ctx->fe_total) return DMP_UNIT_LIGHT;
   if (ctx->passes_done > ctx->run_nloops) return DMP_UNIT_NONE;
   return (ctx->unit_next >= 1 && ctx->unit_next <= NBLOCK) ? DMP_UNIT_CONV : DMP_UNIT_LIGHT;
@@ -1232,21 +1150,9 @@ int dmp_ctx_pending(dmp_ctx* ctx) {
   return 2;
 }
 
-// one whole pass = the remaining units of the current pass
-int dmp_predict_pass(dmp_ctx* ctx, void* stream) {
-  DMP_ARG(ctx != nullptr, "null context");
-  DMP_ARG(ctx->fe_next >= ctx->fe_total, "front-end units of this prediction are still outstanding");
-  DMP_ARG(ctx->passes_done <= ctx->run_nloops, "all passes of this prediction were already issued");
-  const int pass = ctx->passes_done;
-  while (ctx->passes_done == pass) {
-    const int rc = dmp_predict_issue_unit(ctx, stream);
-    if (rc) return rc;
-  }
-  return DMP_OK;
-}
 
-// final refinement of the best trace; optional first half of dmp_predict_end
-int dmp_predict_end_refine(dmp_ctx* ctx, void* stream) {
+// final refinement of the best trace: first half of dmp_predict_end
+static int predict_end_refine(dmp_ctx* ctx, void* stream) {
   DMP_ARG(ctx != nullptr, "null context");
   dmp_ctx* c = ctx;
   DMP_ARG(c->fe_next >= c->fe_total && c->passes_done == c->run_nloops + 1,
@@ -1265,7 +1171,7 @@ int dmp_predict_end_refine(dmp_ctx* ctx, void* stream) {
 int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) {
   DMP_ARG(ctx && d_coords && d_conf, "null argument");
   dmp_ctx* c = ctx;
-  int rc = dmp_predict_end_refine(ctx, stream);
+  int rc = predict_end_refine(ctx, stream);
   if (rc) return rc;
   hipStream_t s = STREAM;
   const int L = c->last_L;
@@ -1281,28 +1187,30 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) 
 }
 
 // ---- heavy lane: serialises the conv launches of the contexts that share it -----------------
-int dmp_lane_create(dmp_lane** out) {
-  DMP_ARG(out != nullptr, "out is NULL");
-  dmp_lane* l = new dmp_lane();
+static std::shared_ptr<dmp_lane> lane_create() {
+  std::shared_ptr<dmp_lane> l(new dmp_lane(), [](dmp_lane* p) {
+    for (void* e : p->ev) (void)hipEventDestroy((hipEvent_t)e);
+    delete p;
+  });
   for (int i = 0; i < dmp_lane::RING; ++i) {
     hipEvent_t e;
-    hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    if (err != hipSuccess) { dmp_lane_destroy(l); return hip_fail(err, "hipEventCreate", __FILE__, __LINE__); }
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     l->ev.push_back((void*)e);
   }
-  *out = l;
-  return DMP_OK;
+  return l;
 }
 
-void dmp_lane_destroy(dmp_lane* l) {
-  if (!l) return;
-  for (void* e : l->ev) (void)hipEventDestroy((hipEvent_t)e);
-  delete l;
-}
-
-int dmp_ctx_set_lane(dmp_ctx* ctx, dmp_lane* lane) {
+int dmp_ctx_share_lane(dmp_ctx* ctx, dmp_ctx* other) {
   DMP_ARG(ctx != nullptr, "null context");
-  ctx->lane = lane;
+  if (!other) { ctx->lane_hold.reset(); ctx->lane = nullptr; return DMP_OK; }
+  DMP_ARG(other != ctx && other->device == ctx->device, "a lane is shared by different contexts of one GPU");
+  if (!other->lane_hold) {
+    other->lane_hold = lane_create();
+    if (!other->lane_hold) { set_error("hipEventCreate failed for the lane"); return DMP_ERR_HIP; }
+    other->lane = other->lane_hold.get();
+  }
+  ctx->lane_hold = other->lane_hold;
+  ctx->lane = ctx->lane_hold.get();
   return DMP_OK;
 }
 
@@ -1341,20 +1249,6 @@ int dmp_profile_enable(dmp_ctx* ctx, int on, int max_launches) {
   return DMP_OK;
 }
 
-int dmp_profile_conv_ms(dmp_ctx* ctx, float* h_avg_ms, int* h_launches) {
-  DMP_ARG(ctx && h_avg_ms && h_launches, "null argument");
-  double tot = 0.0;
-  const int n = ctx->prof_n / 2;
-  for (int i = 0; i < n; ++i) {
-    float ms = 0.f;
-    DMP_HIP(hipEventElapsedTime(&ms, (hipEvent_t)ctx->prof_ev[2 * i], (hipEvent_t)ctx->prof_ev[2 * i + 1]));
-    tot += ms;
-  }
-  *h_avg_ms = n ? (float)(tot / n) : 0.f;
-  *h_launches = n;
-  ctx->prof_n = 0;
-  return DMP_OK;
-}
 
 // developer diagnostic (tools/lane_trace.py): start and end of every recorded conv launch in ms after the
 // first recorded launch of `ref`; does not reset the counter
@@ -1372,28 +1266,5 @@ int dmp_profile_conv_intervals(dmp_ctx* ctx, dmp_ctx* ref, float* h_start_ms, fl
   return DMP_OK;
 }
 
-int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, void* stream) {
-  CHECK_CAP(L, 1);
-  CHECK_W();
-  DMP_ARG(block >= 1 && block <= NBLOCK && iters >= 1 && h_ms, "bad argument");
-  hipEvent_t e0, e1;
-  DMP_HIP(hipEventCreate(&e0));
-  DMP_HIP(hipEventCreate(&e1));
-  int rc = conv5x5_maxout_padded(ctx, block, ctx->xa, L, ctx->u, ctx->stats, STREAM, false);  // warm
-  if (rc) return rc;
-  ctx->xsplit_current = true;      // time the convolution alone: the warm call split the input
-  DMP_HIP(hipEventRecord(e0, STREAM));
-  for (int i = 0; i < iters; ++i)
-    if ((rc = conv5x5_maxout_padded(ctx, block, ctx->xa, L, ctx->u, ctx->stats, STREAM, false))) return rc;
-  DMP_HIP(hipEventRecord(e1, STREAM));
-  ctx->xsplit_current = false;
-  DMP_HIP(hipEventSynchronize(e1));
-  float ms = 0.f;
-  DMP_HIP(hipEventElapsedTime(&ms, e0, e1));
-  *h_ms = ms / iters;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  return DMP_OK;
-}
 
 }  // extern "C"

@@ -67,6 +67,9 @@ struct BlockW {
   uint16_t* wq = nullptr;  // bf16 pieces, layout in conv_bf16.h          (bf16x6 kernel)
   uint16_t* wh = nullptr;  // f16 pieces of scale*w, layout in conv_f16.h (f16x3 kernel)
   float wh_inv_scale = 1.f;
+  // power-of-two scale of the f16 pieces of this block's INPUT activations (conv_mode 0), chosen at
+  // dmp_weights_finalize from the InstanceNorm gamma / beta of the blocks before it (api.hip: act_scales)
+  float x_scale = 1.f;
   float* bias = nullptr;   // [512]
   float* gamma = nullptr;  // [128]
   float* beta = nullptr;   // [128]
@@ -115,7 +118,8 @@ struct dmp_lane {
 
 struct dmp_ctx {
   int device = 0;
-  dmp_lane* lane = nullptr;
+  dmp_lane* lane = nullptr;                // = lane_hold.get()
+  std::shared_ptr<dmp_lane> lane_hold;     // dmp_ctx_share_lane: the lane lives as long as a context refers to it
   int run_nloops = 0, run_refine = 0;
   int max_L = 0, max_N = 0;
   int64_t bytes = 0;
@@ -140,6 +144,9 @@ struct dmp_ctx {
   float* hT[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [layer][parity][128][Lb][4] float32 state (Lb: the group's columns)
   uint16_t* hH[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // same state as f16 pieces [2][64][Lb][8]
   uint8_t* vgru_run = nullptr;             // device VRun / VRun2 record read by the graph's step kernels
+  uint8_t* vgru_sync = nullptr;            // VPSync of the persistent chain (vgru.hip): XCD arrival counters, row flags
+  int vgru_persist = 1;                    // option "vgru_persistent": the chain as ONE weight-stationary launch (0: one launch per row)
+  bool vgru_persist_ok = false;            // the device has the 256 CUs the persistent form is laid out for
   int vg_ntiles = 0, vg_maxN = 0;          // group this context leads (vgru.hip): column tiles, deepest member alignment
   int vg_tile0[8] = {0};                   // ... first column tile of every member
   int vg_cap_cols = 0;                     // columns the state buffers hold (a group's members side by side)
@@ -150,13 +157,10 @@ struct dmp_ctx {
   std::vector<VgRider> vg_riders;          // leader: alignments of LATER predictions whose vertical GRU rides in this chain
   int vg_index = 0;                        // this context's index among its leader's members
   bool vg_done_issued = false;             // leader: the chain's last unit (and the members' outputs) has been enqueued
-                                           // (written by the thread that issues a detached chain: atomic accesses)
-  int vg_detached = 0;                     // leader: the chain is issued by dmp_predict_issue_group_chain, not by its units
   int vg_waiters = 0;                      // leader: members that have not yet enqueued their wait for vg_done_ev
   void* vg_done_ev = nullptr;              // hipEvent_t recorded behind the chain's last unit
   const float* ext_vout = nullptr;         // dmp_predict_set_vgru_result: the vertical GRU of this prediction was run ahead
   void* ext_vout_ev = nullptr;             // ... hipEvent_t recorded behind it (not owned)
-  int vgru_legacy = 0;                     // option: 1 = the round-2 step kernel (one target per launch, K split over waves)
   std::map<int64_t, void*> vgru_graphs;    // (grid, chain length) -> hipGraphExec_t
   std::map<int, void*> tri_graphs;         // matrix order -> hipGraphExec_t of the tridiagonalisation chain
   int cluster_local = 1;                   // option: 0 = the cluster kernels always publish with agent-scope stores (no XCD-local fast path)
@@ -165,7 +169,6 @@ struct dmp_ctx {
   unsigned long long* tri_gx = nullptr;    // [2][4][min(max_L, 640)] hand-off granules of the tridiagonalisation cluster + [2] placement header
   int refine_single = 0;                   // option: 1 = single-workgroup minimiser
   int gj_diag_groups = 4;                  // option: row groups of the diagonal sweep (2 = 256 threads as in rounds 1-3, 4 = 512 threads)
-  int gj_lds = 0;                          // option: trailing update of the inverse: 0 = operands from L2, 1 = panels staged in LDS, 2 = + tile fetched first
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions
   float* seq_a = nullptr;   // [L][512]
@@ -187,6 +190,7 @@ struct dmp_ctx {
   float* xdense = nullptr;  // [128][L][L] scratch for the stage-level API
   uint16_t* xsplit = nullptr;  // [3][16][P][P][8] bf16 pieces of the current activations
   int conv_mode = 0;           // 0: f16x3 split products (default), 1: exact f32 MFMA, 2: bf16x6 split
+  int act_scaling = 1;         // conv_mode 0: f16 pieces of x_scale * activation per block (0 = unscaled pieces)
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
   bool ab_current = false;     // the statistics reduction already wrote this block's InstanceNorm coefficients
   double* part = nullptr;   // [tiles][128][2]
@@ -216,11 +220,6 @@ struct dmp_ctx {
   bool fe_side = false;                    // this prediction's front end forks onto the side stream
   long unit_seq = 0;           // units issued since the context was created
   int fe_next = 0, fe_total = 0;           // front-end units (features, sequence trunk, static stem)
-  // features ahead (dmp_predict_ahead_*): reweighting, covariance, inverse and contacts of the NEXT alignment, computed
-  // into this context's feature buffers (idle once the static stem of the prediction in flight exists)
-  const uint8_t* ahead_msa = nullptr;
-  int ahead_N = 0, ahead_L = 0, ahead_next = 0, ahead_total = 0;
-  bool fe_have_features = false;           // this prediction's features were computed ahead
   int fe_inv = 0, fe_vgru = 0;             // ... of which inverse chunks / vertical-GRU chunks
   const uint8_t* run_msa = nullptr;        // arguments of the prediction in flight
   const float* run_template = nullptr;
@@ -286,7 +285,7 @@ int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, floa
 int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);
 int act_unpad(const float* d_xpad, int L, float* d_dense, hipStream_t s);
 int act_clear(float* d_xpad, int L, hipStream_t s);
-int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s);
+int act_split(dmp_ctx* c, const float* d_xpad, int L, int block, hipStream_t s);
 // mds.hip
 // ---- GRU gate functions: float32-accurate (<= 2.5 ulp) on the hardware exponential and reciprocal ---------------------
 // v_exp_f32 / v_rcp_f32 are 1 ulp each; what a plain `exp2(x * log2 e)` loses is the rounding of the product (relative

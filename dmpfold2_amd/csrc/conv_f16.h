@@ -57,12 +57,9 @@ constexpr int CH_IN_SLOTS = 2 * 2 * CH_HALO * CH_PITCH;               // 1920 16
 constexpr int CH_IN_BYTES = CH_IN_SLOTS * 16;                         // 30720
 constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slots = 2 KB per wave and tap
 constexpr int CH_WCOL = 5 * CH_WSLOT;                                 // one tap column of one wave in the packed weights
-#ifndef CH_WRING
-#define CH_WRING 0   // 1: five tap slots per wave (even pass 0-2, odd pass 3-4): every weight DMA flies two passes, not one
-#endif
-constexpr int CH_WBUF = (CH_WRING ? 5 : 3) * CH_WSLOT;                // per-wave LDS weight buffer: 3 (5) tap slots
+constexpr int CH_WBUF = 3 * CH_WSLOT;                                 // per-wave LDS weight buffer: 3 tap slots
 constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_WBUF * 16;       // 55296
-// number of workgroups to launch for tiles x tiles pixel tiles (XCD-aware block map, see CH_MAP)
+// number of workgroups to launch for tiles x tiles pixel tiles (XCD-aware block map)
 // block -> (tile, channel split) map (round 3, tools/r03_map.sh, profiles/r03_conv_block_maps.txt; block b runs on XCD
 // b % 8).  Sustained ms per launch at L = 300 (one stream / two launches in flight), L2-fabric bytes per launch
 // (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included; 98.7 MB algorithmic), scheduler throughput:
@@ -71,13 +68,10 @@ constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_WBUF * 16;       // 55296
 //   2  XCD x: ONE split of half of the tiles (1.64 MB of weight pieces per XCD)           0.675 / 0.645   339 MB   7.28
 // Fewer XCDs per tile do not lower the traffic - the weight set no longer fits the L2 beside the activations and comes
 // back from the Infinity Cache - and the map with the MOST fabric bytes is the fastest: its weights stay in the L2, and
-// what the kernel waits for is the weight stream, not the bytes.  Map 2 is the default.
-#ifndef CH_MAP
-#define CH_MAP 2
-#endif
+// what the kernel waits for is the weight stream, not the bytes.  Map 2 is the one built; 0 and 1 are history.
 inline int conv_f16_grid(int tiles) {
   const int nt = tiles * tiles;
-  return CH_MAP == 1 ? 8 * 4 * ((nt + 7) / 8) : (CH_MAP == 2 ? 8 * ((nt + 1) / 2) : 8 * 2 * ((nt + 3) / 4));
+  return 8 * ((nt + 1) / 2);
 }
 
 __host__ __device__ inline uint16_t ch_f16_bits(float f) {
@@ -147,28 +141,14 @@ __device__ __forceinline__ void ch_lane_pixel(int li, int& row, int& x) {
 
 // Issue efficiency is NOT what bounds this kernel (round 3, gpurun_out r03d, profiles/r03_conv_variants.txt).  The
 // compiler sinks a row pair's ds_reads down to their first use (a wait for a read issued two instructions earlier
-// before every third to ninth MFMA: the LDS latency shows on every row pair).  CH_PINNED=1 puts a scheduling barrier
-// behind the reads so that they stay one row pair ahead, as written (needs 188 VGPRs: CH_WPE=2 lifts the 168 cap),
-// and CH_PIPE=1 additionally software-pipelines the passes (next pass's weight fragments and first B fragment
-// fetched during the current one, 206 VGPRs).  Sustained at L = 300, same box: 0.659 ms per launch as shipped, 0.654
+// before every third to ninth MFMA: the LDS latency shows on every row pair).  Two variants were built and measured in
+// round 3 (removed in round 4): "pinned" - a scheduling barrier behind the reads keeps them one row pair ahead (188
+// VGPRs, lifting the 168 cap) - and "pipelined" - additionally the next pass's weight fragments and first B fragment
+// fetched during the current one (206 VGPRs).  Sustained at L = 300, same box: 0.659 ms per launch as shipped, 0.654
 // uncapped, 0.650 pinned, 0.647 pipelined (two launches in flight: 0.646 / 0.644 / 0.642 / 0.637): the stalls go and
 // 1.8 % of the time with them - the chip sits at its power cap (section 4 of DESIGN.md) and gives the issue slots
 // back as clock.  In the scheduler the shipped form is the fastest (6.95 structures/s against 6.82 .. 6.91): the
 // larger footprints take registers from the kernels that run beside the convolutions.
-#ifndef CH_PIPE
-#define CH_PIPE 0
-#endif
-#ifndef CH_WPE
-#define CH_WPE (CH_PIPE ? 2 : 3)
-#endif
-#ifndef CH_PINNED
-#define CH_PINNED CH_PIPE
-#endif
-#if CH_PINNED
-#define CH_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define CH_PIN() do {} while (0)
-#endif
 // One pass of a tap column: NT taps (rows dy = PAR, PAR + 2, ..) whose weight fragments a[t][piece] sit in
 // registers, against the row pairs r = PAR, PAR + 2, .. < 19 read from the halo tile at `il`.
 // Per fragment the small products go first (w0 x1, w1 x0), then w0 x0.
@@ -183,7 +163,6 @@ __device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const ui
       bn0 = il[(r + 2) * CH_PITCH];
       bn1 = il[(r + 2) * CH_PITCH + PIECE];
     }
-    CH_PIN();                                          // the next row pair's reads stay ahead of this one's MFMAs
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int q = (r - PAR - 2 * t) / 2;
@@ -200,47 +179,6 @@ __device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const ui
       if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b0, acc[q]);
     }
   }
-}
-
-// Software-pipelined form of a pass (CH_PIPE): the pass's first B fragment arrives in (f0, f1) - loaded during
-// the previous pass - and the first fragment of the NEXT pass (at `nxt`, null at the end of a stage) is loaded
-// during the last row pair; `hook(r)` runs after the MFMAs of row pair r (the caller fetches the next pass's weight
-// fragments there), so that a pass starts with everything it needs in registers.
-template <int NT, int PAR, class Hook>
-__device__ __forceinline__ void ch_column_pass_p(const uint4 (&a)[NT][2], const uint4* il, uint4& f0, uint4& f1,
-                                                 const uint4* nxt, ch_f32x16 (&acc)[8], Hook hook) {
-  constexpr int PIECE = 2 * CH_HALO * CH_PITCH;
-  uint4 bn0 = f0, bn1 = f1;
-#pragma unroll
-  for (int r = PAR; r < 19; r += 2) {
-    const uint4 b0 = bn0, b1 = bn1;
-    if (r + 2 < 19) {
-      bn0 = il[(r + 2) * CH_PITCH];
-      bn1 = il[(r + 2) * CH_PITCH + PIECE];
-    } else if (nxt) {
-      bn0 = nxt[0];
-      bn1 = nxt[PIECE];
-    }
-    CH_PIN();
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int q = (r - PAR - 2 * t) / 2;
-      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b1, acc[q]);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int q = (r - PAR - 2 * t) / 2;
-      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][1], b0, acc[q]);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int q = (r - PAR - 2 * t) / 2;
-      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b0, acc[q]);
-    }
-    hook(r);
-  }
-  f0 = bn0;
-  f1 = bn1;
 }
 
 // Footprint: the register budget is capped at 168 VGPRs (3 waves per SIMD; the input-tile DMA plan is
@@ -251,37 +189,21 @@ __device__ __forceinline__ void ch_column_pass_p(const uint4 (&a)[NT][2], const 
 // throughput mode (vertical GRU step 156 registers / 32 KB, norm 108, Gauss-Jordan update 92); uncapped
 // (194 registers) the same kernel cost the scheduler 6 % although it is faster alone.
 // grid: conv_f16_grid(tiles) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_WPE))) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
                                                                const uint16_t* __restrict__ wq,
                                                                const float* __restrict__ bias, float inv_scale,
                                                                int L, int P, int tiles, int nwork,
                                                                float* __restrict__ u, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
   const int id = blockIdx.x;
-  // XCD x works on the channel splits {0,1} (x even) or {2,3} (x odd) only: its share of the weight
-  // pieces is 3.3 MB, which fits the 4 MB L2; a tile's input is then read by two XCDs
   const int xcd = id & 7, slot = id >> 3;
   const int ntiles = tiles * tiles;
-#if CH_MAP == 1
-  // experiment: XCD x works on all four channel splits of a contiguous eighth of the tiles (a tile's input is read
-  // by ONE XCD; its share of the weight pieces is all 6.6 MB)
-  const int tper = (ntiles + 7) >> 3;
-  const int tile = xcd * tper + (slot >> 2);
-  const int split = slot & 3;
-  if ((slot >> 2) >= tper || tile >= ntiles) return;
-#elif CH_MAP == 2
   // XCD x works on ONE channel split (x & 3) of a contiguous half of the tiles: its 1.64 MB of weight pieces stay in
   // its 4 MB L2; a tile's input is read by four XCDs at about the same time (Infinity-Cache hits)
   const int tper = (ntiles + 1) >> 1;
   const int tile = (xcd >> 2) * tper + slot;
   const int split = xcd & 3;
   if (slot >= tper || tile >= ntiles) return;
-#else
-  const int tper = (ntiles + 3) >> 2;
-  const int tile = (xcd >> 1) * tper + (slot >> 1);
-  const int split = 2 * (xcd & 1) + (slot & 1);
-  if ((slot >> 1) >= tper || tile >= ntiles) return;
-#endif
   const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -325,87 +247,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
     const uint4* src = wq4 + (int64_t)(h >> 1) * 4 * CH_WCOL + odd * 3 * CH_WSLOT;
     if (odd) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ch_dma16(src + 64 * i, w_lds_addr + (CH_WRING ? 3 * CH_WSLOT * 16 : 0) + 1024 * i);
+      for (int i = 0; i < 4; ++i) ch_dma16(src + 64 * i, w_lds_addr + 1024 * i);
     } else {
 #pragma unroll
       for (int i = 0; i < 6; ++i) ch_dma16(src + 64 * i, w_lds_addr + 1024 * i);
     }
   };
-#if CH_PIPE
-  // software pipeline over the 80 passes: the weight fragments of pass h+1 are read from the wave's buffer in the
-  // middle of pass h (the buffer is then refilled for pass h+2), and the first B fragment of pass h+1 at its end
-  constexpr int PIECE = 2 * CH_HALO * CH_PITCH;
-  uint4 ae[3][2], ao[2][2], f0, f1;
   wdma(0);
-  ch_wait_vm<0>();
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    ae[t][0] = w_l[t * CH_WSLOT + a_off];
-    ae[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  wdma(1);
-  for (int g = 0; g < 8; ++g) {
-    __syncthreads();                                   // every wave is done with the previous tile
-    {
-      const uint4* src = xs4 + (int64_t)g * 2 * PP;
-      const unsigned dst = lds_base + (wave * 64) * 16;
-      int t = tid;
-      asm volatile("" : "+v"(t));                    // opaque per stage: the plan is not hoisted out of the loop
-#pragma unroll
-      for (int e = 0; e < CH_IN_SLOTS / 256; ++e) ch_dma16(src + in_src(e, t), dst + e * 4096);
-      if (wave * 64 < CH_IN_SLOTS % 256) ch_dma16(src + in_src(CH_IN_SLOTS / 256, t), dst + (CH_IN_SLOTS / 256) * 4096);
-    }
-    ch_wait_vm<0>();                                   // the tile (and the odd-pass weights issued before it)
-    __syncthreads();                                   // the tile of every wave has landed
-    f0 = in_l[b_base];
-    f1 = in_l[b_base + PIECE];
-#pragma unroll 1
-    for (int dx = 0; dx < 5; ++dx) {
-      const uint4* il = in_l + b_base + dx;
-      const int h0 = 2 * (g * 5 + dx);
-      ch_column_pass_p<3, 0>(ae, il, f0, f1, il + CH_PITCH, acc, [&](int r) {
-        if (r == 6) {                                  // the odd pass's weights (in flight since the previous pass)
-          __builtin_amdgcn_sched_barrier(0);
-          ch_wait_vm<0>();
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            ao[t][0] = w_l[t * CH_WSLOT + a_off];
-            ao[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        } else if (r == 10) {                          // the buffer is free: stream the next even pass
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          if (h0 + 2 < 80) wdma(h0 + 2);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
-      ch_column_pass_p<2, 1>(ao, il, f0, f1, dx < 4 ? il + 1 : nullptr, acc, [&](int r) {
-        if (r == 7) {
-          __builtin_amdgcn_sched_barrier(0);
-          ch_wait_vm<0>();
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            ae[t][0] = w_l[t * CH_WSLOT + a_off];
-            ae[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        } else if (r == 11) {
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          if (h0 + 3 < 80) wdma(h0 + 3);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
-    }
-  }
-#else
-  wdma(0);
-  if (CH_WRING) wdma(1);
 
   for (int g = 0; g < 8; ++g) {
     __syncthreads();                                   // every wave is done with the previous tile
@@ -425,9 +273,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
       const uint4* il = in_l + b_base + dx;
       const int h0 = 2 * (g * 5 + dx);
       {
-        // this pass's weights: issued one pass ago - or, with the five-slot ring, two passes ago with the odd pass's
-        // four DMAs behind them (at the head of a stage everything was drained with the tile)
-        if (CH_WRING) ch_wait_vm<4>(); else ch_wait_vm<0>();
+        // this pass's weights: issued one pass ago (at the head of a stage everything was drained with the tile)
+        ch_wait_vm<0>();
         uint4 a[3][2];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -435,28 +282,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CH_WPE, CH_
           a[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (CH_WRING) { if (h0 + 2 < 80) wdma(h0 + 2); }   // the even slots are free: the next EVEN pass
-        else wdma(h0 + 1);                             // the buffer is free: stream the next pass
+        wdma(h0 + 1);                                  // the buffer is free: stream the next pass
         ch_column_pass<3, 0>(a, il, acc);
       }
       {
-        // ring: behind the odd weights only the next even pass's six DMAs may be outstanding (none after the last)
-        if (CH_WRING) { if (h0 + 2 < 80) ch_wait_vm<6>(); else ch_wait_vm<0>(); } else ch_wait_vm<0>();
+        ch_wait_vm<0>();
         uint4 a[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          a[t][0] = w_l[(CH_WRING ? 3 : 0) * CH_WSLOT + t * CH_WSLOT + a_off];
-          a[t][1] = w_l[(CH_WRING ? 3 : 0) * CH_WSLOT + t * CH_WSLOT + 64 + a_off];
+          a[t][0] = w_l[t * CH_WSLOT + a_off];
+          a[t][1] = w_l[t * CH_WSLOT + 64 + a_off];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (CH_WRING) { if (h0 + 3 < 80) wdma(h0 + 3); }   // the odd slots are free: the next ODD pass
-        else if (h0 + 2 < 80) wdma(h0 + 2);
+        if (h0 + 2 < 80) wdma(h0 + 2);
         ch_column_pass<2, 1>(a, il, acc);
       }
     }
   }
 
-#endif
   // epilogue: undo the weight scale, bias, 4-way max, store, per-channel partial sums
   const float* bsp = bias + split * 128 + wave * 32;
   const int64_t LL = (int64_t)L * L;

@@ -250,13 +250,8 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-#if defined(GJ_DBG_NOMFMA)
-#define GJ_C_END 1
-#else
-#define GJ_C_END (16 / PF)
-#endif
 #pragma unroll
-  for (int c = 0; c < GJ_C_END; ++c) {
+  for (int c = 0; c < 16 / PF; ++c) {
     if (c + 1 < 16 / PF) load((c + 1) & 1, c + 1);
 #pragma unroll
     for (int u = 0; u < PF; ++u)
@@ -285,132 +280,8 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
         float v = 0.f;
         if (row < D && col < D) {
           float* p = A + (int64_t)row * D + col;
-#if defined(GJ_DBG_NOREAD)
-          v = -acc[mi][ni][r];
-          *p = v;
-#elif defined(GJ_DBG_NOSTORE)
-          v = (blockcol ? 0.f : *p) - acc[mi][ni][r];
-          if (v == 123.456f) *p = v;
-#else
           v = (blockcol ? 0.f : *p) - acc[mi][ni][r];
           *p = v;
-#endif
-        }
-      }
-    }
-}
-
-// The same update with the two panels staged through LDS (round 3): the four waves of a tile share its 128 panel
-// rows and 128 panel columns, which the kernel above fetches from L2 once per WAVE (twice per workgroup) with every
-// load on the critical path of the 16 MFMAs it feeds.  K = 128 in 4 stages of 8 k quads: per stage 2 x 16 KB arrive
-// by LDS-DMA (global_load_lds_dwordx4: 8 wave-wide 1 KB transfers per wave, contiguous in CT / RT and in LDS) into one
-// of two buffers while the MFMAs of the previous stage run out of the other; one workgroup barrier per stage.  The
-// fragment a lane reads (k quad 2o + kk of row / column li) is the one the register kernel loads, the MFMAs run
-// in the same order: results are identical bit for bit.  PRE = 1 also fetches the tile's old values before the MFMA
-// chain instead of after it.
-// grid: (Dp/128)^2 blocks, row-block major   block: 256   dynamic LDS: 64 KB
-__device__ __forceinline__ void gj_dma16(const void* gsrc, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
-}
-constexpr int GJL_STAGE_F4 = 2 * 8 * 128;        // float4 per stage buffer: A quads [8][128], then B quads [8][128]
-constexpr int GJL_LDS_BYTES = 2 * GJL_STAGE_F4 * 16;
-template <int PRE>
-__global__ __launch_bounds__(256, 2) void gj_trailing_lds_kernel(float* __restrict__ A, int D, int Dp, int k0,
-                                                                 const float4* __restrict__ CT,
-                                                                 const float4* __restrict__ RT) {
-  extern __shared__ __attribute__((aligned(16))) float4 gjl_sm[];
-  const int nt = Dp >> 7;
-  const int tm = blockIdx.x / nt, tn = blockIdx.x % nt, kb = k0 >> 7;
-  if (tm == kb || tn > tm) return;                      // see gj_trailing_kernel
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kk = lane >> 5, li = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = tm * 128 + wm * 64, n0 = tn * 128 + wn * 64;
-  const bool blockcol = (tn == kb);
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)gjl_sm;
-  // this wave's share of a stage: local quads 2 wave, 2 wave + 1 of both panels, 128 rows each = 2 transfers per quad
-  const float4* ca = CT + (int64_t)(2 * wave) * Dp + tm * 128 + lane;
-  const float4* rb = RT + (int64_t)(2 * wave) * Dp + tn * 128 + lane;
-  auto issue = [&](int st) {
-    const unsigned dst = lds_base + (unsigned)((st & 1) * GJL_STAGE_F4) * 16u;
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int64_t g = (int64_t)(8 * st + qq) * Dp + 64 * h;
-        const unsigned l = (unsigned)(((2 * wave + qq) * 128 + 64 * h) * 16);
-        gj_dma16(ca + g, dst + l);
-        gj_dma16(rb + g, dst + 8 * 128 * 16 + l);
-      }
-  };
-  issue(0);
-  float old[2][2][16];
-  if (PRE) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + 32 * ni + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
-          old[mi][ni][r] = (!blockcol && row < D && col < D) ? A[(int64_t)row * D + col] : 0.f;
-        }
-      }
-  }
-  gj_f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-#pragma unroll 1
-  for (int st = 0; st < 4; ++st) {
-    // this wave's transfers of stage st have landed (PRE: the tile loads issued behind stage 0 are older than nothing
-    // that follows, so a full drain is only paid once); after the barrier everybody's have, and everybody has left
-    // the buffer stage st + 1 goes to
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (st + 1 < 4) issue(st + 1);
-    const float4* sa = gjl_sm + (st & 1) * GJL_STAGE_F4 + wm * 64 + li;
-    const float4* sb = sa + 8 * 128 + (wn - wm) * 64;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      float4 av[2], bv[2];
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        av[x] = sa[(2 * o + kk) * 128 + 32 * x];
-        bv[x] = sb[(2 * o + kk) * 128 + 32 * x];
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const float a4[4] = {av[mi].x, av[mi].y, av[mi].z, av[mi].w};
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const float b4[4] = {bv[ni].x, bv[ni].y, bv[ni].z, bv[ni].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[mi][ni], 0, 0, 0);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int col = n0 + 32 * ni + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
-        if (row < D && col < D) {
-          float* p = A + (int64_t)row * D + col;
-          const float o = PRE ? old[mi][ni][r] : (blockcol ? 0.f : *p);
-          *p = o - acc[mi][ni][r];
         }
       }
     }
@@ -420,8 +291,6 @@ int gj_kernel_attrs(dmp_ctx* c) {
   static bool done[64] = {};
   if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
   if (c->device >= 0 && c->device < 64) done[c->device] = true;
-  DMP_HIP(hipFuncSetAttribute((const void*)gj_trailing_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GJL_LDS_BYTES));
-  DMP_HIP(hipFuncSetAttribute((const void*)gj_trailing_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, GJL_LDS_BYTES));
   return DMP_OK;
 }
 
@@ -528,9 +397,7 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
     DMP_LAUNCH_CHECK();
     // A -= C R outside the block column, A[:, block] = -C P inside it
     const dim3 tgrid((Dp / 128) * (Dp / 128));
-    if (c->gj_lds == 1) hipLaunchKernelGGL(gj_trailing_lds_kernel<0>, tgrid, dim3(256), GJL_LDS_BYTES, s, A, D, Dp, k0, CT, RT);
-    else if (c->gj_lds == 2) hipLaunchKernelGGL(gj_trailing_lds_kernel<1>, tgrid, dim3(256), GJL_LDS_BYTES, s, A, D, Dp, k0, CT, RT);
-    else hipLaunchKernelGGL(gj_trailing_kernel, tgrid, dim3(256), 0, s, A, D, Dp, k0, CT, RT);
+    hipLaunchKernelGGL(gj_trailing_kernel, tgrid, dim3(256), 0, s, A, D, Dp, k0, CT, RT);
     DMP_LAUNCH_CHECK();
     hipLaunchKernelGGL(gj_writeback_kernel, dim3(cdiv(D, 256), bs), dim3(256), 0, s, A, D, k0, bs,
                        R, P);

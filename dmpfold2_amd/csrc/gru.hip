@@ -105,14 +105,7 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
     }
   };
   load_gi(0);
-#ifdef SEQ_PROFILE
-  long long pt[5] = {0, 0, 0, 0, 0};
-  unsigned pspins = 0;
-#define SEQ_T(i) { const long long now = clock64(); pt[i] += now - plast; plast = now; }
-  long long plast = clock64();
-#else
 #define SEQ_T(i)
-#endif
   for (int step = 0; step < a.T; ++step) {
     const int t = dir ? (a.T - 1 - step) : step;
     const unsigned epoch = (unsigned)step + 1u;
@@ -189,9 +182,6 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
           ok = ok && ((unsigned)(x >> 32) == epoch);
         }
         if (__all(ok)) break;
-#ifdef SEQ_PROFILE
-        ++pspins;
-#endif
         if (spins > 2000000u) { dead = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -206,11 +196,6 @@ __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
       SEQ_T(3)
     }
   }
-#ifdef SEQ_PROFILE
-  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 57))
-    printf("seq_gru block %d T=%d cycles per step: read h %lld, matvec+reduce %lld, gates+publish %lld, gather %lld; failed sweeps per step %.2f\n",
-           (int)blockIdx.x, a.T, pt[0] / a.T, pt[1] / a.T, pt[2] / a.T, pt[3] / a.T, (double)pspins / a.T);
-#endif
 }
 
 int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hipStream_t s) {

@@ -382,14 +382,7 @@ __global__ __launch_bounds__(256) void tridiag_cluster_kernel(TriClusterArgs a) 
   const bool local = sh_local != 0;
   constexpr int NI = 3;                                   // 256 * 3 >= 640 = largest order of this kernel
   double tkprev = 0.0;                                    // tau_{k-1}
-#ifdef TC_PROFILE
-  long long pt[6] = {0, 0, 0, 0, 0, 0};
-  long long plast = clock64();
-  int psteps = 0;
-#define TC_T(i) { const long long now = clock64(); pt[i] += now - plast; plast = now; }
-#else
 #define TC_T(i)
-#endif
   for (int k = 0; k < n; ++k) {
     if (k >= last_row && !(k == n - 1 && last_row == n - 1)) break;
     const int mp = n - k;
@@ -528,15 +521,7 @@ __global__ __launch_bounds__(256) void tridiag_cluster_kernel(TriClusterArgs a) 
       }
     }
     TC_T(4)
-#ifdef TC_PROFILE
-    ++psteps;
-#endif
   }
-#ifdef TC_PROFILE
-  if ((tid == 0 || tid == 192) && (g == 0 || g == 13 || g == 31) && psteps > 0)
-    printf("tridiag cluster wg %d tid %d n=%d steps %d local %d, cycles per step: gather %lld, barrier %lld, w %lld, x+norm+v %lld, rows %lld\n",
-           g, tid, n, psteps, (int)local, pt[0] / psteps, pt[1] / psteps, pt[2] / psteps, pt[3] / psteps, pt[4] / psteps);
-#endif
   if (sh_abort && tid == 0) atomicOr(a.abort_flag, DMP_FAULT_EIG_HANDOFF);
 }
 
@@ -588,13 +573,7 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   __shared__ double sh_scal[4];
   __shared__ double red[8][NEV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef TE_PROFILE
-  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long plast = clock64();
-#define TE_T(i) { const long long now = clock64(); pt[i] += now - plast; plast = now; }
-#else
 #define TE_T(i)
-#endif
 
   // Gershgorin interval and norms
   double lo = 1e300, hi = -1e300, emax = 0.0, nrm1 = 0.0;
@@ -811,12 +790,6 @@ __global__ __launch_bounds__(512) void tri_eig_kernel(const double* __restrict__
   if (MODE != 2)
     for (int r = tid; r < n * NEV; r += 512) Z[r] = x[r];
   if (tid < NEV) lam_out[tid] = lam[tid];
-#ifdef TE_PROFILE
-  TE_T(5)
-  if (tid == 0)
-    printf("tri_eig n=%d cycles: setup %lld, bisection %lld, LU + start vectors %lld, triangular solves (5 iterations) %lld, Gram-Schmidt %lld, write-back %lld\n",
-           n, pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
-#endif
 }
 
 // Z <- Q Z with Q = H_0 H_1 ... H_{n-2}; then sign rule and scaling.

@@ -24,9 +24,12 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // Eight consecutive channels of one pixel -> the 16-byte operands of the split-product
 // convolutions.  MODE 0: two f16 pieces (conv_f16.h), MODE 2: three bf16 pieces (conv_bf16.h).
 // `slot` is the uint4 index inside one piece plane set, `piece_stride` the uint4 count per piece.
+// MODE 0: the pieces are those of xscale * o (a power of two per block: exact, undone in the convolution's epilogue),
+// so that the low pieces of the bulk of the activations are normal f16 numbers whatever the trunk's activation
+// scale is, and the range check is made on the scaled value.
 template <int MODE>
 __device__ __forceinline__ void store_pieces(const float (&o)[8], uint16_t* __restrict__ xs, int64_t slot,
-                                             int64_t piece_stride, int* __restrict__ fault) {
+                                             int64_t piece_stride, int* __restrict__ fault, float xscale) {
   constexpr int NP = (MODE == 0) ? 2 : 3;
   uint16_t pc[NP][8];
   bool bad = false;
@@ -34,9 +37,10 @@ __device__ __forceinline__ void store_pieces(const float (&o)[8], uint16_t* __re
   for (int e = 0; e < 8; ++e) {
     if constexpr (MODE == 0) {
       uint16_t p2[2];
-      split2_f16(o[e], p2);
+      const float v = o[e] * xscale;
+      split2_f16(v, p2);
       pc[0][e] = p2[0]; pc[1][e] = p2[1];
-      bad = bad || !(fabsf(o[e]) < 60000.f);          // f16 range (also catches NaN)
+      bad = bad || !(fabsf(v) < 60000.f);             // f16 range (also catches NaN)
     } else {
       uint16_t p3[3];
       split3_bf16(o[e], p3);
@@ -598,7 +602,8 @@ int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s, int 
 // convolutions read (MODE 0: two f16 pieces, MODE 2: three bf16 pieces); borders stay 0.
 template <int MODE>
 __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict__ xpad, int P,
-                                                        uint16_t* __restrict__ xs, int* __restrict__ fault) {
+                                                        uint16_t* __restrict__ xs, int* __restrict__ fault,
+                                                        float xscale) {
   const int y = blockIdx.y, cgp = blockIdx.z;
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x >= P) return;
@@ -606,16 +611,18 @@ __global__ __launch_bounds__(256) void act_split_kernel(const float* __restrict_
   float o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = xpad[(int64_t)(cgp * 8 + e) * PP + (int64_t)y * P + x];
-  store_pieces<MODE>(o, xs, (int64_t)cgp * PP + (int64_t)y * P + x, 16 * PP, fault);
+  store_pieces<MODE>(o, xs, (int64_t)cgp * PP + (int64_t)y * P + x, 16 * PP, fault, xscale);
 }
 
-int act_split(dmp_ctx* c, const float* d_xpad, int L, hipStream_t s) {
+// pieces of the input of residual block `block` (1..16)
+int act_split(dmp_ctx* c, const float* d_xpad, int L, int block, hipStream_t s) {
   const int P = act_pitch(L);
   dim3 grid(cdiv(P, 256), P, 16);
   if (c->conv_mode == 2)
-    hipLaunchKernelGGL(act_split_kernel<2>, grid, dim3(256), 0, s, d_xpad, P, c->xsplit, c->seq_abort);
+    hipLaunchKernelGGL(act_split_kernel<2>, grid, dim3(256), 0, s, d_xpad, P, c->xsplit, c->seq_abort, 1.0f);
   else
-    hipLaunchKernelGGL(act_split_kernel<0>, grid, dim3(256), 0, s, d_xpad, P, c->xsplit, c->seq_abort);
+    hipLaunchKernelGGL(act_split_kernel<0>, grid, dim3(256), 0, s, d_xpad, P, c->xsplit, c->seq_abort,
+                       c->act_scaling ? c->W.blk[block - 1].x_scale : 1.0f);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
@@ -644,7 +651,7 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
   if (c->conv_mode != 1) {
     // float32-grade products from f16 / bf16 pieces on the 16-bit matrix cores
     if (!c->xsplit_current) {
-      int rc = act_split(c, d_xpad, L, s);
+      int rc = act_split(c, d_xpad, L, block, s);
       if (rc) return rc;
     }
     if (c->conv_mode == 2)
@@ -652,7 +659,8 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
                          B.bias, L, P, tiles, nwork, d_u, c->part);
     else
       hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,
-                         B.bias, B.wh_inv_scale, L, P, tiles, nwork, d_u, c->part);
+                         B.bias, c->act_scaling ? B.wh_inv_scale / B.x_scale : B.wh_inv_scale, L, P, tiles, nwork, d_u,
+                         c->part);
     DMP_LAUNCH_CHECK();
     return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
   }
@@ -675,7 +683,7 @@ template <int SPLIT>
 __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     const float* __restrict__ u, const float* __restrict__ ab, const float* __restrict__ cse,
     const float* __restrict__ sse_w, float sse_b, const float* __restrict__ xin, int L, int P,
-    float* __restrict__ xout, uint16_t* __restrict__ xs, int* __restrict__ fault) {
+    float* __restrict__ xout, uint16_t* __restrict__ xs, int* __restrict__ fault, float xscale) {
   __shared__ float sh_a[CW], sh_b[CW], sh_g[CW], sh_w[CW];
   if (threadIdx.x < CW) {
     sh_a[threadIdx.x] = ab[threadIdx.x * 2];
@@ -716,8 +724,8 @@ __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
       xout[c * PP + pp] = o[e];
     }
     // inside a trunk pass: also emit the pieces the next block's split-product convolution reads
-    if constexpr (SPLIT == 0) store_pieces<0>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault);
-    if constexpr (SPLIT == 2) store_pieces<2>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault);
+    if constexpr (SPLIT == 0) store_pieces<0>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault, xscale);
+    if constexpr (SPLIT == 2) store_pieces<2>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault, 1.0f);
   }
 }
 
@@ -731,12 +739,14 @@ int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const dou
     DMP_LAUNCH_CHECK();
   }
   c->ab_current = false;
-  // inside a trunk pass the kernel also emits the pieces the next convolution reads
-  const int split = (c->conv_mode != 1 && c->xsplit_current) ? c->conv_mode : -1;
+  // inside a trunk pass the kernel also emits the pieces the next convolution reads (scaled for THAT block; the last
+  // block's output is read by the head in float32 only: no pieces)
+  const int split = (c->conv_mode != 1 && c->xsplit_current && block < NBLOCK) ? c->conv_mode : -1;
+  const float xscale = (c->act_scaling && block < NBLOCK) ? c->W.blk[block].x_scale : 1.0f;
   dim3 grid(cdiv(L, 128), L);
 #define NORM_LAUNCH(S)                                                                              \
   hipLaunchKernelGGL(norm_scse_residual_kernel<S>, grid, dim3(256), 0, s, d_u, c->ab, B.cse, B.sse_w, \
-                     B.sse_b, d_xpad_in, L, P, d_xpad_out, c->xsplit, c->seq_abort)
+                     B.sse_b, d_xpad_in, L, P, d_xpad_out, c->xsplit, c->seq_abort, xscale)
   if (split == 0) NORM_LAUNCH(0);
   else if (split == 2) NORM_LAUNCH(2);
   else NORM_LAUNCH(-1);

@@ -1,45 +1,35 @@
 // gru_vertical: the 2-layer GRU that runs DOWN the alignment (reference network.py:189, 223-224:
-// time axis = N sequences, batch = L columns, hidden 512).
+// time axis = N sequences, batch = L columns, hidden 512), for up to 8 alignments at once (a "group":
+// the targets a throughput scheduler starts together, and the riders of its next round).
 //
-// One launch per time step computes layer 0 at step t and layer 1 at step t-1 (both read the same
-// h0 state) as GEMMs  gates^T[j, b] = sum_k W[j, k] * x[k, b]  with the hidden index j on the MFMA M
-// axis and the alignment column b on the N axis.
+// Row t computes layer 0 at step t and layer 1 at step t-1 (both read the same h0 state) as GEMMs
+// gates^T[j, b] = sum_k W[j, k] * x[k, b]  with the hidden index j on the MFMA M axis and the alignment
+// column b on the N axis.
 //
 // Arithmetic: float32-grade products on the f16 matrix cores, the same scheme as conv_f16.h.  Every
 // operand is the sum of two f16 pieces (weights: S*w = w0 + w1 with a power-of-two S per layer;
-// state: 1024*h = h0 + h1, |h| < 1); v_mfma_f32_32x32x16_f16 accumulates w0 h1 + w1 h0 + w0 h0 in
-// float32 and the sums are scaled back by 1/(1024 S) (exact).  The dropped w1 h1 term is 2^-22 of a
-// product.  The one-hot layer-0 input is the exact f16 value 1024 (low piece 0: two products).
-// The previous version of this kernel ran the exact-f32 MFMA (32x32x2): 17.6 us of matrix-core time
-// per step against 3.3 us here.
+// state: 1024*h = h0 + h1, |h| < 1); the MFMA accumulates w0 h1 + w1 h0 + w0 h0 in float32 and the sums
+// are scaled back by 1/(1024 S) (exact).  The dropped w1 h1 term is 2^-22 of a product.  The one-hot
+// layer-0 input contributes 1024 (w0 + w1)[j, code].
 //
 // Layouts (one 16-byte load = one MFMA operand):
 //   weights  Wq[piece 2][gate 3][k/8][512 j][8]  f16     A operand of (gate, piece) for 8 k
 //   state    hH[piece 2][k/8 = 64][Lb][8]        f16     B operand;  written by the epilogue
 //            hP[j/4 = 128][Lb][4]                f32     the state itself, for h' = (h - n) z + n
 //
-// Workgroup = 8 waves = two groups of four, each group one K = 512 product on a (32 hidden x 32
-// column) tile split four ways (layer 1: recurrent and input product of one tile; layer 0: the
-// recurrent products of two tiles, the K = 22 -> 32 one-hot input product generated in registers by
-// wave 0 of the group).  The K slices are summed through LDS (two rounds: r and z, then the third
-// gate) and four waves per tile apply the gate maths (ATen gru_cell: h' = (h - n) z + n).
-// Block b runs on XCD b % 8; XCD x owns hidden tiles 2x, 2x+1 of both layers, so the weights it
-// streams every step (1.6 MB) stay in its 4 MB L2.
-// The N + 1 dependent launches are replayed from hipGraph chains of 128 (or 16) step nodes; what
-// changes between chunks lives in a small device record (VRun) written by a 1-thread kernel.
+// Two forms, same interface (vgru_group_setup / vgru_group_steps / vgru_group_output):
+//   * the PERSISTENT weight-stationary launch (round 4, the default on a 256-CU device): the whole chain in
+//     one launch, columns partitioned over the XCDs, hidden units over the CUs of an XCD, weights resident
+//     in registers and LDS, XCD-local row barriers - see vgru_persist_kernel;
+//   * one launch PER ROW (round 3, option "vgru_persistent" = 0 and the fallback on other devices): the
+//     group step kernel below, replayed from hipGraph chains of 128 (or 16) nodes.
 #include "common.h"
+#include <type_traits>
 
 namespace dmp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 vg_f16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ float vsigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__device__ __forceinline__ f32x16 vg_mfma(uint4 a, uint4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vg_f16x8, a), __builtin_bit_cast(vg_f16x8, b),
-                                                c, 0, 0, 0);
-}
 
 // Per-context constants of the step kernel (baked into the hipGraph nodes) ...
 struct VStatic {
@@ -50,206 +40,11 @@ struct VStatic {
   float* hT[2][2];          // [layer][parity] float32 state [128][Lb][4]
   uint16_t* hH[2][2];       // [layer][parity] f16 pieces of 1024*state [2][64][Lb][8]
 };
-// ... and what changes from chunk to chunk, read from device memory (vgru_set_run_kernel)
-struct VRun {
-  const uint8_t* msa;       // N x L residue codes
-  int N, L, Lb;
-  int t0, t_end;            // node idx of the chunk runs time step t = t0 + idx if t < t_end
-};
-
-
 constexpr int VG_TB = 32;              // columns per tile
 
 
-// One wave's quarter of a K = 512 contraction: MFMA steps s = w, w+4, ..., w+28 (16 k each), three
-// gate accumulators per column subtile.  Hand-staged: the loads of the next chunk are issued before
-// the MFMAs of the current one.
-// Measured at L = 300 (240 workgroups, 12.3 us per step): the same kernel without MFMAs takes as
-// long; with all loads redirected to one cache line 7.6 us.  A CU sustains about 50 GB/s of L1
-// misses here whatever the request pattern (rotating the k order per workgroup changes nothing), so
-// the step time follows the bytes one CU has to pull.  64-column tiles (weight operands used for two
-// column subtiles from registers: 0.6x the total L2 traffic, half as many workgroups pulling 1.25x the
-// bytes each, 246 VGPRs) were built and measured in round 2, bit-identical and slower everywhere: alone
-// 31.9 against 26.3 ms at L = 300, N = 2000, two targets side by side 43.5 against 34.5 ms, four 119
-// against 115 ms, and 3 % less throughput in the scheduler.
-__device__ __forceinline__ void k512_steps(const uint4* __restrict__ wp, const uint4* __restrict__ xp, int Lb,
-                                           int w, int kk, f32x16& ar, f32x16& az, f32x16& at) {
-  // Two operand sets (6 weight + 2 state loads of 16 bytes each) alternate: the loads of step c+1
-  // are in flight during the nine MFMAs of step c.  The loop is kept rolled (two steps per trip) so
-  // the kernel stays inside the register budget that lets it share a CU with two convolution
-  // workgroups; fully unrolled the compiler hoists loads and needs 200 registers.
-  const uint4* wq = wp + (int64_t)(2 * w + kk) * 512;
-  const uint4* xq = xp + (int64_t)(2 * w + kk) * Lb;
-  uint4 a0[6], b0[2], a1[6], b1[2];
-  auto load = [&](uint4* a, uint4* b, int c) {           // step c of this wave: k octet pair 8c + 2w + kk
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      b[p] = xq[(int64_t)(p * 64 + 8 * c) * Lb];
-#pragma unroll
-      for (int g = 0; g < 3; ++g) a[p * 3 + g] = wq[(int64_t)((p * 3 + g) * 64 + 8 * c) * 512];
-    }
-  };
-  auto mfma9 = [&](const uint4* a, const uint4* b) {     // a[piece*3 + gate], b[piece]
-    ar = vg_mfma(a[0], b[1], ar);
-    az = vg_mfma(a[1], b[1], az);
-    at = vg_mfma(a[2], b[1], at);
-    ar = vg_mfma(a[3], b[0], ar);
-    az = vg_mfma(a[4], b[0], az);
-    at = vg_mfma(a[5], b[0], at);
-    ar = vg_mfma(a[0], b[0], ar);
-    az = vg_mfma(a[1], b[0], az);
-    at = vg_mfma(a[2], b[0], at);
-  };
-  load(a0, b0, 0);
-#pragma unroll 1
-  for (int c = 0; c < 8; c += 2) {
-    load(a1, b1, c + 1);
-    mfma9(a0, b0);
-    if (c + 2 < 8) load(a0, b0, c + 2);
-    mfma9(a1, b1);
-  }
-}
-
-constexpr int VG_LDS_BYTES = 4 * 2 * 16 * 64 * 4;   // 32 KB: partial sums of two gates from four waves
-
-// column pitch of the state buffers / number of workgroups of a step: per XCD 2 hidden tiles x
-// (nbt layer-1 tiles + nbt layer-0 tiles)
+// column pitch of a member's state: whole 32-column tiles
 __host__ __device__ inline int vgru_pitch(int L) { return (L + VG_TB - 1) / VG_TB * VG_TB; }
-__host__ __device__ inline int vgru_grid(int Lb) { return 8 * 2 * 2 * (Lb / VG_TB); }
-
-// Workgroup = 4 waves (one per SIMD) on one (32 hidden x 32 column) tile of one layer; wave w takes
-// the K quarter {w, w+4, ...} of the recurrent product and, for layer 1, of the input product as
-// well (the r and z accumulators are shared, W_hn h and W_in x are kept apart); for layer 0 wave 0
-// adds the K = 32 one-hot input product.  The partial sums go through LDS two gates at a time
-// (32 KB); every wave then finishes a quarter of the tile's rows.
-// Footprint: 4 waves of at most 160 VGPRs and 32 KB of LDS - exactly what two f16x3 convolution
-// workgroups leave free on a CU (512 - 2*176 registers per SIMD lane, 160 - 2*62 KB), so the steps of
-// one target run beside the convolutions of another (7.3 structures/s if this kernel cost nothing,
-// 6.4 with the previous 8-wave / 72 KB version that needed one of the two convolution slots).
-// grid: vgru_grid(Lb)   block: 256   dynamic LDS: VG_LDS_BYTES
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void vgru_step_kernel(VStatic st, const VRun* __restrict__ run, int idx) {
-  extern __shared__ __attribute__((aligned(16))) float vg_red[];   // [4 waves][2 gates][16][64]
-  const int t = run->t0 + idx;
-  if (t >= run->t_end) return;
-  const int N = run->N, L = run->L, Lb = run->Lb;
-  const int nbt = Lb / VG_TB;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int rest = slot >> 1;                       // [0, nbt): layer 1 tiles, [nbt, 2 nbt): layer 0 tiles
-  const int layer = rest < nbt ? 1 : 0;
-  if (layer == 0 && !(t < N)) return;
-  if (layer == 1 && !(t >= 1)) return;
-  const int par = t & 1;      // layer 0 reads parity t, writes t+1; layer 1 (step t-1) reads t+1, writes t
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kk = lane >> 5, li = lane & 31;
-  const int j0 = (2 * xcd + (slot & 1)) * 32;
-  const int b0 = (layer ? rest : rest - nbt) * VG_TB;
-
-  f32x16 acc_r, acc_z, acc_hn, acc_in;    // r and z: both products; W_hn h; W_in x
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc_r[r] = 0.f; acc_z[r] = 0.f; acc_hn[r] = 0.f; acc_in[r] = 0.f; }
-
-  if (layer == 1) {
-    k512_steps(st.wh[1] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[1][par ^ 1]) + (b0 + li), Lb, w, kk,
-               acc_r, acc_z, acc_hn);
-    k512_steps(st.wx[1] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[0][par]) + (b0 + li), Lb, w, kk,
-               acc_r, acc_z, acc_in);
-  } else {
-    k512_steps(st.wh[0] + (j0 + li), reinterpret_cast<const uint4*>(st.hH[0][par]) + (b0 + li), Lb, w, kk,
-               acc_r, acc_z, acc_hn);
-    if (w == 0) {
-      // layer 0 input: one-hot of the residue code (value 1024 = the state scale), K = 32 (rows
-      // 22..31 of the packed weights are 0)
-      const uint4* wp = st.wx[0] + (j0 + li);
-      const int b = b0 + li;
-      const int code = (b < L) ? (int)run->msa[(int64_t)t * L + b] : 0;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int kq = 2 * s + kk;
-        const int d = code - 8 * kq;                     // position of the hot element among this lane's 8 k
-        const unsigned hot = (d >= 0 && d < 8) ? (0x6400u << (16 * (d & 1))) : 0u;
-        uint4 x;
-        x.x = (d >> 1) == 0 ? hot : 0u;
-        x.y = (d >> 1) == 1 ? hot : 0u;
-        x.z = (d >> 1) == 2 ? hot : 0u;
-        x.w = (d >> 1) == 3 ? hot : 0u;
-        acc_r = vg_mfma(wp[(int64_t)((1 * 3 + 0) * 4 + kq) * 512], x, acc_r);
-        acc_z = vg_mfma(wp[(int64_t)((1 * 3 + 1) * 4 + kq) * 512], x, acc_z);
-        acc_in = vg_mfma(wp[(int64_t)((1 * 3 + 2) * 4 + kq) * 512], x, acc_in);
-        acc_r = vg_mfma(wp[(int64_t)((0 * 3 + 0) * 4 + kq) * 512], x, acc_r);
-        acc_z = vg_mfma(wp[(int64_t)((0 * 3 + 1) * 4 + kq) * 512], x, acc_z);
-        acc_in = vg_mfma(wp[(int64_t)((0 * 3 + 2) * 4 + kq) * 512], x, acc_in);
-      }
-    }
-  }
-
-  const float* bias = st.bias[layer];
-  const float inv = st.inv_scale[layer];
-  const float* hprev = layer ? st.hT[1][par ^ 1] : st.hT[0][par];
-  float* hnext = layer ? st.hT[1][par] : st.hT[0][par ^ 1];
-  uint16_t* gnext = layer ? st.hH[1][par] : st.hH[0][par ^ 1];
-  const int j4 = j0 + 8 * w + 4 * kk;              // rows (4w+q): j = j4 + q, q = 0..3
-  const int b = b0 + li;
-  const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
-  constexpr int WS = 2 * 16 * 64;                  // floats per wave and round
-  float* mine = vg_red + (int64_t)w * WS;
-  auto sum4 = [&](const float* p) { return (p[0] + p[WS]) + (p[2 * WS] + p[3 * WS]); };
-  float rg[4], zg[4];
-  // round 1: r, z
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    mine[(0 * 16 + r) * 64 + lane] = acc_r[r];
-    mine[(1 * 16 + r) * 64 + lane] = acc_z[r];
-  }
-  __syncthreads();
-  {
-    const float4 bR = *reinterpret_cast<const float4*>(bias + j4);
-    const float4 bZ = *reinterpret_cast<const float4*>(bias + 512 + j4);
-    const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = w * 4 + q;
-      rg[q] = vsigmoid(sum4(vg_red + (0 * 16 + r) * 64 + lane) * inv + br[q]);
-      zg[q] = vsigmoid(sum4(vg_red + (1 * 16 + r) * 64 + lane) * inv + bz[q]);
-    }
-  }
-  __syncthreads();
-  // round 2: W_in x, W_hn h
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    mine[(0 * 16 + r) * 64 + lane] = acc_in[r];
-    mine[(1 * 16 + r) * 64 + lane] = acc_hn[r];
-  }
-  const float4 hp4 = *reinterpret_cast<const float4*>(hprev + hoff);
-  __syncthreads();
-  const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
-  const float4 bI = *reinterpret_cast<const float4*>(bias + 1024 + j4);
-  const float4 bH = *reinterpret_cast<const float4*>(bias + 1536 + j4);
-  const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
-  float hn[4];
-  unsigned short q0[4], q1[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = w * 4 + q;
-    const float s_in = sum4(vg_red + (0 * 16 + r) * 64 + lane);
-    const float s_hn = sum4(vg_red + (1 * 16 + r) * 64 + lane);
-    const float ng = tanhf((s_in * inv + bi[q]) + rg[q] * (s_hn * inv + bh[q]));
-    hn[q] = (hp[q] - ng) * zg[q] + ng;
-    const float hs = hn[q] * VGRU_STATE_SCALE;
-    const _Float16 p0 = (_Float16)hs;
-    const _Float16 p1 = (_Float16)(hs - (float)p0);
-    q0[q] = __builtin_bit_cast(unsigned short, p0);
-    q1[q] = __builtin_bit_cast(unsigned short, p1);
-  }
-  *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-  const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
-  *reinterpret_cast<uint2*>(gnext + goff) =
-      make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
-  *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
-      make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
-}
-
 
 // =====================================================================================================
 // Round 3: the GROUP step kernel.  One launch per alignment row serves the columns of several targets
@@ -396,20 +191,13 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)vg2_smem;
   const unsigned ring_addr = lds_base + half * (VG_RING_SLOTS * 16);
   const uint4* ring_l = reinterpret_cast<const uint4*>(vg2_smem) + half * VG_RING_SLOTS + lane;
-#ifdef VG_DBG_NOTHING
-  if (ntiles > 0) return;
-#endif
 
   auto dma_slot = [&](int c) {                        // this wave's share of slot c (weights of k-steps 2c, 2c+1)
     const unsigned dst = ring_addr + (unsigned)((c % VG_R) * VG_CK * VG_FRAGS) * 1024u;
 #pragma unroll
     for (int n = 0; n < D; ++n) {
       const int i = wl + n * NW, ks = i / VG_FRAGS, f = i - ks * VG_FRAGS;
-#ifdef VG_DBG_SAMEADDR
-      vg_dma16(wsrc + (int64_t)(f * 64 + 2 * ks) * 512, dst + (unsigned)i * 1024u);
-#else
       vg_dma16(wsrc + (int64_t)(f * 64 + 2 * (c * VG_CK + ks)) * 512, dst + (unsigned)i * 1024u);
-#endif
     }
   };
   constexpr int DIST = VG_R - 1;                      // the weight DMA runs DIST slots ahead of the MFMAs
@@ -454,11 +242,7 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
 #pragma unroll
     for (int ks = 0; ks < VG_CK; ++ks)
 #pragma unroll
-#ifdef VG_DBG_SAMEADDR
-      for (int p = 0; p < 2; ++p) b[ks][p] = vg_gload16(xsrc + (int64_t)(p * 64 + 2 * ks) * Lb);
-#else
       for (int p = 0; p < 2; ++p) b[ks][p] = vg_gload16(xsrc + (int64_t)(p * 64 + 2 * (c * VG_CK + ks)) * Lb);
-#endif
   };
 
   f32x16 acc_r, acc_z, acc_t, acc_in;     // r, z, third gate (recurrent: W_hn h; input: W_in x); layer 0: + W_in x
@@ -467,31 +251,9 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
 
   // The weight fragments of k-step ks+1 are read from the ring while the nine MFMAs of k-step ks run: left to itself
   // the compiler sinks every ds_read to its first use (read, wait, one MFMA, read, wait, ... - the LDS latency shows
-  // four times per k-step); the scheduling barrier behind the reads keeps them a k-step ahead.  VG_NOPIN=1: the
-  // unpinned form for comparison.
+  // four times per k-step); the scheduling barrier behind the reads keeps them a k-step ahead.  
   auto compute = [&](const vg_u32x4 (&b)[VG_CK][2], int c) {
     const uint4* a_l = ring_l + (c % VG_R) * (VG_CK * VG_FRAGS * 64);
-#if defined(VG_NOPIN) || defined(VG_DBG_NOMFMA)
-#pragma unroll
-    for (int ks = 0; ks < VG_CK; ++ks) {
-      uint4 a[VG_FRAGS];                               // a[piece * 3 + gate]
-#pragma unroll
-      for (int f = 0; f < VG_FRAGS; ++f) a[f] = a_l[(ks * VG_FRAGS + f) * 64];
-#ifdef VG_DBG_NOMFMA
-      acc_r[0] += __builtin_bit_cast(float, a[0].x ^ a[1].y ^ a[2].z ^ a[3].w ^ a[4].x ^ a[5].y ^ b[ks][0].x ^ b[ks][1].y);
-      continue;
-#endif
-      acc_r = vg_mfma2(a[0], b[ks][1], acc_r);         // small products first: w0 h1, w1 h0, then w0 h0
-      acc_z = vg_mfma2(a[1], b[ks][1], acc_z);
-      acc_t = vg_mfma2(a[2], b[ks][1], acc_t);
-      acc_r = vg_mfma2(a[3], b[ks][0], acc_r);
-      acc_z = vg_mfma2(a[4], b[ks][0], acc_z);
-      acc_t = vg_mfma2(a[5], b[ks][0], acc_t);
-      acc_r = vg_mfma2(a[0], b[ks][0], acc_r);
-      acc_z = vg_mfma2(a[1], b[ks][0], acc_z);
-      acc_t = vg_mfma2(a[2], b[ks][0], acc_t);
-    }
-#else
     uint4 an[VG_FRAGS];
 #pragma unroll
     for (int f = 0; f < VG_FRAGS; ++f) an[f] = a_l[f * 64];
@@ -515,7 +277,6 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
       acc_z = vg_mfma2(a[1], b[ks][0], acc_z);
       acc_t = vg_mfma2(a[2], b[ks][0], acc_t);
     }
-#endif
   };
 
   // VMEM order of a wave: DMA(0 .. DIST-1) touch B(0) | slot c: B(c+1) DMA(c+DIST).  At the top of slot c+1
@@ -535,11 +296,7 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
     const unsigned char* q = M.msa + (int64_t)(t < N ? t : 0) * L + col;
     asm volatile("global_load_ubyte %0, %1, off" : "+v"(pf2) : "v"(q) : "memory");
   }
-#ifdef VG_DBG_NOLOOP
-  constexpr int C_END = 0;
-#else
   constexpr int C_END = VG_NC - 2;
-#endif
 #pragma unroll 1
   for (int c = 0; c < C_END; c += 2) {
     __syncthreads();                                   // slot c is complete; every wave is done with slot c-1
@@ -646,14 +403,9 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
         if (prod == 0) { s_r = acc_r[r] + o_r; s_z = acc_z[r] + o_z; s_hn = acc_t[r]; s_in = o_t; }
         else           { s_r = o_r + acc_r[r]; s_z = o_z + acc_z[r]; s_hn = o_t; s_in = acc_t[r]; }
       }
-#ifdef VG_DBG_NOEPI
-      const float rg = s_r * inv + br[q], zg = s_z * inv + bz[q];
-      const float ng = (s_in * inv + bi[q]) + rg * (s_hn * inv + bh[q]);
-#else
       const float rg = vg_sigmoid(s_r * inv + br[q]);
       const float zg = vg_sigmoid(s_z * inv + bz[q]);
       const float ng = vg_tanh((s_in * inv + bi[q]) + rg * (s_hn * inv + bh[q]));
-#endif
       hn[q] = (hp[q] - ng) * zg + ng;
       const float hs = hn[q] * VGRU_STATE_SCALE;
       const _Float16 p0 = (_Float16)hs;
@@ -670,106 +422,262 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
   }
 }
 
-// out[l][j] = hP[j/4][l][j%4]
-__global__ __launch_bounds__(128) void vgru_out_kernel(const float* __restrict__ hP, int Lb,
-                                                       float* __restrict__ out) {
-  const int l = blockIdx.x, j4 = threadIdx.x;
-  const float4 v = *reinterpret_cast<const float4*>(hP + ((int64_t)j4 * Lb + l) * 4);
-  *reinterpret_cast<float4*>(out + (int64_t)l * WIDTH + 4 * j4) = v;
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary form (round 4): the whole chain of a group in ONE launch.
+//
+// The per-row launches above restart from cold L2s 2001 times (24 MB of fabric reads per row for one target against
+// 9.4 MB of weight pieces) and a row costs 16.8 (one target) .. 47 us (eight) against 2.2 .. 17.6 us of matrix-core time.
+// Here the chain is partitioned by COLUMNS over the XCDs and by HIDDEN UNITS over the 32 CUs of an XCD:
+//   * XCD x owns a contiguous range of the group's column tiles - the state of a column never leaves its XCD, so a row
+//     boundary is an XCD-local barrier (plain stores that stop in the XCD's L2, sc1 loads that find them there:
+//     common.h, cluster hand-off), and the eight XCDs never synchronise with each other at all;
+//   * CU u of an XCD owns hidden units 16u .. 16u+15 of BOTH layers, all three gates, all three products (layer-0
+//     recurrent, layer-1 input, layer-1 recurrent): its gate arithmetic is local, and its share of the weight pieces -
+//     295 KB - never moves again: wave w keeps the K quarter [128w, 128w+128) of the two layer-1 products in 192
+//     accumulation registers (the A operands of v_mfma_f32_16x16x32_f16 are read straight from AGPRs) and of the
+//     layer-0 product in 24 KB of LDS.  9.4 MB of weights per XCD live in 32 x (registers + LDS); nothing is streamed;
+//   * per row and column tile a wave multiplies its K quarter (216 MFMAs 16x16x32, float32-grade: w0 h1 + w1 h0 + w0 h0
+//     as above) against the tile's state pieces read from the L2 (32 KB per wave and tile), the four waves' partial
+//     sums meet in LDS, 256 threads finish 16 hidden units x 32 columns x 2 layers.
+// One workgroup per CU (160 KB of LDS, 1 wave per SIMD with up to 512 registers): the launch owns the machine while it
+// runs - which is what the scheduler wants of a chain (a front-end phase has no convolutions to run beside it).
+// Summation order: K quarters in wave order, k ascending inside a quarter - independent of what else is in the group,
+// so a member's result is the same bits whatever the grouping; against the per-row kernel (K in 32 ascending k-steps
+// of one accumulator) the results agree to float32 rounding (tests: 1e-5 against the oracle's nn.GRU either way).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float vp_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int VP_WL0_SLOTS = 4 * 4 * 6 * 64;                 // [wave][k-step][piece x gate][lane] 16-byte slots: 98 304 B
+constexpr int VP_RED_SLOTS = 4 * 14 * 64;                    // [wave][accumulator][lane] float4: 57 344 B
+constexpr int VP_TAB_FLOATS = 3 * 24 * 16;                   // [gate][code][row] one-hot input terms: 4 608 B
+constexpr int VP_LDS_BYTES = (VP_WL0_SLOTS + VP_RED_SLOTS) * 16 + VP_TAB_FLOATS * 4;     // 160 256 of 163 840
+constexpr int VP_GRID = 256;                                 // one workgroup per CU, 32 per XCD
+struct VPSync { unsigned count[8]; unsigned pad[24]; unsigned flag[8][32]; };              // zeroed before every launch
+static_assert(sizeof(VPSync) == 128 + 1024, "VPSync layout");
+
+__device__ __forceinline__ vp_f32x4 vp_mfma_a(vg_u32x4 a, vg_u32x4 b, vp_f32x4 c) {        // A from an AGPR quad
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
+  return c;
+}
+__device__ __forceinline__ vp_f32x4 vp_mfma_v(uint4 a, vg_u32x4 b, vp_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vg_f16x8, a), __builtin_bit_cast(vg_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ vg_u32x4 vp_load16_sc1(const void* p) {                         // past the L1: served by the XCD's L2
+  vg_u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N> __device__ __forceinline__ void vp_wait8(vg_u32x4 (&b)[2][2], vg_u32x4 (&c)[2][2]) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]),
+                                       "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]) : "n"(N) : "memory");
 }
 
-__global__ void vgru_set_run_kernel(VRun* run, const uint8_t* msa, int N, int L, int Lb, int t0, int t_end) {
-  run->msa = msa; run->N = N; run->L = L; run->Lb = Lb; run->t0 = t0; run->t_end = t_end;
-}
-
-// A chain of `len` step-kernel nodes (idx = 0..len-1) for a given grid; built once per context and
-// grid size.  Replaying it costs one host call instead of `len` launches, and the gap between
-// dependent kernels is 1.8 us instead of 2.8 us (tools/ubench_launch.hip).
-static int vgru_graph(dmp_ctx* c, int grid, int len, hipGraphExec_t* out) {
-  const int64_t key = ((int64_t)grid << 16) | len;
-  auto it = c->vgru_graphs.find(key);
-  if (it != c->vgru_graphs.end()) { *out = (hipGraphExec_t)it->second; return DMP_OK; }
-  const Weights& W = c->W;
-  VStatic st{};
-  for (int l = 0; l < 2; ++l) {
-    st.wx[l] = reinterpret_cast<const uint4*>(W.v_wx[l]);
-    st.wh[l] = reinterpret_cast<const uint4*>(W.v_wh[l]);
-    st.inv_scale[l] = W.v_inv_scale[l];
-    for (int p = 0; p < 2; ++p) { st.hT[l][p] = c->hT[l][p]; st.hH[l][p] = c->hH[l][p]; }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* __restrict__ sync, int* __restrict__ fault,
+                         int t_lo, int t_hi, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vp_smem[];
+  uint4* wl0 = reinterpret_cast<uint4*>(vp_smem);
+  vp_f32x4* red = reinterpret_cast<vp_f32x4*>(vp_smem + VP_WL0_SLOTS * 16);
+  float* tab = reinterpret_cast<float*>(vp_smem + (VP_WL0_SLOTS + VP_RED_SLOTS) * 16);
+  __shared__ int sh_u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  if (tid == 0) sh_u = (int)__hip_atomic_fetch_add(&sync->count[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int u = sh_u;                                  // this workgroup's hidden-unit slice on its XCD
+  if (u >= 32) {                                       // more than 32 workgroups landed on this XCD: another one is short
+    if (tid == 0) atomicOr(fault, DMP_FAULT_VGRU_HANDOFF);
+    return;
   }
-  st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
-  const VRun* run = reinterpret_cast<const VRun*>(c->vgru_run);
-  hipGraph_t g;
-  DMP_HIP(hipGraphCreate(&g, 0));
-  hipGraphNode_t prev = nullptr;
-  for (int idx = 0; idx < len; ++idx) {
-    int idx_arg = idx;
-    void* params[3] = {(void*)&st, (void*)&run, (void*)&idx_arg};
-    hipKernelNodeParams kp{};
-    kp.func = (void*)vgru_step_kernel;
-    kp.gridDim = dim3(grid);
-    kp.blockDim = dim3(256);
-    kp.sharedMemBytes = VG_LDS_BYTES;
-    kp.kernelParams = params;
-    kp.extra = nullptr;
-    hipGraphNode_t node;
-    hipError_t e = hipGraphAddKernelNode(&node, g, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
-    if (e != hipSuccess) { (void)hipGraphDestroy(g); return hip_fail(e, "hipGraphAddKernelNode", __FILE__, __LINE__); }
-    prev = node;
-  }
-  hipGraphExec_t ge;
-  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
-  c->vgru_graphs[key] = (void*)ge;
-  *out = ge;
-  return DMP_OK;
-}
+  const int j0 = 16 * u, lr = lane & 15, lq = lane >> 4;
+  const int Lb = ntiles * VG_TB;
+  const int c_lo = (int)(((long long)ntiles * xcc) / 8), c_hi = (int)(((long long)ntiles * (xcc + 1)) / 8);
 
-static int gru_vertical_steps_legacy(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
-                                     hipStream_t s) {
-  const int Lb = vgru_pitch(L);
-  const size_t hbytes = sizeof(float) * WIDTH * Lb;
-  if (t_lo <= 0) {
-    t_lo = 0;
-    for (int l = 0; l < 2; ++l) {
-      DMP_HIP(hipMemsetAsync(c->hT[l][0], 0, hbytes, s));
-      DMP_HIP(hipMemsetAsync(c->hH[l][0], 0, hbytes, s));     // 2 pieces x 512 x Lb x 2 bytes
+  // ---- this wave's weights: K quarter w, rows j0 .. j0+15; fragment f = (k-step, piece, gate)
+  vg_u32x4 WA[24], WB[24];                             // layer-1 input (from h0) and recurrent (from h1) products
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int pg = 0; pg < 6; ++pg) {
+      const int64_t off = (int64_t)(pg * 64 + 16 * w + 4 * ks + lq) * 512 + j0 + lr;
+      const uint4 a = st.wx[1][off], b = st.wh[1][off], c0 = st.wh[0][off];
+      WA[ks * 6 + pg] = vg_u32x4{a.x, a.y, a.z, a.w};
+      WB[ks * 6 + pg] = vg_u32x4{b.x, b.y, b.z, b.w};
+      wl0[((w * 4 + ks) * 6 + pg) * 64 + lane] = c0;
     }
+  // one-hot input of layer 0: the term a residue code adds to a gate's sum = 1024 (w0 + w1)[row, code], as the
+  // product of the f16 pieces with the state scale
+  for (int i = tid; i < 3 * 22 * 16; i += 256) {
+    const int g = i / (22 * 16), code = (i / 16) % 22, row = i & 15;
+    const uint16_t* wp = reinterpret_cast<const uint16_t*>(st.wx[0]);
+    const int64_t e0 = ((int64_t)((0 * 3 + g) * 4 + code / 8) * 512 + j0 + row) * 8 + code % 8;
+    const int64_t e1 = ((int64_t)((1 * 3 + g) * 4 + code / 8) * 512 + j0 + row) * 8 + code % 8;
+    tab[(g * 24 + code) * 16 + row] = VGRU_STATE_SCALE * ((float)__builtin_bit_cast(_Float16, wp[e0]) + (float)__builtin_bit_cast(_Float16, wp[e1]));
   }
-  if (t_hi > N + 1) t_hi = N + 1;
-  const int grid = vgru_grid(Lb);
-  VRun* run = reinterpret_cast<VRun*>(c->vgru_run);
-  for (int t = t_lo; t < t_hi;) {
-    const int len = (t_hi - t > VGRU_CHUNK / 2) ? VGRU_CHUNK : VGRU_CHUNK_SMALL;
-    hipGraphExec_t ge;
-    int rc = vgru_graph(c, grid, len, &ge);
-    if (rc) return rc;
-    hipLaunchKernelGGL(vgru_set_run_kernel, dim3(1), dim3(1), 0, s, run, d_msa, N, L, Lb, t, t_hi);
-    DMP_HIP(hipGraphLaunch(ge, s));
-    t += len;
-  }
-  DMP_LAUNCH_CHECK();
-  if (t_hi == N + 1) {
-    hipLaunchKernelGGL(vgru_out_kernel, dim3(L), dim3(128), 0, s, c->hT[1][N & 1], Lb, d_out);
-    DMP_LAUNCH_CHECK();
-  }
-  return DMP_OK;
-}
+  // finishing thread: layer fl, rows j0 + 4 fg .. +3, column fc of the tile
+  const int fl = tid >> 7, fg = (tid >> 5) & 3, fc = tid & 31;
+  const int flane = 16 * fg + (fc & 15), fnt = fc >> 4;
+  const int j4 = j0 + 4 * fg;
+  const float4 bR = *reinterpret_cast<const float4*>(st.bias[fl] + j4);
+  const float4 bZ = *reinterpret_cast<const float4*>(st.bias[fl] + 512 + j4);
+  const float4 bI = *reinterpret_cast<const float4*>(st.bias[fl] + 1024 + j4);
+  const float4 bH = *reinterpret_cast<const float4*>(st.bias[fl] + 1536 + j4);
+  const float inv = st.inv_scale[fl];
+  const int nmem = rec->nmem;
+  __syncthreads();
 
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int par = t & 1;
+    const uint4* h0p = reinterpret_cast<const uint4*>(st.hH[0][par]);          // layer 0 state at row t (both layers read it)
+    const uint4* h1p = reinterpret_cast<const uint4*>(st.hH[1][par ^ 1]);      // layer 1 state at row t-1
+    for (int ct = c_lo; ct < c_hi; ++ct) {
+      int mi = 0;
+      for (int m = 1; m < VG_MAX_MEMBERS; ++m)
+        if (m < nmem && ct >= rec->mem[m].tile0) mi = m;
+      const int N = rec->mem[mi].N, L = rec->mem[mi].L;
+      const bool act0 = t < N, act1 = t >= 1 && t <= N;
+      if (!act0 && !act1) continue;
+      const int tcol = ct * VG_TB;
+      // ---- state pieces of this wave's K quarter: [k-step][piece][column half]
+      vg_u32x4 b0[4][2][2], b1[4][2][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int64_t off = (int64_t)(p * 64 + 16 * w + 4 * ks + lq) * Lb + tcol + nt * 16 + lr;
+            b0[ks][p][nt] = vp_load16_sc1(h0p + off);
+            b1[ks][p][nt] = vp_load16_sc1(act1 ? h1p + off : h0p + off);
+          }
+      vp_f32x4 a0[3][2], a1[4][2];                     // layer 0: r z hn; layer 1: r z hn in; x column half
+#pragma unroll
+      for (int g = 0; g < 3; ++g) { a0[g][0] = vp_f32x4{0, 0, 0, 0}; a0[g][1] = vp_f32x4{0, 0, 0, 0}; }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { a1[g][0] = vp_f32x4{0, 0, 0, 0}; a1[g][1] = vp_f32x4{0, 0, 0, 0}; }
+      auto kstep = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        vp_wait8<8 * (3 - ks)>(b0[ks], b1[ks]);
+        if (act0) {
+          uint4 f[6];
+#pragma unroll
+          for (int pg = 0; pg < 6; ++pg) f[pg] = wl0[((w * 4 + ks) * 6 + pg) * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {              // small products first: w0 h1, w1 h0, then w0 h0
+              a0[g][nt] = vp_mfma_v(f[g], b0[ks][1][nt], a0[g][nt]);
+              a0[g][nt] = vp_mfma_v(f[3 + g], b0[ks][0][nt], a0[g][nt]);
+              a0[g][nt] = vp_mfma_v(f[g], b0[ks][0][nt], a0[g][nt]);
+            }
+        }
+        if (act1) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+              const int qa = g == 2 ? 3 : g, qb = g;   // the third gate's input and recurrent sums stay apart
+              a1[qb][nt] = vp_mfma_a(WB[ks * 6 + g], b1[ks][1][nt], a1[qb][nt]);
+              a1[qb][nt] = vp_mfma_a(WB[ks * 6 + 3 + g], b1[ks][0][nt], a1[qb][nt]);
+              a1[qb][nt] = vp_mfma_a(WB[ks * 6 + g], b1[ks][0][nt], a1[qb][nt]);
+              a1[qa][nt] = vp_mfma_a(WA[ks * 6 + g], b0[ks][1][nt], a1[qa][nt]);
+              a1[qa][nt] = vp_mfma_a(WA[ks * 6 + 3 + g], b0[ks][0][nt], a1[qa][nt]);
+              a1[qa][nt] = vp_mfma_a(WA[ks * 6 + g], b0[ks][0][nt], a1[qa][nt]);
+            }
+        }
+      };
+      kstep(std::integral_constant<int, 0>{});
+      kstep(std::integral_constant<int, 1>{});
+      kstep(std::integral_constant<int, 2>{});
+      kstep(std::integral_constant<int, 3>{});
+      // ---- partial sums of the four K quarters meet in LDS
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) red[(w * 14 + g * 2 + nt) * 64 + lane] = a0[g][nt];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) red[(w * 14 + 6 + g * 2 + nt) * 64 + lane] = a1[g][nt];
+      __syncthreads();
+      if (fl ? act1 : act0) {
+        const int nq = fl ? 4 : 3, base = fl ? 6 : 0;
+        vp_f32x4 sum[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < nq) {
+            const int a = base + q * 2 + fnt;
+            sum[q] = ((red[(0 * 14 + a) * 64 + flane] + red[(1 * 14 + a) * 64 + flane]) + red[(2 * 14 + a) * 64 + flane]) +
+                     red[(3 * 14 + a) * 64 + flane];
+          }
+        }
+        const int b = tcol + fc;
+        if (fl == 0) {
+          const int bm = (ct - rec->mem[mi].tile0) * VG_TB + fc;              // the column in ITS alignment
+          const int code = bm < L ? (int)rec->mem[mi].msa[(int64_t)t * L + bm] : 0;
+          const float* tr = tab + (0 * 24 + code) * 16 + 4 * fg;
+          const float* tz = tab + (1 * 24 + code) * 16 + 4 * fg;
+          const float* tn = tab + (2 * 24 + code) * 16 + 4 * fg;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { sum[0][i] += tr[i]; sum[1][i] += tz[i]; sum[3][i] = tn[i]; }
+        }
+        const float* hprev = fl ? st.hT[1][par ^ 1] : st.hT[0][par];
+        float* hnext = fl ? st.hT[1][par] : st.hT[0][par ^ 1];
+        uint16_t* gnext = fl ? st.hH[1][par] : st.hH[0][par ^ 1];
+        const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
+        const vg_u32x4 hpu = vp_load16_sc1(hprev + hoff);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float hp[4] = {__builtin_bit_cast(float, hpu.x), __builtin_bit_cast(float, hpu.y),
+                             __builtin_bit_cast(float, hpu.z), __builtin_bit_cast(float, hpu.w)};
+        const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
+        const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
+        float hn[4];
+        unsigned short q0[4], q1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float rg = vg_sigmoid(sum[0][i] * inv + br[i]);
+          const float zg = vg_sigmoid(sum[1][i] * inv + bz[i]);
+          const float ng = vg_tanh((sum[3][i] * inv + bi[i]) + rg * (sum[2][i] * inv + bh[i]));
+          hn[i] = (hp[i] - ng) * zg + ng;
+          const float hs = hn[i] * VGRU_STATE_SCALE;
+          const _Float16 p0 = (_Float16)hs;
+          const _Float16 p1 = (_Float16)(hs - (float)p0);
+          q0[i] = __builtin_bit_cast(unsigned short, p0);
+          q1[i] = __builtin_bit_cast(unsigned short, p1);
+        }
+        *reinterpret_cast<float4*>(hnext + hoff) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        const int64_t goff = ((int64_t)(j4 >> 3) * Lb + b) * 8 + (j4 & 7);
+        *reinterpret_cast<uint2*>(gnext + goff) =
+            make_uint2((unsigned)q0[0] | ((unsigned)q0[1] << 16), (unsigned)q0[2] | ((unsigned)q0[3] << 16));
+        *reinterpret_cast<uint2*>(gnext + (int64_t)64 * Lb * 8 + goff) =
+            make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
+      }
+      __syncthreads();                                 // `red` is free for the next tile
+    }
+    // ---- row boundary: every workgroup of this XCD has written its rows of the new state
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
+    __syncthreads();
+    const unsigned epoch = (unsigned)(t - t_lo + 1);
+    if (tid == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(&sync->flag[xcc][u]), "v"(epoch) : "memory");
+    if (w == 0) {
+      const unsigned* fp = &sync->flag[xcc][lane & 31];
+      bool ok = false;
+      for (unsigned spins = 0; spins < 4000000u && !ok; ++spins) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(fp) : "memory");
+        ok = __builtin_amdgcn_ballot_w64(v < epoch) == 0ull;
+      }
+      if (!ok && lane == 0) atomicOr(fault, DMP_FAULT_VGRU_HANDOFF);
+    }
+    __syncthreads();
+  }
+}
 
 // ---- group launcher ---------------------------------------------------------------------------------
-static int vgru2_nw(int ntiles) {
-  static const int forced = getenv("DMP_VGRU_NW") ? atoi(getenv("DMP_VGRU_NW")) : 0;     // tuning experiments
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
-  return ntiles >= 24 ? 4 : (ntiles >= 12 ? 2 : 1);
-}
-
-static int vgru2_cgs(int ntiles) {
-  static const int forced = getenv("DMP_VGRU_CGS") ? atoi(getenv("DMP_VGRU_CGS")) : 0;   // tuning experiments
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
-  return ntiles >= 24 ? 2 : 1;
-}
+static int vgru2_nw(int ntiles) { return ntiles >= 24 ? 4 : (ntiles >= 12 ? 2 : 1); }
+static int vgru2_cgs(int ntiles) { return ntiles >= 24 ? 2 : 1; }
 
 static int vgru2_graph(dmp_ctx* c, int ntiles, int nw, int cgs, int len, hipGraphExec_t* out) {
   const int grid = vgru2_grid(ntiles, nw, cgs);
@@ -815,7 +723,14 @@ static int vgru2_graph(dmp_ctx* c, int ntiles, int nw, int cgs, int len, hipGrap
   return DMP_OK;
 }
 
-int vgru_kernel_attrs(dmp_ctx*) {
+int vgru_kernel_attrs(dmp_ctx* c) {
+  DMP_HIP(hipFuncSetAttribute((const void*)vgru_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, VP_LDS_BYTES));
+  {
+    // the persistent form is laid out for 256 CUs in 8 XCDs (one workgroup per CU, 32 per XCD)
+    int cus = 0;
+    DMP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    c->vgru_persist_ok = cus == VP_GRID;
+  }
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
@@ -869,6 +784,25 @@ int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
   if (t_lo < 0) t_lo = 0;
   if (t_lo & 1) { set_error("vertical-GRU chunks start at even rows (got %d)", t_lo); return DMP_ERR_ARG; }
   VGroupRec* rec = reinterpret_cast<VGroupRec*>(lead->vgru_run);
+  if (lead->vgru_persist && lead->vgru_persist_ok) {
+    // one launch for all the rows: XCD-local row barriers inside (vgru_persist_kernel)
+    const Weights& W = lead->W;
+    VStatic st{};
+    for (int l = 0; l < 2; ++l) {
+      st.wx[l] = reinterpret_cast<const uint4*>(W.v_wx[l]);
+      st.wh[l] = reinterpret_cast<const uint4*>(W.v_wh[l]);
+      st.inv_scale[l] = W.v_inv_scale[l];
+      for (int p = 0; p < 2; ++p) { st.hT[l][p] = lead->hT[l][p]; st.hH[l][p] = lead->hH[l][p]; }
+    }
+    st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
+    if (t_lo >= t_hi) return DMP_OK;
+    VPSync* sync = reinterpret_cast<VPSync*>(lead->vgru_sync);
+    DMP_HIP(hipMemsetAsync(sync, 0, sizeof(VPSync), s));
+    hipLaunchKernelGGL(vgru_persist_kernel, dim3(VP_GRID), dim3(256), VP_LDS_BYTES, s, st, (const VGroupRec*)rec, sync,
+                       lead->seq_abort, t_lo, t_hi, nt);
+    DMP_LAUNCH_CHECK();
+    return DMP_OK;
+  }
   for (int t = t_lo; t < t_hi;) {
     // whole 128-row chains, then 16-row chains: an idle node of a chain costs a full step (a step learns its row
     // number only after its main loop)
@@ -902,7 +836,6 @@ int vgru_group_output(dmp_ctx* lead, int mi, int N, int L, float* d_out, hipStre
 
 int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo, int t_hi, float* d_out,
                        hipStream_t s) {
-  if (c->vgru_legacy) return gru_vertical_steps_legacy(c, d_msa, N, L, t_lo, t_hi, d_out, s);
   int rc;
   if (t_lo <= 0) {
     t_lo = 0;

@@ -131,7 +131,7 @@ def load_state_dict(weights_file=None):
 
 
 # device-side fault bits (include/dmpfold_hip.h, DMP_FAULT_*)
-FAULT_SEQ_HANDOFF, FAULT_F16_RANGE, FAULT_REFINE_HANDOFF, FAULT_BAD_CODE, FAULT_EIG_HANDOFF = 1, 2, 4, 8, 16
+FAULT_SEQ_HANDOFF, FAULT_F16_RANGE, FAULT_REFINE_HANDOFF, FAULT_BAD_CODE, FAULT_EIG_HANDOFF, FAULT_VGRU_HANDOFF = 1, 2, 4, 8, 16, 32
 
 
 class DeviceFault(_lib.DmpError):
@@ -142,6 +142,7 @@ class DeviceFault(_lib.DmpError):
         what = [txt for bit, txt in ((FAULT_SEQ_HANDOFF, "sequence-GRU workgroup hand-off timed out"),
                                      (FAULT_REFINE_HANDOFF, "minimiser workgroup hand-off timed out"),
                                      (FAULT_EIG_HANDOFF, "tridiagonalisation workgroup hand-off timed out"),
+                                     (FAULT_VGRU_HANDOFF, "vertical-GRU row barrier timed out"),
                                      (FAULT_F16_RANGE, "an activation left the f16 range of the "
                                       "split-product convolution (conv_mode 2 has no range limit)"))
                 if bits & bit]
@@ -196,27 +197,6 @@ class Engine:
     def stream(self):
         s = self._stream if self._stream is not None else torch.cuda.current_stream(self.device)
         return C.c_void_p(s.cuda_stream)
-
-    def issue_phases(self, d_msa, iterations=default_iterations, minsteps=default_minsteps, out=None):
-        """Generator that enqueues one prediction phase by phase (features + sequence trunk, then
-        each trunk pass, then the final refinement); the caller interleaves several engines by
-        advancing their generators in turn.  The (coords, confs) tensors are appended to `out`."""
-        n, L = d_msa.shape
-        ctx = torch.cuda.stream(self._stream) if self._stream is not None else torch.cuda.device(self.device)
-        with ctx:
-            coords = torch.empty((L, 5, 3), dtype=torch.float32, device=self.device)
-            confs = torch.empty((L,), dtype=torch.float32, device=self.device)
-        nloops = int(max(iterations, 0))
-        _lib.check(self.lib.dmp_predict_begin(self._ctx, d_msa.data_ptr(), n, L, None, 0, nloops,
-                                              int(max(minsteps, 0)), self.stream()))
-        yield "begin"
-        for p in range(nloops + 1):
-            _lib.check(self.lib.dmp_predict_pass(self._ctx, self.stream()))
-            yield p
-        _lib.check(self.lib.dmp_predict_end(self._ctx, coords.data_ptr(), confs.data_ptr(),
-                                            self.stream()))
-        if out is not None:
-            out.append((coords, confs))
 
     def set_weights(self, state_dict, tag=None):
         """Strict load like load_state_dict (predict.py:98): unknown, missing or mis-shaped
@@ -341,19 +321,6 @@ class Engine:
         return out[:n]
 
 
-# DMP_PUMP_TIMING=1: host time of every dmp_predict_issue_unit call by unit kind (developer diagnostic)
-_PUMP_TIMING = {} if os.environ.get("DMP_PUMP_TIMING") else None
-
-
-def pump_timing_report():
-    import numpy as np
-    for kind, v in sorted((_PUMP_TIMING or {}).items()):
-        a = np.array(v) * 1e6
-        print(f"issue_unit kind {kind}: n={len(a)} mean {a.mean():.0f} us  p50 {np.percentile(a, 50):.0f}  "
-              f"p90 {np.percentile(a, 90):.0f}  p99 {np.percentile(a, 99):.0f}  max {a.max():.0f}  total {a.sum() / 1e3:.0f} ms",
-              file=sys.stderr)
-
-
 # Engine streams are reused from one pipeline of the process to the next: which hardware queues a stream gets depends
 # on how many streams were created before it, and on this runtime the SECOND set of four costs the scheduler 15 %
 # (tools/pipeline_order.py: 5.87 structures/s on pool streams 5-8 against 6.9-7.0 on every other set).
@@ -391,12 +358,10 @@ class Pipeline:
     an engine that is still in its eigensolver or front end.  Targets are taken from one queue by
     whichever engine is free."""
 
-    def __init__(self, device, max_L, max_N, state_dict, streams=2, stagger=False):
+    def __init__(self, device, max_L, max_N, state_dict, streams=2):
         self.lib = _lib.load()
         self.device = _resolve_device(device)
         self.engines = []
-        self._lane = C.c_void_p()
-        _lib.check(self.lib.dmp_lane_create(C.byref(self._lane)))
         for _ in range(max(1, int(streams))):
             st = _take_stream(self.device)
             eng = Engine(self.device, max_L, max_N, stream=st)
@@ -405,28 +370,23 @@ class Pipeline:
             else:
                 eng.set_weights(state_dict)
             if streams > 1:
-                _lib.check(self.lib.dmp_ctx_set_lane(eng.ctx, self._lane))
+                if self.engines:
+                    _lib.check(self.lib.dmp_ctx_share_lane(eng.ctx, self.engines[0].ctx))    # one lane for all of them
                 # Several engines: the eigensolver's Householder steps as one launch each, not as the cluster kernel
                 # (same bits).  The cluster is the faster form for ONE prediction (0.9 against 1.9 ms at L = 300), but
                 # its 32 resident workgroups poll beside the other engines' convolutions for that long: measured
                 # 7.39 / 7.32 structures/s with the launches against 7.29 / 7.30 (bench.py, alternating, one box).
-                if "DMP_TRIDIAG_CLUSTER" not in os.environ:
-                    eng.set_option("tridiag_cluster", 0)
+                eng.set_option("tridiag_cluster", 0)
             self.engines.append(eng)
         S = len(self.engines)
         self._pending = []            # (ticket, d_msa, iterations, minsteps)
         self._slot = [None] * S       # per engine: (ticket, coords, confs) of the prediction in flight
         self._done = [0] * S          # residual blocks issued / in total for the prediction in flight
         self._total = [0] * S
-        self._stagger = bool(stagger)
         self._results = {}
         self._done_ev = {}            # ticket -> event recorded behind dmp_predict_end (poll)
         self._jobs = {}               # ticket -> job, kept until the result is handed out (retry of faults)
         self._tickets = 0
-        # DMP_PUMP_SLEEP_US: sleep that long whenever a scheduling round found nothing to issue (default:
-        # only yield the core).  One scheduler thread per GPU polls HIP events; with 8 ranks on a node
-        # that is 8 polling threads, which yield to anything else runnable on their cores.
-        self._idle_sleep = float(os.environ.get("DMP_PUMP_SLEEP_US", "0")) * 1e-6
         # An engine issues its first residual block only when the engine that started before it is half a pass
         # (8 blocks) into its own.  The lane deals the blocks out in turn, so engines that leave their front
         # ends together would also reach the end of every pass together and sit in their pass tails
@@ -439,7 +399,7 @@ class Pipeline:
         # targets take 52-55 ms in one chain against 110 ms as four chains side by side.  A free engine therefore
         # waits for the engines that are about to finish (at most DMP_GROUP_PATIENCE residual blocks left) and
         # starts together with them, up to DMP_VGRU_GROUP members (1 = every prediction runs its own chain).
-        self._group_max = max(1, min(4, int(os.environ.get("DMP_VGRU_GROUP", "4"))))   # state buffers hold 4 x max_L columns
+        self._group_max = max(1, min(4, int(os.environ.get("DMP_VGRU_GROUP", "4"))))   # engines that start together (the state buffers hold 8 x max_L columns: members + riders)
         self._group_patience = int(os.environ.get("DMP_GROUP_PATIENCE", "40"))
         # Riders: a group's chain also serves the NEXT targets in the queue (dmp_predict_group_riders; members + riders
         # <= 8), whose results are handed over when those targets start (dmp_predict_set_vgru_result): a chain costs
@@ -449,95 +409,18 @@ class Pipeline:
         self._riders_max = max(0, min(7, int(os.environ.get("DMP_VGRU_RIDERS", "4")))) if S > 1 else 0
         self._riding = {}             # ticket -> True: a rider whose chain has not been issued to its end yet
         self._rider_wait = [None] * S  # per leading engine: (jobs, outs) of the riders in the chain it has yet to issue
-        # Look-ahead: the chain of the NEXT group touches none of the buffers the trunk passes use, so it is run
-        # beside the last DMP_VGRU_LOOKAHEAD residual blocks of the predictions in flight (on its own stream, in the
-        # state buffers of a context that predicts nothing itself) and handed to the engines when they start those
-        # targets (dmp_predict_set_vgru_result).  0 = off (the default): the chain runs in the group's front-end phase.
-        # Measured (bench.py, same box): 6.07-6.36 structures/s with a look-ahead of 24-176 blocks against 6.98-7.24
-        # without - a step kernel's 240 workgroups (8 waves, 72 KB of LDS each) only get onto a CU when a
-        # convolution workgroup retires there, so beside the convolutions the chain crawls and slows them.
-        # Detached chain: enqueuing a group's 2001 dependent launches keeps the calling thread busy for about as long
-        # as they run (kernel trace of the round-3 scheduler: between the first and the last step kernel of a
-        # chain - 58 ms - no other stream received anything, the members' inverses only started when the chain had
-        # ended).  The chain is therefore issued by a helper thread on its own stream
-        # (dmp_predict_detach_group_chain / dmp_predict_issue_group_chain) while this thread keeps issuing the
-        # members' covariance and inverse units, which run beside it.
-        # MEASURED (bench.py, alternating runs on one box, gpurun_out r03c): slower - 5.99 / 6.11 structures/s detached
-        # against 6.95 / 6.96: beside four inverses the chain's steps take 45 us instead of 26 (their 240 workgroups
-        # wait for CU slots 2001 times), the front-end phase grows from 99 to 110 ms.  Off by default;
-        # DMP_VGRU_DETACH=1 switches it on, DMP_VGRU_CHAIN_PRIO=1 gives the chain's stream the high HIP priority.
-        # DMP_VGRU_DETACH=2: the helper thread enqueues the chain on the LEADER'S OWN stream (no fifth stream: on this
-        # runtime a fifth active stream shares a hardware pipe with one of the four engines').
-        self._detach_own = os.environ.get("DMP_VGRU_DETACH", "0") == "2" and S > 1 and self._group_max > 1
-        self._detach = (os.environ.get("DMP_VGRU_DETACH", "0") == "1" and S > 1 and self._group_max > 1) or self._detach_own
-        self._chain_stream = None
-        self._chain_pool = None
-        self._chain_futures = []
-        if self._detach:
-            from concurrent.futures import ThreadPoolExecutor
-            if not self._detach_own:
-                with torch.cuda.device(self.device):
-                    prio = -1 if os.environ.get("DMP_VGRU_CHAIN_PRIO") == "1" else 0
-                    self._chain_stream = torch.cuda.Stream(device=self.device, priority=prio)
-            self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
-        # Features ahead: an engine in its trunk passes is given its NEXT target early and computes that target's
-        # reweighting, covariance, inverse and contacts into its own (idle) feature buffers, one unit after every
-        # 1 / (units + 1) of its residual blocks, on its own stream (dmp_predict_ahead_*): the f32 GEMMs run beside the
-        # convolutions of the other engines instead of in the front-end phase, where nothing else runs.
-        # MEASURED (bench.py, alternating runs on one box, gpurun_out r03m): the front-end phase shrinks from 94.7 to
-        # 71 ms per round of four as expected - and the convolutions beside which the inverses now run take 0.708
-        # instead of 0.676 ms of chip time each: 6.92 / 6.94 structures/s against 6.97 / 6.99.  The inverse costs the
-        # same machine time wherever it runs.  Off by default; DMP_FEATURES_AHEAD=1 switches it on.
-        self._features_ahead = os.environ.get("DMP_FEATURES_AHEAD", "0") == "1" and S > 1
-        self._reserved = [None] * S   # per engine: the job it will run next (features being computed ahead)
-        self._ahead_issued = [0] * S  # ahead units issued for it / in total
-        self._ahead_total = [0] * S
-        self._lookahead = int(os.environ.get("DMP_VGRU_LOOKAHEAD", "0")) if S > 1 else 0
-        self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain)
-        self._ahead_pending = None    # (future, jobs, outs): a look-ahead chain the helper thread is still enqueuing
-        self._fe = None
-        if self._lookahead > 0 and self._chain_pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._chain_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dmp-vgru-chain")
-        if self._lookahead > 0:
-            with torch.cuda.device(self.device):
-                st = torch.cuda.Stream(device=self.device)
-            fe = Engine(self.device, max_L, max_N, stream=st)
-            fe.share_weights(self.engines[0])
-            self._fe = fe
-
-    def _reap_chains(self, wait=False):
-        """Surface an error of the helper thread (a chain that failed to enqueue) in the scheduler's thread."""
-        keep = []
-        for f in self._chain_futures:
-            if wait or f.done():
-                f.result()
-            else:
-                keep.append(f)
-        self._chain_futures = keep
+        self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain it rode in)
+        with torch.cuda.device(self.device):
+            self._unit_ev = [[torch.cuda.Event(blocking=True), torch.cuda.Event(blocking=True)] for _ in range(S)]
+        self._unit_seq = [0] * S      # units issued per engine (the event of unit k: _unit_ev[s][k & 1])
 
     def close(self):
-        if self._chain_pool is not None:
-            try:
-                if self._ahead_pending is not None:
-                    self._ahead_pending[0].result()
-                    self._ahead_pending = None
-                self._reap_chains(wait=True)
-            finally:
-                self._chain_pool.shutdown(wait=True)
-                self._chain_pool = None
         for e in self.engines:
             e.close()
             if e._stream is not None:
                 _release_stream(self.device, e._stream)
         self.engines = []
-        if self._fe is not None:
-            self._fe.close()
-            self._fe = None
         self._ahead = {}
-        if self._lane:
-            self.lib.dmp_lane_destroy(self._lane)
-            self._lane = C.c_void_p()
 
     def __del__(self):
         try:
@@ -573,60 +456,13 @@ class Pipeline:
         self._jobs[t] = job
         return t
 
-    def _start_ahead(self, jobs):
-        """The vertical GRUs of these queued targets as one chain on the look-ahead stream, beside whatever the
-        engines are doing.  Enqueued by the helper thread (the 2001 launches keep the enqueuing thread busy for about
-        as long as they run, and this thread has the engines' last units to issue); the targets are started only
-        once the chain has been enqueued to its end (`_ahead_ready`)."""
-        fe = self._fe
-        cur = torch.cuda.current_stream(self.device)
-        fe._stream.wait_stream(cur)
-        k = len(jobs)
-        with torch.cuda.device(self.device):
-            outs = [torch.empty((job[1].shape[1], 512), dtype=torch.float32, device=self.device) for job in jobs]
-        for job, out in zip(jobs, outs):
-            job[1].record_stream(fe._stream)
-            out.record_stream(fe._stream)
-
-        def issue():
-            with torch.cuda.device(self.device):
-                ctxs = (C.c_void_p * k)(*[fe.ctx] * k)
-                mp = (C.c_void_p * k)(*[job[1].data_ptr() for job in jobs])
-                op = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
-                Ns = (C.c_int * k)(*[job[1].shape[0] for job in jobs])
-                Ls = (C.c_int * k)(*[job[1].shape[1] for job in jobs])
-                _lib.check(self.lib.dmp_gru_vertical_group(ctxs, k, mp, Ns, Ls, op, fe.stream()))
-                ev = torch.cuda.Event()
-                ev.record(fe._stream)
-                return ev
-        self._ahead_pending = (self._chain_pool.submit(issue), jobs, outs)
-
-    def _ahead_ready(self):
-        """True when no look-ahead chain is still being enqueued; hands a finished one over to `_ahead`."""
-        if self._ahead_pending is None:
-            return True
-        fut, jobs, outs = self._ahead_pending
-        if not fut.done():
-            return False
-        ev = fut.result()
-        for job, out in zip(jobs, outs):
-            self._ahead[job[0]] = (out, ev)
-        self._ahead_pending = None
-        return True
-
     def _begin_group(self, slots):
-        """Start the next len(slots) queued targets on these free engines; those whose vertical GRU was not run
-        ahead form one vertical-GRU group (the first of them leads)."""
+        """Start the next len(slots) queued targets on these free engines; those whose vertical GRU did not ride in an
+        earlier chain form one vertical-GRU group (the first of them leads), and the chain takes the next queued
+        targets along as riders."""
         grouped = []
         for s in slots:
-            if self._reserved[s] is not None:
-                job = self._reserved[s]
-                e = self.engines[s]
-                while self.lib.dmp_predict_ahead_left(e.ctx) > 0:      # what the trunk passes left no room for
-                    _lib.check(self.lib.dmp_predict_ahead_issue(e.ctx, e.stream()))
-            else:
-                job = self._pending.pop(0)
-            self._reserved[s] = None
+            job = self._pending.pop(0)
             self._done[s] = 0
             self._total[s] = (job[2] + 1) * 16
             self._begin(s, job)
@@ -648,7 +484,7 @@ class Pipeline:
                         x.record_stream(lead._stream)
             ctxs = (C.c_void_p * len(slots))(*[self.engines[s].ctx for s in slots])
             _lib.check(self.lib.dmp_predict_group_vgru(ctxs, len(slots)))
-            if self._riders_max and not self._detach and self._fe is None and not self._features_ahead:
+            if self._riders_max:
                 room = min(self._riders_max, 8 - len(slots))
                 jobs = [j for j in self._pending[:room] if j[0] not in self._ahead and j[0] not in self._riding]
                 if jobs:
@@ -667,23 +503,6 @@ class Pipeline:
                     self._rider_wait[slots[0]] = (jobs, outs)
                     for j in jobs:
                         self._riding[j[0]] = True
-            if self._detach:
-                cs = lead._stream if self._detach_own else self._chain_stream
-                cs.wait_stream(torch.cuda.current_stream(self.device))
-                for s in slots:
-                    for x in self._slot[s][3]:
-                        if x is not None:
-                            x.record_stream(cs)
-                _lib.check(self.lib.dmp_predict_detach_group_chain(lead.ctx))
-                if self._detach_own:
-                    # the leader's first unit (sequence weights + covariance) goes first, then the chain, on its stream
-                    _lib.check(self.lib.dmp_predict_issue_unit(lead.ctx, lead.stream()))
-                    _lib.check(self.lib.dmp_predict_chain_on_own_stream(lead.ctx))
-                self._chain_futures.append(self._chain_pool.submit(self._issue_chain, lead.ctx, cs.cuda_stream))
-
-    def _issue_chain(self, lead_ctx, stream_handle):
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.dmp_predict_issue_group_chain(lead_ctx, C.c_void_p(stream_handle)))
 
     def _begin(self, s, job):
         t, d_msa, nloops, minsteps, d_tpl, ready = job
@@ -711,70 +530,30 @@ class Pipeline:
         lib = self.lib
         gated = len(self.engines) > 1
         progressed = False
-        if self._chain_futures:
-            self._reap_chains()
         # engines whose next unit is a residual block: when there is only one, nobody else can use the
         # lane, so it may queue its next block behind the running one instead of draining first
         n_conv = sum(1 for s, e in enumerate(self.engines)
                      if self._slot[s] is not None and lib.dmp_predict_next_unit(e.ctx) == 2) if gated else 0
         free = [s for s in range(len(self.engines)) if self._slot[s] is None]
-        if self._fe is not None and self._pending and len(free) < len(self.engines):
-            # look-ahead: one group of queued targets at a time, once every prediction in flight is near its end
-            nxt = self._pending[:self._group_max]
-            if self._ahead_ready() and not any(j[0] in self._ahead for j in nxt) and all(
-                    self._total[r] - self._done[r] <= self._lookahead
-                    for r in range(len(self.engines)) if self._slot[r] is not None):
-                self._start_ahead(nxt)
-        # free engines that can start now: those holding a reserved target, then as many others as targets are queued
-        with_job = [r for r in free if self._reserved[r] is not None]
-        without = [r for r in free if self._reserved[r] is None][:len(self._pending)]
-        startable = with_job + without
-        if self._riding and any(j[0] in self._riding for j in self._pending[:len(without)]):
+        startable = free[:len(self._pending)]
+        if self._riding and any(j[0] in self._riding for j in self._pending[:len(startable)]):
             startable = []            # the chain these targets ride in has not been issued to its end yet
-        if startable and self._ahead_ready():
+        if startable:
             # engines about to finish: wait for them and start together (one vertical-GRU chain for the group)
             soon = [r for r in range(len(self.engines)) if self._slot[r] is not None
                     and self._total[r] - self._done[r] <= self._group_patience]
-            left = len(self._pending) - len(without)
-            soon_with_work = sum(1 for r in soon if self._reserved[r] is not None) + \
-                min(left, sum(1 for r in soon if self._reserved[r] is None))
+            soon_with_work = min(len(self._pending) - len(startable), len(soon))
             want = min(self._group_max, len(startable) + soon_with_work)
             if len(startable) >= want or not soon_with_work or self._group_max == 1:
-                # optional phase spacing (stagger=True): a prediction starts only when every other one
-                # in flight is at least 1/S of its way through its residual blocks.  Measured at
-                # L=300, N=2000, 3 engines, 48 targets: 5.24 structures/s with spacing, 5.75 without
-                # (the waiting engines cost more than coinciding front ends), so it is off by default.
-                S = len(self.engines)
-                if not (self._stagger and any(self._slot[r] is not None and self._done[r] * S < self._total[r]
-                                              for r in range(S))):
-                    if self._group_max == 1:
-                        for s in startable:
-                            self._begin_group([s])
-                    else:
-                        self._begin_group(startable[:max(want, 1)])
-                    progressed = True
+                if self._group_max == 1:
+                    for s in startable:
+                        self._begin_group([s])
+                else:
+                    self._begin_group(startable[:max(want, 1)])
+                progressed = True
         for s, e in enumerate(self.engines):
             if self._slot[s] is None:
                 continue
-            if self._features_ahead and self._done[s] > 0:
-                # in its trunk passes: reserve its next target and slip that target's feature units between its blocks
-                if self._reserved[s] is None and self._pending and self._done[s] < self._total[s]:
-                    job = self._pending.pop(0)
-                    n, L = job[1].shape
-                    if n > 1 and L <= e.max_L and n <= e.max_N:
-                        job[1].record_stream(e._stream)
-                        _lib.check(lib.dmp_predict_ahead_begin(e.ctx, job[1].data_ptr(), n, L))
-                        self._reserved[s] = job
-                        self._ahead_issued[s] = 0
-                        self._ahead_total[s] = lib.dmp_predict_ahead_left(e.ctx)
-                    else:
-                        self._pending.insert(0, job)
-                if self._reserved[s] is not None and self._ahead_issued[s] < self._ahead_total[s]:
-                    due = (self._ahead_issued[s] + 1) * self._total[s] // (self._ahead_total[s] + 1)
-                    if self._done[s] >= min(due, self._total[s]) and _lib.check(lib.dmp_ctx_pending(e.ctx)) <= 1:
-                        _lib.check(lib.dmp_predict_ahead_issue(e.ctx, e.stream()))
-                        self._ahead_issued[s] += 1
-                        progressed = True
             while True:
                 kind = lib.dmp_predict_next_unit(e.ctx)
                 if kind == 3:                         # waits for its group leader's vertical-GRU chain
@@ -806,13 +585,14 @@ class Pipeline:
                     busy = _lib.check(lib.dmp_ctx_pending(e.ctx))
                     if busy > (0 if (kind == 2 and n_conv > 1) else 1):
                         break
-                if _PUMP_TIMING is not None:
-                    t0 = time.perf_counter()
-                    _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
-                    _PUMP_TIMING.setdefault(kind, []).append(time.perf_counter() - t0)
-                else:
-                    _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
+                _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
                 progressed = True
+                if gated:
+                    # a (blocking-sync) event behind every unit: what `_idle` sleeps on when nothing can be issued
+                    ring = self._unit_ev[s]
+                    ev = ring[self._unit_seq[s] & 1]
+                    ev.record(e._stream)
+                    self._unit_seq[s] += 1
                 if self._rider_wait[s] is not None and lib.dmp_predict_chain_issued(e.ctx):
                     # the riders' results are behind this point of the leader's stream
                     jobs, outs = self._rider_wait[s]
@@ -829,12 +609,29 @@ class Pipeline:
         return progressed
 
     def _idle(self):
-        """Nothing could be issued: every engine waits for the GPU.  Give the core away instead of
-        polling flat out."""
-        if self._idle_sleep > 0:
-            time.sleep(self._idle_sleep)
+        """Nothing could be issued: every engine waits for the GPU (or for an engine that does).  Sleep until the
+        OLDEST outstanding unit of an engine has completed - an event created for blocking synchronisation, so the
+        thread is descheduled until the GPU's interrupt instead of polling (rounds 1-3 spun on sched_yield: one core
+        per GPU at 100 %).  The lane keeps two convolutions queued, so the 20-50 us of wake-up latency never leave it
+        empty."""
+        oldest = None
+        for s in range(len(self.engines)):
+            n = self._unit_seq[s]
+            for k in (n - 2, n - 1):                   # the two most recent units of the engine, older first
+                if k >= 0:
+                    ev = self._unit_ev[s][k & 1]
+                    if not ev.query():
+                        if oldest is None or self._unit_stamp(s, k) < oldest[0]:
+                            oldest = (self._unit_stamp(s, k), ev)
+                        break
+        if oldest is not None:
+            oldest[1].synchronize()
         else:
             os.sched_yield()
+
+    def _unit_stamp(self, s, k):
+        # issue order across engines is not recorded; the unit count is a good enough age (engines advance in step)
+        return k - self._unit_seq[s]
 
     def pump(self):
         """Schedule until every queued target has been started on an engine."""
@@ -847,10 +644,9 @@ class Pipeline:
         """Schedule until every queued target is fully enqueued; the current stream then waits for
         the engines' streams (nothing is synchronised with the host)."""
         with torch.cuda.device(self.device):
-            while self._pending or any(x is not None for x in self._slot) or any(x is not None for x in self._reserved):
+            while self._pending or any(x is not None for x in self._slot):
                 if not self._pump():
                     self._idle()
-        self._reap_chains(wait=True)
         cur = torch.cuda.current_stream(self.device)
         for e in self.engines:
             cur.wait_stream(e._stream)
@@ -877,7 +673,7 @@ class Pipeline:
         return len(self._pending)
 
     def busy(self):
-        return bool(self._pending) or any(x is not None for x in self._slot) or any(x is not None for x in self._reserved)
+        return bool(self._pending) or any(x is not None for x in self._slot)
 
     def poll(self):
         """Tickets whose prediction has COMPLETED on the GPU since the last call (their tensors may be read from

@@ -27,9 +27,14 @@
 extern "C" {
 #endif
 
-/* 2: dmp_sync_check returns DMP_ERR_FAULT / DMP_ERR_ARG (was DMP_ERR_HIP), dmp_sync_faults clears what it
- *    reports, dmp_ctx_get_option and dmp_dca_features added. */
-#define DMP_ABI_VERSION 2
+/* 3 (round 4): 45 functions instead of 60.  Removed: the experimental scheduler entry points that were measured
+ *    slower (detached group chain, chain on its own stream, features ahead: six functions), the convenience wrappers
+ *    predict_begin / predict_pass / predict_end_refine - dmp_predict and the unit calls cover them -, clear_faults and
+ *    sync_check - dmp_sync_faults reports and clears -, profile_conv_ms and time_conv5x5 - dmp_profile_conv_intervals
+ *    holds every launch's interval; the three lane functions became dmp_ctx_share_lane.  Options vgru_legacy and gj_lds are gone;
+ *    act_scaling and vgru_persistent are new; fault bit DMP_FAULT_VGRU_HANDOFF is new.
+ * 2: dmp_sync_faults clears what it reports, dmp_ctx_get_option and dmp_dca_features added. */
+#define DMP_ABI_VERSION 3
 #define DMP_MAX_SEQS 3000 /* predict.py:130-132: deeper MSAs are truncated */
 
 typedef struct dmp_ctx dmp_ctx;
@@ -40,7 +45,7 @@ typedef enum dmp_status {
   DMP_ERR_HIP = -2,     /* a HIP runtime call failed */
   DMP_ERR_WEIGHTS = -3, /* unknown key, wrong shape, or weights incomplete */
   DMP_ERR_CAPACITY = -4, /* L or N exceeds what the context was created for */
-  DMP_ERR_FAULT = -5     /* a device-side fault was recorded: results invalid (dmp_sync_check) */
+  DMP_ERR_FAULT = -5     /* a device-side fault was recorded: results invalid */
 } dmp_status;
 
 /* Device-side fault bits (dmp_sync_faults).  A prediction during which a bit was raised returns NaN
@@ -49,8 +54,9 @@ typedef enum dmp_status {
 #define DMP_FAULT_F16_RANGE 2      /* conv_mode 0: an activation reached |x| >= 6e4 (re-run in conv_mode 2) */
 #define DMP_FAULT_REFINE_HANDOFF 4 /* minimiser workgroup hand-off timed out */
 #define DMP_FAULT_EIG_HANDOFF 16   /* tridiagonalisation cluster: workgroup hand-off timed out */
+#define DMP_FAULT_VGRU_HANDOFF 32  /* persistent vertical GRU: a row barrier between the workgroups of an XCD timed out */
 #define DMP_FAULT_BAD_CODE 8       /* residue code > 21: the reference's embedding raises IndexError
-                                      (network.py:223); dmp_sync_check returns DMP_ERR_ARG for it */
+                                      (network.py:223) */
 
 int dmp_abi_version(void);
 const char* dmp_last_error(void);
@@ -75,14 +81,14 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  *   0 (default)  each float32 operand split into two f16 pieces, 3 f16 MFMA products, float32
  *                accumulation - same error against float64 as a float32 convolution, 5.3x the
  *                f32 matrix-core rate; activations must stay inside the f16 range (|x| < 6e4,
- *                checked on the device, reported by dmp_sync_check);
+ *                checked on the device, reported by dmp_sync_faults);
  *   1            the f32 matrix-core instruction (bitwise an fmaf chain);
  *   2            exact 3-way bf16 split, 6 bf16 MFMA products (no range limit, 2.7x the f32 rate).
  * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default).
  * "tridiag_single" = 1 runs the Householder tridiagonalisation of the MDS eigensolver in a single
  * workgroup (one launch) instead of one multi-workgroup launch per step; same algorithm, different
  * summation order (results agree to float64 rounding).
- * "tridiag_cluster" (default 1; the environment variable DMP_TRIDIAG_CLUSTER presets it): orders up to 640 run
+ * "tridiag_cluster" (default 1): orders up to 640 run
  * every Householder step in ONE launch on a cluster of 32 workgroups of one XCD; 0 = one launch per step (hipGraph
  * chain).  The two forms produce the same bits; the cluster is faster for one prediction (0.9 against 1.9 ms at
  * order 300), the launches disturb the convolutions of other contexts less (the multi-engine scheduler sets 0).
@@ -91,19 +97,21 @@ int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
  * agent-scope stores, the protocol that does not depend on placement.  Same bits, 1.84 against 2.8 us per GRU step.
  * "gj_diag_groups" = 2 / 4 / 8: threads (x 128) of the one-workgroup diagonal sweep of the inverse; same bits; 4 is the
  * default (8.9 against 10.0 ms per inverse at D = 6300 with 2, the form of rounds 1-3).
- * "gj_lds" = 1 / 2 stages the panels of the Gauss-Jordan trailing update through LDS (2: and fetches the tile before
- * the MFMA chain); same bits, measured slower than 0 at D = 6300 (12.1 / 11.1 against 10.8 ms), faster at
- * D = 10500 (30.4 against 32.6 ms with 2): an experiment knob.
- * "vgru_legacy" = 1 runs the vertical GRU with the round-2 step kernel (one target per launch, K split over the
- * waves of a workgroup; different summation order, results agree to float32 rounding; no group form).
+ * "act_scaling" (default 1): conv_mode 0 takes the f16 pieces of 2^e x activation, with e chosen per residual block
+ * at dmp_weights_finalize from the InstanceNorm weights of the blocks before it (a bound of the residual stream), so the
+ * low pieces of the bulk of the activations are normal f16 numbers whether the trunk sits at 1e-3 or at 1e4, and a trunk
+ * that would leave the f16 range unscaled is scaled down instead of faulting; 0 = unscaled pieces (the round-3
+ * arithmetic).  "act_scale_log2_block<k>" (k = 1..16, read only) answers e of block k's input.
+ * "vgru_persistent" (default 1): the vertical GRU's chain as ONE weight-stationary launch (columns partitioned over the
+ * XCDs, hidden units over the CUs of an XCD, XCD-local row barriers); 0 = one launch per alignment row (the round-3
+ * group step kernel, also the fallback on a device without 256 CUs).  Reads back 0 where the persistent form is not
+ * available.  The two forms sum K in different orders: results agree to float32 rounding.
  * "refine_single" = 1 runs the minimiser (dmp_refine_coords, dmp_predict*) in one workgroup instead
  * of a cluster of 16 that hands the coordinates over every step; same iteration, different
  * partial-sum slices (results agree to float32 rounding). */
 int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value);
 /* Current value of an option of dmp_ctx_set_option ("conv_f32_exact" reads as conv_mode == 1). */
 int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value);
-/* Reset the device-side fault words read by dmp_sync_faults (enqueued on `stream`). */
-int dmp_clear_faults(dmp_ctx* ctx, void* stream);
 
 /* ---- weights (the reference's state_dict ABI, network.py:182-215) ---------------------
  * dmp_weights_set: hand over one tensor of GRUResNet(512,128).state_dict() by key, host
@@ -223,24 +231,14 @@ int dmp_predict(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d
                 int Lt, int nloops, int refine_steps, float* d_coords, float* d_conf,
                 void* stream);
 
-/* The same prediction issued in phases, so that one host thread can interleave several contexts
- * (different streams) pass by pass: begin = features + sequence trunk + static stem, then exactly
- * nloops + 1 calls of dmp_predict_pass (first pass, then the recycling iterations), then end =
- * final refinement + backbone.  dmp_predict is begin + (nloops+1) x pass + end. */
-int dmp_predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
-                      int Lt, int nloops, int refine_steps, void* stream);
-int dmp_predict_pass(dmp_ctx* ctx, void* stream);
-int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream);
-
-/* Finer issue granularity for a throughput scheduler.  dmp_predict_begin_units validates and
- * records the arguments without enqueueing anything; the prediction is then a sequence of units
- * handed out by dmp_predict_issue_unit: first the front end in chunks of about 2 ms of GPU work
+/* The same prediction issued unit by unit, so that one host thread can interleave several contexts (different
+ * streams).  dmp_predict_begin_units validates and records the arguments without enqueueing anything; the
+ * prediction is then a sequence of units handed out by dmp_predict_issue_unit: first the front end in chunks of about 2 ms of GPU work
  * (sequence weights + covariance; the inverse, 6 block steps at a time, then contacts; the
  * vertical GRU, 128 alignment rows at a time; sequence GRU + static stem), then 18 units per pass:
  * unit 0 = recycled distance map + stem update, units 1..16 = residual block k (its conv5x5 takes
  * the lane), unit 17 = head + Gram matrix + MDS + coordinate GRU + best-of update.
- * dmp_predict_begin = begin_units + all front-end units; dmp_predict_pass = the remaining units of
- * the current pass.  dmp_predict_next_unit tells what the next dmp_predict_issue_unit would
+ * dmp_predict = begin_units + every unit + dmp_predict_end.  dmp_predict_next_unit tells what the next dmp_predict_issue_unit would
  * enqueue; dmp_ctx_pending returns how many issued units have not completed on the GPU (0, 1, or 2
  * for "two or more"; negative on error), so a scheduler can hand the lane only to contexts whose
  * next convolution can start at once and keep its own issue loop from running far ahead. */
@@ -251,18 +249,6 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream);
 int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L,
                             const float* d_template_ca, int Lt, int nloops, int refine_steps);
 int dmp_predict_next_unit(const dmp_ctx* ctx);
-/* Features ahead.  Reweighting, covariance, Gauss-Jordan inverse and contacts (predict.py:32-61) of the NEXT alignment
- * this context will predict, in units of the same size as the front end's (unit 0 = sequence weights + covariance, then
- * 6 block steps of the inverse each, contacts behind the last), computed into the context's own feature buffers -
- * which are idle from the moment the static stem of the prediction in flight exists.  A scheduler slips these units
- * between the residual blocks of the prediction in flight (same stream): their f32 GEMMs run beside the convolutions
- * of the OTHER contexts instead of in a front-end phase with no convolution to run.  dmp_predict_ahead_begin needs a
- * prediction in flight that is past its front end; dmp_predict_begin_units on the same alignment (same pointer, N,
- * L) after every ahead unit has been issued finds the features done and has no covariance / inverse units; for any
- * other alignment, or unfinished ahead work, the features are computed again.  Results are bit-identical. */
-int dmp_predict_ahead_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L);
-int dmp_predict_ahead_left(const dmp_ctx* ctx);
-int dmp_predict_ahead_issue(dmp_ctx* ctx, void* stream);
 /* Vertical GRUs of n <= 8 predictions as ONE launch chain (dmp_gru_vertical_group inside the unit machinery): call
  * right after dmp_predict_begin_units on every member, before any of their units is issued.  ctxs[0] leads: its
  * vertical-GRU units serve all members on the stream its units are issued on (which must be ordered behind the
@@ -275,31 +261,13 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n);
  * computed in the same launch chain as the group led by `lead` (members + riders <= 8; the chain's fixed cost per
  * alignment row - launch boundary, cold L2s - is shared by twice as many columns), their results (L_i x 512 each)
  * written to d_outs[i].  Call once, right after dmp_predict_group_vgru (a group of one is allowed), before the
- * leader issues a unit; not combinable with dmp_predict_detach_group_chain.  dmp_predict_chain_issued(lead) answers
+ * leader issues a unit.  dmp_predict_chain_issued(lead) answers
  * 1 once the chain has been enqueued to its end on the stream of the leader's units: an event recorded on that
  * stream from then on is behind the riders' results, which go to their predictions through
  * dmp_predict_set_vgru_result.  Every result is bit-identical to the alignment's own chain. */
 int dmp_predict_group_riders(dmp_ctx* lead, int n, const uint8_t* const* d_msas, const int* Ns, const int* Ls,
                              float* const* d_outs);
 int dmp_predict_chain_issued(const dmp_ctx* ctx);
-/* Take the chain of a group of two or more out of the leader's units (call right after dmp_predict_group_vgru,
- * before the leader issues a unit): the leader then has no vertical-GRU units either, and the whole chain - group
- * record, every alignment row, the members' results, the event - is enqueued by ONE call of
- * dmp_predict_issue_group_chain(lead, stream), which may come from another host thread and on another stream than
- * any member's (enqueuing the 2001 dependent launches keeps the calling thread busy for about as long as they run;
- * issued from the scheduler's own thread, the members' covariance / inverse units would queue up behind it instead
- * of running beside it).  `stream` must be ordered behind the producers of every member's alignment.  Every member,
- * the leader included, waits (event) in its last front-end unit, for which dmp_predict_next_unit answers
- * DMP_UNIT_WAIT until the chain has been issued to its end.  While the chain is being issued the leader's other
- * units may be issued concurrently from the scheduler's thread; no other call on the leader context is allowed.
- * Results are bit-identical to ungrouped predictions. */
-int dmp_predict_detach_group_chain(dmp_ctx* lead);
-int dmp_predict_issue_group_chain(dmp_ctx* lead, void* stream);
-/* Variant: the detached chain will be enqueued (by the helper thread) on the stream the leader's units are issued on -
- * no additional stream / hardware queue.  Call between detach and issue: the leader's units behind its first one then
- * answer DMP_UNIT_WAIT until the chain has been enqueued to its end (kernels slipped between its rows would stretch
- * it); the other members' units run beside the chain on their own streams. */
-int dmp_predict_chain_on_own_stream(dmp_ctx* lead);
 /* The vertical GRU of this prediction has been (or is being) computed ahead of time by dmp_gru_vertical /
  * dmp_gru_vertical_group on the same alignment: d_vout (L x 512, device) is its result, `event` (hipEvent_t or
  * NULL) was recorded behind it.  Call right after dmp_predict_begin_units, before any unit is issued: the
@@ -307,10 +275,9 @@ int dmp_predict_chain_on_own_stream(dmp_ctx* lead);
  * a scheduler can run the launch chains of the NEXT targets beside the trunk passes of the current ones (the
  * chain touches none of the buffers the trunk uses).  d_vout must stay valid until that unit has run. */
 int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event);
-/* After the last pass: dmp_predict_end_refine enqueues the final minimisation of the best trace
- * alone (optional: dmp_predict_end does it itself if it was not called), for callers that want to
- * interleave other work between the minimisation and the backbone kernel. */
-int dmp_predict_end_refine(dmp_ctx* ctx, void* stream);
+/* After the last unit: final refinement of the best trace + backbone + confidences into d_coords (L x 5 x 3) and
+ * d_conf (L); a prediction during which a device-side fault was recorded returns NaN. */
+int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream);
 int dmp_predict_issue_unit(dmp_ctx* ctx, void* stream);
 int dmp_ctx_pending(dmp_ctx* ctx);
 
@@ -318,19 +285,15 @@ int dmp_ctx_pending(dmp_ctx* ctx);
  * machine-filling conv5x5 launches of all contexts on a lane then take turns (cross-stream events),
  * two in flight at a time (a launch waits for the one before the previous one, so the tail of one
  * launch fills with the head of the next), while every other kernel of one target overlaps the
- * convolutions of another.  All contexts of a lane must be driven by the same host thread.  NULL
- * detaches. */
-typedef struct dmp_lane dmp_lane;
-int dmp_lane_create(dmp_lane** out);
-void dmp_lane_destroy(dmp_lane* lane);
-int dmp_ctx_set_lane(dmp_ctx* ctx, dmp_lane* lane);
+ * convolutions of another.  dmp_ctx_share_lane(ctx, other): ctx joins the lane of `other` (made on first use; it
+ * lives as long as a context refers to it); other = NULL detaches.  All contexts of a lane must be driven by the same
+ * host thread. */
+int dmp_ctx_share_lane(dmp_ctx* ctx, dmp_ctx* other);
 
 /* Synchronise `stream` and report the device-side faults recorded since the last report
  * (DMP_FAULT_* bits in *h_bits; 0 = every result handed out since then is valid).  Reporting clears
- * them: one failed prediction does not poison the checks of later ones.  dmp_sync_check is the same
- * as a status: DMP_OK, DMP_ERR_ARG (residue code > 21) or DMP_ERR_FAULT, message in dmp_last_error. */
+ * them: one failed prediction does not poison the checks of later ones. */
 int dmp_sync_faults(dmp_ctx* ctx, void* stream, int* h_bits);
-int dmp_sync_check(dmp_ctx* ctx, void* stream);
 
 /* ---- introspection for tests and the benchmark ------------------------------------------- */
 /* After dmp_predict: copy an internal tensor to d_dst (device).  Names: "w", "contacts",
@@ -338,19 +301,13 @@ int dmp_sync_check(dmp_ctx* ctx, void* stream);
  * refinement), "inv_cov" (21L x 21L), "mds" (L x 8) and "gram" (L x L) of the last pass.  Returns the number of floats written or a negative status. */
 int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t capacity,
                         void* stream);
-/* Optional HIP-event timing of every conv5x5 launch inside dmp_predict / dmp_trunk_pass (events
- * are recorded on the caller's stream around each launch; up to max_launches per read-out).
- * dmp_profile_conv_ms returns the mean launch duration since the last read-out (the caller
- * must have synchronised the stream) and resets the counter. */
+/* Optional HIP-event timing of every conv5x5 launch inside dmp_predict / dmp_trunk_pass / the unit calls (events
+ * are recorded on the caller's stream around each launch; up to max_launches).  dmp_profile_enable(ctx, 1, n) starts a
+ * fresh record, (ctx, 0, 0) stops recording.  dmp_profile_conv_intervals: start / end of every recorded launch of ctx
+ * in ms after the first recorded launch of ref (streams synchronised by the caller); the record is kept. */
 int dmp_profile_enable(dmp_ctx* ctx, int on, int max_launches);
-int dmp_profile_conv_ms(dmp_ctx* ctx, float* h_avg_ms, int* h_launches);
-/* Developer diagnostic: start / end of every recorded launch of ctx in ms after the first recorded
- * launch of ref (streams synchronised by the caller); the counter is not reset. */
 int dmp_profile_conv_intervals(dmp_ctx* ctx, dmp_ctx* ref, float* h_start_ms, float* h_end_ms, int capacity,
                                int* h_launches);
-/* Time the pair-trunk convolution kernel alone with HIP events on `stream`: runs `iters`
- * launches of block `block` at length L on internal buffers, returns average ms per launch. */
-int dmp_time_conv5x5(dmp_ctx* ctx, int block, int L, int iters, float* h_ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,20 @@ class Stages:
         self.call("dmp_trunk_pass", z0, dmap, L, conf, M)
         return conf, M
 
+    def conv_ms(self, z0, dmap, passes=1):
+        """Mean duration (ms) of the 5x5 convolution launches of `passes` trunk passes, from the HIP events the library
+        records around every launch (dmp_profile_enable / dmp_profile_conv_intervals)."""
+        L = dmap.shape[0]
+        cap = 16 * passes
+        _lib.check(self.lib.dmp_profile_enable(self.eng.ctx, 1, cap))
+        for _ in range(passes):
+            self.trunk_pass(z0, dmap)
+        torch.cuda.synchronize()
+        a, b, n = (C.c_float * cap)(), (C.c_float * cap)(), C.c_int()
+        _lib.check(self.lib.dmp_profile_conv_intervals(self.eng.ctx, self.eng.ctx, a, b, cap, C.byref(n)))
+        _lib.check(self.lib.dmp_profile_enable(self.eng.ctx, 0, 0))
+        return sum(b[i] - a[i] for i in range(n.value)) / max(1, n.value)
+
     def eigh_top8(self, M):
         L = M.shape[0]
         out = self.f32(L, 8)

@@ -248,10 +248,7 @@ def test_f16_range_fault_is_reported(st_engine):
     st_engine.conv(1, st_engine.to(x.numpy()))
     with pytest.raises(Exception, match="f16 range"):
         st_engine.eng.sync_check()
-    # the flag is sticky by design; clear it for the remaining tests
-    import ctypes as C
-    from dmpfold2_amd import _lib
-    _lib.check(st_engine.lib.dmp_clear_faults(st_engine.eng.ctx, st_engine.eng.stream()))
+    # reporting clears the fault words: the remaining tests start clean
     st_engine.eng.sync_check()
 
 
@@ -458,38 +455,32 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
     pipe.close()
 
 
-@pytest.mark.parametrize("group,lookahead,detach,ahead,riders",
-                         [(1, 0, 1, 1, 4), (2, 0, 1, 1, 4), (4, 0, 1, 0, 4), (4, 0, 0, 1, 4), (4, 0, 0, 0, 4),
-                          (2, 0, 0, 1, 4), (4, 24, 1, 1, 4), (3, 400, 0, 1, 4), (4, 0, 2, 0, 4), (3, 0, 2, 1, 4),
-                          (4, 0, 0, 0, 0), (2, 0, 0, 0, 6), (3, 0, 0, 0, 2), (4, 0, 0, 0, 7)])
-def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, monkeypatch, group, lookahead, detach,
-                                                            ahead, riders):
-    """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE launch chain
-    (group leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so
-    groups of every size up to `group` form.  detach = 1: the chain is issued by a helper thread on
-    its own stream - or, detach = 2, on the leader's stream - (dmp_predict_detach_group_chain /
-    dmp_predict_issue_group_chain / dmp_predict_chain_on_own_stream) while the scheduler's thread
-    issues the members' other front-end units.  With a look-ahead the chains of the next group run beside the
-    predictions in flight and are handed over (dmp_predict_set_vgru_result).  riders: a group's chain also serves
-    up to that many of the NEXT targets in the queue (dmp_predict_group_riders; members + riders <= 8; the default of
-    the scheduler when the chain is neither detached nor run ahead), handed over the same way.  Every result equals
-    the single engine's, bit for bit."""
+@pytest.mark.parametrize("persistent", [1, 0])
+@pytest.mark.parametrize("group,riders", [(1, 4), (2, 4), (4, 4), (4, 0), (2, 6), (3, 2), (4, 7)])
+def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(synth_sd, monkeypatch, group, riders, persistent):
+    """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE chain (the group
+    leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so groups of every
+    size up to `group` form.  riders: a group's chain also serves up to that many of the NEXT targets in the queue
+    (dmp_predict_group_riders; members + riders <= 8), handed over when those targets start
+    (dmp_predict_set_vgru_result).  Every result equals the single engine's, bit for bit - in the persistent
+    weight-stationary form of the chain (one launch) and in the launch-per-row form."""
     from dmpfold2_amd import synth
-    from dmpfold2_amd.predict import Pipeline, encode_aln
+    from dmpfold2_amd.predict import Engine, Pipeline, encode_aln
     monkeypatch.setenv("DMP_VGRU_GROUP", str(group))
-    monkeypatch.setenv("DMP_VGRU_LOOKAHEAD", str(lookahead))
-    monkeypatch.setenv("DMP_VGRU_DETACH", str(detach))
-    monkeypatch.setenv("DMP_FEATURES_AHEAD", str(ahead))       # features of an engine's next target computed ahead
     monkeypatch.setenv("DMP_VGRU_RIDERS", str(riders))
     shapes = [(82, 200), (33, 64), (128, 300), (40, 1), (64, 257), (96, 31), (120, 129), (50, 64), (128, 17)]
     msas = [encode_aln(synth.synth_msa(L, N, 40 + i)) for i, (L, N) in enumerate(shapes)]
     dev = torch.device("cuda:0")
+    single = Engine(dev, 128, 512)
+    single.set_weights(synth_sd)
+    single.set_option("vgru_persistent", persistent)
     pipe = Pipeline(dev, 128, 512, synth_sd, streams=4)
-    assert pipe._group_max == group and (pipe._fe is not None) == (lookahead > 0)
-    assert pipe._detach == bool(detach and group > 1) and pipe._features_ahead == bool(ahead)
-    assert pipe._riders_max == riders
+    for e in pipe.engines:
+        e.set_option("vgru_persistent", persistent)
+    assert pipe.engines[0].get_option("vgru_persistent") == persistent        # a 256-CU device has the persistent form
+    assert pipe._group_max == group and pipe._riders_max == riders
     rode = []
-    if riders and not detach and not lookahead and not ahead and group > 1:
+    if riders and group > 1:
         pipe_lib = pipe.lib                               # count the chains that carried riders
 
         class Counting:
@@ -503,18 +494,68 @@ def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(st_engine, synth_sd, 
                     return fn(*a)
                 return counted
         pipe.lib = Counting()
-    msas = msas + msas[:5]                       # more targets than engines: reservations and ahead units happen
+    msas = msas + msas[:5]                       # more targets than engines
     tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 3) for m in msas]
     pipe.drain()
     pipe.sync_check()
-    if riders and not detach and not lookahead and not ahead and group > 1:
+    if riders and group > 1:
         assert rode and max(rode) == min(riders, 8 - group) and not pipe._riding and not pipe._ahead
-    for m, t in zip(msas, tickets):
-        coords, confs = pipe.result(t)
-        ref_c, ref_f = st_engine.eng.predict(m, None, 1, 3)
-        st_engine.eng.sync_check()
-        assert torch.equal(coords, ref_c) and torch.equal(confs, ref_f), m.shape
-    pipe.close()
+    try:
+        for m, t in zip(msas, tickets):
+            coords, confs = pipe.result(t)
+            ref_c, ref_f = single.predict(m, None, 1, 3)
+            single.sync_check()
+            assert torch.equal(coords, ref_c) and torch.equal(confs, ref_f), m.shape
+    finally:
+        pipe.close()
+        single.close()
+
+
+def test_persistent_vertical_gru_vs_oracle_and_launch_chain(st_engine, synth_sd, oracle_weights):
+    """Round 4: the chain as ONE persistent weight-stationary launch (vgru_persist_kernel: columns over the XCDs, hidden
+    units over the CUs of an XCD, XCD-local row barriers) against the oracle's nn.GRU (1e-5, the tolerance of the
+    launch-per-row kernel) on a ragged group - odd lengths, a one-row alignment, more rows than columns - and against
+    the launch-per-row form (different K summation order: float32 rounding); a member's bits do not depend on the
+    group it ran in; no row barrier timed out."""
+    import ctypes as C
+    from dmpfold2_amd import _lib, synth
+    from dmpfold2_amd.predict import encode_aln
+    shapes = [(82, 100), (33, 7), (128, 64), (40, 1), (50, 257), (9, 300)]
+    msas = [encode_aln(synth.synth_msa(L, N, 70 + i)) for i, (L, N) in enumerate(shapes)]
+    st = st_engine
+    eng = st.eng
+    assert eng.get_option("vgru_persistent") == 1
+
+    def chain(ms, persistent):
+        eng.set_option("vgru_persistent", persistent)
+        k = len(ms)
+        d = [st.to(m, torch.uint8) for m in ms]
+        outs = [st.f32(m.shape[1], 512) for m in ms]
+        ctxs = (C.c_void_p * k)(*[eng.ctx] * k)
+        mp = (C.c_void_p * k)(*[x.data_ptr() for x in d])
+        op = (C.c_void_p * k)(*[x.data_ptr() for x in outs])
+        Ns = (C.c_int * k)(*[m.shape[0] for m in ms])
+        Ls = (C.c_int * k)(*[m.shape[1] for m in ms])
+        _lib.check(st.lib.dmp_gru_vertical_group(ctxs, k, mp, Ns, Ls, op, eng.stream()))
+        torch.cuda.synchronize()
+        return outs
+    try:
+        grouped = chain(msas, 1)
+        assert eng.sync_faults() == 0
+        rows = chain(msas, 0)
+        for m, a, b in zip(msas, grouped, rows):
+            x = oracle_weights["embed.weight"][torch.from_numpy(m.astype(np.int64))]
+            ref = O._gru(oracle_weights, "vgru", x, 22, 512, 2, False, False)[-1]
+            assert float((a.cpu() - ref).abs().max()) < 1e-5, m.shape
+            assert float((a - b).abs().max()) < 5e-6, m.shape
+        for i, m in enumerate(msas):
+            alone = chain([m], 1)[0]
+            assert torch.equal(alone, grouped[i]), i
+            pair = chain([msas[(i + 1) % len(msas)], m], 1)[1]
+            assert torch.equal(pair, grouped[i]), i
+        assert eng.sync_faults() == 0
+    finally:
+        eng.set_option("vgru_persistent", 1)
 
 
 def test_gru_vertical_group_stage_call(st, synth_sd):
@@ -646,10 +687,17 @@ def test_backbone_bitwise_stable_beside_convolutions(synth_sd):
     torch.cuda.synchronize()
     ref_c, ref_f = out[0].clone(), cf[0].clone()
 
+    z0 = torch.randn(384, L, L, device=dev)
+    dm = torch.full((L, L), -1.0, device=dev)
+    cfb, Mb = torch.empty(L, device=dev), torch.empty(L, L, device=dev)
+    sb.wait_stream(torch.cuda.current_stream(dev))
+
     def convolutions():
-        ms = C.c_float()
         with torch.cuda.device(dev):
-            _lib.check(eb.lib.dmp_time_conv5x5(eb.ctx, 1, L, 600, C.byref(ms), eb.stream()))
+            for _ in range(38):                          # 38 x 16 split-product convolutions on the other stream
+                _lib.check(eb.lib.dmp_trunk_pass(eb.ctx, z0.data_ptr(), dm.data_ptr(), L, cfb.data_ptr(), Mb.data_ptr(),
+                                                 eb.stream()))
+            sb.synchronize()
     t = threading.Thread(target=convolutions)
     t.start()
     bad = 0
@@ -707,7 +755,7 @@ def test_unit_api_contract(st_engine):
     confs = torch.empty((L,), device="cuda")
     s = eng.stream()
     assert lib.dmp_predict_begin_units(eng.ctx, d_msa.data_ptr(), n, L, None, 0, 2, 0) == 0
-    assert lib.dmp_predict_pass(eng.ctx, s) < 0                # front end still outstanding
+    assert lib.dmp_predict_end(eng.ctx, coords.data_ptr(), confs.data_ptr(), s) < 0      # units still outstanding
     kinds = []
     while True:
         k = lib.dmp_predict_next_unit(eng.ctx)

@@ -134,12 +134,9 @@ def timings(L, N, n=10, m=100):
     dmap = st.to(np.full((L, L), -1, np.float32))
     x = timed("stem_update", lambda: st.stem_update(z0, dmap))
     timed("conv5x5 (stage API, +pad)", lambda: st.conv(1, x))
-    ms = np.zeros(1, np.float32)
-    import ctypes as C
-    val = C.c_float()
-    st.lib.dmp_time_conv5x5(st.eng.ctx, 1, L, 5, C.byref(val), st.eng.stream())
+    val = st.conv_ms(z0, dmap, 2)
     flops = 2.0 * 128 * 512 * 25 * L * L
-    print(f"time conv5x5 kernel only        {val.value:10.3f} ms  -> {flops / val.value / 1e9:.1f} TFLOP/s", flush=True)
+    print(f"time conv5x5 kernel only        {val:10.3f} ms  -> {flops / val / 1e9:.1f} TFLOP/s", flush=True)
     conf, M = timed("trunk_pass", lambda: st.trunk_pass(z0, dmap))
     mds = timed("eigh_top8", lambda: st.eigh_top8(M))
     ca = timed("coords_from_mds", lambda: st.coords_from_mds(mat1d, mds))

@@ -33,8 +33,6 @@ for name in sys.argv[1:] or ["pf10963_n10_m0"]:
         alnmat = encode_aln(synth.synth_msa(L, int(g["msa_rows"]) if "msa_rows" in g.files else 2000, int(g["msa_seed"])))
     eng = Engine("cuda:0", max(L, 64), 3000)
     eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
-    if os.environ.get("DMP_VGRU_LEGACY") == "1":          # the round-2 vertical GRU (library expf / tanhf gates)
-        eng.set_option("vgru_legacy", 1)
     P = n + 1
     print(name, "floor", ["%.1e" % x for x in (g["noise_ca_pass"] if "noise_ca_pass" in g.files else [])])
     for mode in (0, 1, 2):
