@@ -356,6 +356,7 @@ def main(argv=None):
             a, b, n = (C.c_float * cap)(), (C.c_float * cap)(), C.c_int()
             _lib.check(lib.dmp_profile_conv_intervals(e.ctx, pipe.engines[0].ctx, a, b, cap, C.byref(n)))
             iv += [(a[i], b[i]) for i in range(n.value)]
+        for e in pipe.engines:                           # (the record of engines[0] is the time origin of all of them)
             _lib.check(lib.dmp_profile_enable(e.ctx, 0, 0))
         union = interval_union(iv)
         tot, cnt = sum(b_ - a_ for a_, b_ in iv), len(iv)

@@ -313,12 +313,10 @@ static int trunk_open(dmp_ctx* c, const float* z0, const float* dmap, int L, hip
   c->trunk_oth = c->xb;
   c->xsplit_current = false;
   c->ab_current = false;
-  if ((rc = stem_update_padded(c, z0, dmap, L, c->trunk_cur, s))) return rc;
-  if (c->conv_mode != 1) {
-    // f16 / bf16 pieces of the stem output; every block's norm kernel then emits those of its output
-    if ((rc = act_split(c, c->trunk_cur, L, 1, s))) return rc;
-    c->xsplit_current = true;
-  }
+  // the stem's norm kernel also writes the f16 / bf16 pieces of its output; every block's norm kernel then emits
+  // those of its own
+  if ((rc = stem_update_padded(c, z0, dmap, L, c->trunk_cur, s, true))) return rc;
+  c->xsplit_current = c->conv_mode != 1;
   return DMP_OK;
 }
 
@@ -351,7 +349,7 @@ static int trunk_block(dmp_ctx* c, int k, int L, hipStream_t s) {
     c->prof_n += 2;
   }
   if ((rc = conv5x5_reduce_stats(c, L, c->stats, s, k))) return rc;
-  if ((rc = norm_scse_residual_padded(c, k, c->u, c->stats, c->trunk_cur, L, c->trunk_oth, s))) return rc;
+  if ((rc = norm_scse_residual_padded(c, k, c->u, c->stats, c->trunk_cur, L, c->trunk_oth, s, k == NBLOCK))) return rc;
   std::swap(c->trunk_cur, c->trunk_oth);
   return DMP_OK;
 }
@@ -470,6 +468,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(stats, CW * 2);
   A_(ab, CW * 2);
   A_(head0, LL);
+  A_(head1, LL);
   A_(conf, L);
   A_(gram, LL);
   A_(eig_a, LL);
@@ -1231,6 +1230,12 @@ int64_t dmp_debug_fetch(dmp_ctx* ctx, const char* name, float* d_dst, int64_t ca
   else if (k == "inv_cov") { src = ctx->cov; n = (int64_t)NS * L * NS * L; }
   else if (k == "mds") { src = ctx->mds; n = L * 8; }
   else if (k == "gram") { src = ctx->gram; n = L * L; }
+  else if (k == "vgru_h0" || k == "vgru_h1") {
+    // the vertical GRU's float32 state after the chain this context led last: [128][Lb][4], Lb = 32 x (column tiles)
+    const int layer = k == "vgru_h1";
+    src = ctx->hT[layer][ctx->vg_maxN & 1];
+    n = (int64_t)WIDTH * ctx->vg_ntiles * 32;
+  }
   else { set_error("unknown debug tensor %s", name); return DMP_ERR_ARG; }
   if (n > capacity) { set_error("capacity %lld too small for %s (%lld)", (long long)capacity, name, (long long)n); return DMP_ERR_ARG; }
   if (n > 0) DMP_HIP(hipMemcpyAsync(d_dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, STREAM));

@@ -196,7 +196,9 @@ struct dmp_ctx {
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm
-  float* head0 = nullptr;   // [L][L]
+  float* head0 = nullptr;   // [L][L] head channel 0 (distances)
+  float* head1 = nullptr;   // [L][L] head channel 1 (confidence logits)
+  bool head_current = false;   // the last block's norm kernel already wrote head0 / head1 of the current activations
   float* conf = nullptr;    // [L]
   float* gram = nullptr;    // [L][L]
   // coordinates
@@ -274,12 +276,12 @@ int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hip
 int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const float* d_contacts,
                 int L, float* d_z0, hipStream_t s);
 int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L, float* d_xpad,
-                       hipStream_t s);
+                       hipStream_t s, bool split = false);
 int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
                           double* d_stats, hipStream_t s, bool reduce);
 int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s, int block = 0);
 int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
-                              const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s);
+                              const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s, bool head = false);
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
                      hipStream_t s);
 int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);

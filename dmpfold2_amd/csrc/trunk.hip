@@ -283,47 +283,34 @@ int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const floa
 // ---------------------------------------------------------------------------------------
 // stem, per-pass part: + W[o,954]*dmap, max over triples, InstanceNorm
 // ---------------------------------------------------------------------------------------
+// Also the InstanceNorm statistics of what it writes (round 4: a separate pass over u read its 46 MB again):
+// part[blockIdx.x][g][2] = float64 (sum, sum of squares) of the block's 256 pixels - wave sums by the xor butterfly,
+// the four waves added in order; stats_reduce_kernel then adds the blocks in a fixed order.
 __global__ __launch_bounds__(256) void stem_maxout_kernel(const float* __restrict__ z0,
                                                           const float* __restrict__ wd,
                                                           const float* __restrict__ dmap, int64_t LL,
-                                                          float* __restrict__ u) {
+                                                          float* __restrict__ u, double* __restrict__ part) {
+  __shared__ double red[2][4];
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= LL) return;
   const int g = blockIdx.y;
-  const float d = dmap[p];
-  const float v0 = z0[(int64_t)(3 * g) * LL + p] + wd[3 * g] * d;
-  const float v1 = z0[(int64_t)(3 * g + 1) * LL + p] + wd[3 * g + 1] * d;
-  const float v2 = z0[(int64_t)(3 * g + 2) * LL + p] + wd[3 * g + 2] * d;
-  u[(int64_t)g * LL + p] = fmaxf(fmaxf(v0, v1), v2);
-}
-
-constexpr int STAT_SLICES = 8;
-// part[slice][c][2] = (sum, sum of squares) of u[c] over one slice of the pixels
-__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ u, int64_t LL,
-                                                            double* __restrict__ part) {
-  __shared__ double red[2][256];
-  const int c = blockIdx.x, sl = blockIdx.y;
-  const int64_t per = (LL + STAT_SLICES - 1) / STAT_SLICES;
-  const int64_t lo = sl * per, hi = (lo + per < LL) ? lo + per : LL;
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t p = lo + threadIdx.x; p < hi; p += 256) {
-    const double v = (double)u[(int64_t)c * LL + p];
-    s1 += v;
-    s2 += v * v;
+  if (p < LL) {
+    const float d = dmap[p];
+    const float v0 = z0[(int64_t)(3 * g) * LL + p] + wd[3 * g] * d;
+    const float v1 = z0[(int64_t)(3 * g + 1) * LL + p] + wd[3 * g + 1] * d;
+    const float v2 = z0[(int64_t)(3 * g + 2) * LL + p] + wd[3 * g + 2] * d;
+    const float v = fmaxf(fmaxf(v0, v1), v2);
+    u[(int64_t)g * LL + p] = v;
+    s1 = (double)v;
+    s2 = s1 * s1;
   }
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
+  s1 = wave_sum_f64(s1);
+  s2 = wave_sum_f64(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + s];
-      red[1][threadIdx.x] += red[1][threadIdx.x + s];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    part[((int64_t)sl * CW + c) * 2 + 0] = red[0][0];
-    part[((int64_t)sl * CW + c) * 2 + 1] = red[1][0];
+  if (threadIdx.x < 2) {
+    const double t = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+    part[((int64_t)blockIdx.x * CW + g) * 2 + threadIdx.x] = t;
   }
 }
 
@@ -374,32 +361,59 @@ __global__ void norm_coeff_kernel(const double* __restrict__ stats, double count
   ab[c * 2 + 1] = beta[c] - (float)mean * alpha;
 }
 
+// InstanceNorm of the stem's maxout output into the padded planes - and, SPLIT = 0 / 2, the f16 / bf16 pieces of
+// block 1's input in the same pass (round 4: a separate act_split read the 48 MB it had just written again).  One
+// thread = 8 consecutive channels of one position of the PADDED plane: border positions write zero pieces (the
+// float32 border is kept zero by act_clear), interior ones the normalised values and their pieces.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void stem_norm_kernel(const float* __restrict__ u,
                                                         const float* __restrict__ ab, int L, int P,
-                                                        float* __restrict__ xpad) {
-  const int c = blockIdx.z, y = blockIdx.y;
+                                                        float* __restrict__ xpad, uint16_t* __restrict__ xs,
+                                                        int* __restrict__ fault, float xscale) {
+  const int y = blockIdx.y, cgp = blockIdx.z;
   const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x >= L) return;
-  const float v = u[((int64_t)c * L + y) * L + x];
-  xpad[((int64_t)c * P + y + 2) * P + x + 2] = v * ab[c * 2] + ab[c * 2 + 1];
+  if (x >= P) return;
+  const int yy = y - 2, xx = x - 2;
+  const bool inside = yy >= 0 && yy < L && xx >= 0 && xx < L;
+  if (SPLIT < 0 && !inside) return;
+  const int64_t PP = (int64_t)P * P, LL = (int64_t)L * L;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cgp * 8 + e;
+    o[e] = 0.f;
+    if (inside) {
+      o[e] = u[(int64_t)c * LL + (int64_t)yy * L + xx] * ab[c * 2] + ab[c * 2 + 1];
+      xpad[(int64_t)c * PP + (int64_t)y * P + x] = o[e];
+    }
+  }
+  if constexpr (SPLIT == 0) store_pieces<0>(o, xs, (int64_t)cgp * PP + (int64_t)y * P + x, 16 * PP, fault, xscale);
+  if constexpr (SPLIT == 2) store_pieces<2>(o, xs, (int64_t)cgp * PP + (int64_t)y * P + x, 16 * PP, fault, 1.0f);
 }
 
+// `split` = also write the pieces block 1's convolution reads (inside a trunk pass, conv_mode 0 / 2)
 int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L, float* d_xpad,
-                       hipStream_t s) {
+                       hipStream_t s, bool split) {
   const Weights& W = c->W;
   const int64_t LL = (int64_t)L * L;
   const int P = act_pitch(L);
-  hipLaunchKernelGGL(stem_maxout_kernel, dim3((unsigned)cdiv64(LL, 256), CW), dim3(256), 0, s, d_z0,
-                     W.stem_wd, d_dmap, LL, c->u);
+  const unsigned nblk = (unsigned)cdiv64(LL, 256);
+  hipLaunchKernelGGL(stem_maxout_kernel, dim3(nblk, CW), dim3(256), 0, s, d_z0,
+                     W.stem_wd, d_dmap, LL, c->u, c->part);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(channel_stats_kernel, dim3(CW, STAT_SLICES), dim3(256), 0, s, c->u, LL,
-                     c->part);
-  DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, STAT_SLICES, c->stats, (double)LL,
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, (int)nblk, c->stats, (double)LL,
                      W.stem_gamma, W.stem_beta, c->ab);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(stem_norm_kernel, dim3(cdiv(L, 256), L, CW), dim3(256), 0, s, c->u, c->ab, L,
-                     P, d_xpad);
+  const dim3 grid(cdiv(P, 256), P, 16);
+  const int mode = (split && c->conv_mode != 1) ? c->conv_mode : -1;
+  if (mode == 0)
+    hipLaunchKernelGGL(stem_norm_kernel<0>, grid, dim3(256), 0, s, c->u, c->ab, L, P, d_xpad, c->xsplit, c->seq_abort,
+                       c->act_scaling ? W.blk[0].x_scale : 1.0f);
+  else if (mode == 2)
+    hipLaunchKernelGGL(stem_norm_kernel<2>, grid, dim3(256), 0, s, c->u, c->ab, L, P, d_xpad, c->xsplit, c->seq_abort, 1.0f);
+  else
+    hipLaunchKernelGGL(stem_norm_kernel<-1>, grid, dim3(256), 0, s, c->u, c->ab, L, P, d_xpad, (uint16_t*)nullptr,
+                       c->seq_abort, 1.0f);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
@@ -671,67 +685,93 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
 }
 
 // ---------------------------------------------------------------------------------------
-// InstanceNorm + scSE + residual (network.py:32, 37-82, 99-101), one thread per pixel:
+// InstanceNorm + scSE + residual (network.py:32, 37-82, 99-101):
 //   y_c = u_c*alpha_c + beta'_c ;  s = sigmoid(sum_c ws_c y_c + bs)
 //   out_c = (y_c*cse_c + y_c*s) + x_c
 // ---------------------------------------------------------------------------------------
-// SPLIT: -1 = float32 output only, 0 / 2 = also write f16 / bf16 pieces (store_pieces)
-// Two threads per pixel (lane halves of a wave, 64 channels each: about 100 VGPRs).  Two f16x3
-// convolution workgroups per CU leave 512 - 2*176 = 160 registers per SIMD lane, so this kernel's
-// waves can run beside the convolutions of another target (with one thread per pixel it needed 170).
-template <int SPLIT>
+// SPLIT: -1 = float32 output only, 0 / 2 = also write f16 / bf16 pieces (store_pieces) for the next block's convolution.
+// HEAD = 1 (the last block inside a trunk pass): also the two channels of the 1x1 head convolution (network.py:207) of
+// the block's OUTPUT, as planes - the head used to read the 128 output channels again.
+// FOUR lanes per pixel (round 4; a lane = 32 channels in registers: about 60 VGPRs): beside two f16x3 convolution
+// workgroups a CU has 176 registers per SIMD lane left, which was ONE wave per SIMD of the two-lanes-per-pixel form
+// (108 registers; the kernel took 135 us there against 38 alone) and is three waves of this one.  A wave = 16 pixels
+// x 4 channel quarters; sums over the channels are formed as (q0 + q1) + (q2 + q3), each quarter an fmaf chain in
+// channel order - the same in every lane of a pixel.
+template <int SPLIT, int HEAD>
 __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     const float* __restrict__ u, const float* __restrict__ ab, const float* __restrict__ cse,
     const float* __restrict__ sse_w, float sse_b, const float* __restrict__ xin, int L, int P,
-    float* __restrict__ xout, uint16_t* __restrict__ xs, int* __restrict__ fault, float xscale) {
-  __shared__ float sh_a[CW], sh_b[CW], sh_g[CW], sh_w[CW];
+    float* __restrict__ xout, uint16_t* __restrict__ xs, int* __restrict__ fault, float xscale,
+    const float* __restrict__ hw, float hb0, float hb1, float* __restrict__ head0, float* __restrict__ head1) {
+  __shared__ float sh_a[CW], sh_b[CW], sh_g[CW], sh_w[CW], sh_h[HEAD ? 2 * CW : 1];
   if (threadIdx.x < CW) {
     sh_a[threadIdx.x] = ab[threadIdx.x * 2];
     sh_b[threadIdx.x] = ab[threadIdx.x * 2 + 1];
     sh_g[threadIdx.x] = cse[threadIdx.x];
     sh_w[threadIdx.x] = sse_w[threadIdx.x];
   }
+  if constexpr (HEAD) sh_h[threadIdx.x] = hw[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = lane >> 5;                       // channels [64 half, 64 half + 64)
+  const int q = lane >> 4;                          // channels [32 q, 32 q + 32)
   const int y = blockIdx.y;
-  const int x = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int x = blockIdx.x * 64 + wave * 16 + (lane & 15);
   const bool live = x < L;
   const int xc = live ? x : L - 1;                  // clamped lanes compute, do not store
   const int64_t LL = (int64_t)L * L, PP = (int64_t)P * P;
   const int64_t p = (int64_t)y * L + xc, pp = (int64_t)(y + 2) * P + xc + 2;
-  constexpr int HC = CW / 2;
-  float yv[HC];
+  constexpr int QC = CW / 4;
+  float yv[QC];
   float dot = 0.f;
 #pragma unroll
-  for (int i = 0; i < HC; ++i) {
-    const int c = half * HC + i;
+  for (int i = 0; i < QC; ++i) {
+    const int c = q * QC + i;
     yv[i] = u[c * LL + p] * sh_a[c] + sh_b[c];
     dot = fmaf(sh_w[c], yv[i], dot);
   }
-  const float other = __shfl_xor(dot, 32, 64);
-  const float sg = sigmoid_f((half ? other + dot : dot + other) + sse_b);   // channels 0..63 first, then 64..127
-  if (!live) return;
+  dot += __shfl_xor(dot, 16, 64);                   // q0 + q1 | q2 + q3
+  dot += __shfl_xor(dot, 32, 64);                   // (q0 + q1) + (q2 + q3)
+  const float sg = sigmoid_f(dot + sse_b);
+  float h0 = 0.f, h1 = 0.f;
 #pragma unroll
-  for (int g8 = 0; g8 < HC / 8; ++g8) {
-    const int cgp = half * (HC / 8) + g8;
+  for (int g8 = 0; g8 < QC / 8; ++g8) {
+    const int cgp = q * (QC / 8) + g8;
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = cgp * 8 + e;
       const float t = yv[g8 * 8 + e] * sh_g[c] + yv[g8 * 8 + e] * sg;      // contraction is off for this file
       o[e] = t + xin[c * PP + pp];
-      xout[c * PP + pp] = o[e];
+      if (live) xout[c * PP + pp] = o[e];
+      if constexpr (HEAD) {
+        h0 = fmaf(sh_h[c], o[e], h0);
+        h1 = fmaf(sh_h[CW + c], o[e], h1);
+      }
     }
     // inside a trunk pass: also emit the pieces the next block's split-product convolution reads
-    if constexpr (SPLIT == 0) store_pieces<0>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault, xscale);
-    if constexpr (SPLIT == 2) store_pieces<2>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault, 1.0f);
+    if (live) {
+      if constexpr (SPLIT == 0) store_pieces<0>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault, xscale);
+      if constexpr (SPLIT == 2) store_pieces<2>(o, xs, (int64_t)cgp * PP + pp, 16 * PP, fault, 1.0f);
+    }
+  }
+  if constexpr (HEAD) {
+    h0 += __shfl_xor(h0, 16, 64);
+    h0 += __shfl_xor(h0, 32, 64);
+    h1 += __shfl_xor(h1, 16, 64);
+    h1 += __shfl_xor(h1, 32, 64);
+    if (live && q == 0) {
+      head0[(int64_t)y * L + x] = h0 + hb0;
+      head1[(int64_t)y * L + x] = h1 + hb1;
+    }
   }
 }
 
+// `head` = the last block of a trunk pass: the kernel also leaves the head's two planes in c->head0 / c->head1
+// (head_gram_padded then skips its pass over the 128 channels)
 int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
-                              const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s) {
+                              const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s, bool head) {
   const BlockW& B = c->W.blk[block - 1];
+  const Weights& W = c->W;
   const int P = act_pitch(L);
   if (!c->ab_current) {
     hipLaunchKernelGGL(norm_coeff_kernel, dim3(1), dim3(CW), 0, s, d_stats, (double)L * (double)L,
@@ -743,44 +783,61 @@ int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const dou
   // block's output is read by the head in float32 only: no pieces)
   const int split = (c->conv_mode != 1 && c->xsplit_current && block < NBLOCK) ? c->conv_mode : -1;
   const float xscale = (c->act_scaling && block < NBLOCK) ? c->W.blk[block].x_scale : 1.0f;
-  dim3 grid(cdiv(L, 128), L);
-#define NORM_LAUNCH(S)                                                                              \
-  hipLaunchKernelGGL(norm_scse_residual_kernel<S>, grid, dim3(256), 0, s, d_u, c->ab, B.cse, B.sse_w, \
-                     B.sse_b, d_xpad_in, L, P, d_xpad_out, c->xsplit, c->seq_abort, xscale)
-  if (split == 0) NORM_LAUNCH(0);
-  else if (split == 2) NORM_LAUNCH(2);
-  else NORM_LAUNCH(-1);
+  dim3 grid(cdiv(L, 64), L);
+#define NORM_LAUNCH(S, H)                                                                              \
+  hipLaunchKernelGGL((norm_scse_residual_kernel<S, H>), grid, dim3(256), 0, s, d_u, c->ab, B.cse, B.sse_w, \
+                     B.sse_b, d_xpad_in, L, P, d_xpad_out, c->xsplit, c->seq_abort, xscale, W.head_w,   \
+                     W.head_b[0], W.head_b[1], c->head0, c->head1)
+  if (head) NORM_LAUNCH(-1, 1);
+  else if (split == 0) NORM_LAUNCH(0, 0);
+  else if (split == 2) NORM_LAUNCH(2, 0);
+  else NORM_LAUNCH(-1, 0);
 #undef NORM_LAUNCH
   DMP_LAUNCH_CHECK();
+  c->head_current = head;
   return DMP_OK;
 }
 
 // ---------------------------------------------------------------------------------------
 // head 1x1 conv (128 -> 2), row means of channel 1, Gram matrix of |sym(channel 0)|
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ xpad,
-                                                   const float* __restrict__ hw, float b0, float b1,
-                                                   int L, int P, float* __restrict__ head0,
-                                                   float* __restrict__ conf) {
+// the two head planes of padded activations (stage-level API; inside a trunk pass the last block's norm kernel
+// writes them): per pixel the channel sum as four quarter chains, (q0 + q1) + (q2 + q3), like that kernel
+__global__ __launch_bounds__(256) void head_planes_kernel(const float* __restrict__ xpad,
+                                                          const float* __restrict__ hw, float b0, float b1,
+                                                          int L, int P, float* __restrict__ head0,
+                                                          float* __restrict__ head1) {
   __shared__ float sw[2 * CW];
-  __shared__ double red[256];
   sw[threadIdx.x] = hw[threadIdx.x];
   __syncthreads();
-  const int i = blockIdx.x;
+  const int i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= L) return;
   const int64_t PP = (int64_t)P * P;
-  double rsum = 0.0;
-  for (int j = threadIdx.x; j < L; j += 256) {
-    const float* px = xpad + (int64_t)(i + 2) * P + j + 2;
-    float o0 = 0.f, o1 = 0.f;
+  const float* px = xpad + (int64_t)(i + 2) * P + j + 2;
+  float p0[4], p1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    p0[q] = 0.f; p1[q] = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < CW; ++c) {
+    for (int k = 0; k < CW / 4; ++k) {
+      const int c = q * (CW / 4) + k;
       const float v = px[c * PP];
-      o0 = fmaf(sw[c], v, o0);
-      o1 = fmaf(sw[CW + c], v, o1);
+      p0[q] = fmaf(sw[c], v, p0[q]);
+      p1[q] = fmaf(sw[CW + c], v, p1[q]);
     }
-    head0[(int64_t)i * L + j] = o0 + b0;
-    rsum += (double)(o1 + b1);
   }
+  head0[(int64_t)i * L + j] = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + b0;
+  head1[(int64_t)i * L + j] = ((p1[0] + p1[1]) + (p1[2] + p1[3])) + b1;
+}
+
+// conf[i] = mean over j of head channel 1 (float64 sum: lane-strided, then a fixed tree)
+__global__ __launch_bounds__(256) void head_conf_kernel(const float* __restrict__ head1, int L,
+                                                        float* __restrict__ conf) {
+  __shared__ double red[256];
+  const int i = blockIdx.x;
+  double rsum = 0.0;
+  for (int j = threadIdx.x; j < L; j += 256) rsum += (double)head1[(int64_t)i * L + j];
   red[threadIdx.x] = rsum;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -808,8 +865,13 @@ int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, floa
                      hipStream_t s) {
   const Weights& W = c->W;
   const int P = act_pitch(L);
-  hipLaunchKernelGGL(head_kernel, dim3(L), dim3(256), 0, s, d_xpad, W.head_w, W.head_b[0],
-                     W.head_b[1], L, P, c->head0, d_conf);
+  if (!c->head_current) {
+    hipLaunchKernelGGL(head_planes_kernel, dim3(cdiv(L, 256), L), dim3(256), 0, s, d_xpad, W.head_w, W.head_b[0],
+                       W.head_b[1], L, P, c->head0, c->head1);
+    DMP_LAUNCH_CHECK();
+  }
+  c->head_current = false;
+  hipLaunchKernelGGL(head_conf_kernel, dim3(L), dim3(256), 0, s, c->head1, L, d_conf);
   DMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_kernel, dim3(cdiv(L, 256), L), dim3(256), 0, s, c->head0, L, d_M);
   DMP_LAUNCH_CHECK();

@@ -25,6 +25,8 @@
 //     group step kernel below, replayed from hipGraph chains of 128 (or 16) nodes.
 #include "common.h"
 #include <type_traits>
+#include <map>
+#include <mutex>
 
 namespace dmp {
 
@@ -467,8 +469,16 @@ __device__ __forceinline__ vg_u32x4 vp_load16_sc1(const void* p) {              
   return v;
 }
 template <int N> __device__ __forceinline__ void vp_wait8(vg_u32x4 (&b)[2][2], vg_u32x4 (&c)[2][2]) {
-  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]),
+  asm volatile("s_waitcnt vmcnt(%8)\n\ts_nop 1" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]),
                                        "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]) : "n"(N) : "memory");
+}
+// The MFMAs of vp_mfma_a are inline assembly: the compiler's hazard recogniser does not see them, and the hardware
+// does not interlock a matrix-core result against a non-MFMA reader (the compiler puts `s_nop 7` between a
+// v_mfma_f32_16x16x32_f16 and a ds_write of its result).  Dependent MFMAs on the same accumulator need no wait states;
+// before anything else reads the eight layer-1 accumulators, this pads 16.
+__device__ __forceinline__ void vp_mfma_results_ready(vp_f32x4 (&a)[4][2]) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
+                                       "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]));
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -528,38 +538,83 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
   const int nmem = rec->nmem;
   __syncthreads();
 
+  // member of a column tile / is the tile computed at row t (layer 0: t < N; layer 1, one row behind: 1 <= t <= N)
+  auto member_of = [&](int ct) {
+    int mi = 0;
+    for (int m = 1; m < VG_MAX_MEMBERS; ++m)
+      if (m < nmem && ct >= rec->mem[m].tile0) mi = m;
+    return mi;
+  };
+  auto next_active = [&](int ct, int t) {               // first tile >= ct of this XCD that is computed at row t, or c_hi
+    for (; ct < c_hi; ++ct) {
+      const int N = rec->mem[member_of(ct)].N;
+      if (t < N || (t >= 1 && t <= N)) break;
+    }
+    return ct;
+  };
+  // state pieces of this wave's K quarter for one column tile: [k-step][piece][column half].  Every load is
+  // unconditional and every one of them is waited for (vp_all_landed) in the same straight-line stretch that issued
+  // it - before the loop's back edge -, so the compiler never holds a copy of a register whose data is still in flight.
+  vg_u32x4 b0[4][2][2], b1[4][2][2];
+  auto load_tile = [&](const uint4* h0p, const uint4* h1p, int tcol) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int64_t off = (int64_t)(p * 64 + 16 * w + 4 * ks + lq) * Lb + tcol + nt * 16 + lr;
+          b0[ks][p][nt] = vp_load16_sc1(h0p + off);
+          b1[ks][p][nt] = vp_load16_sc1(h1p + off);
+        }
+  };
+  auto all_landed = [&]() {
+    vp_wait8<0>(b0[0], b1[0]);
+    vp_wait8<0>(b0[1], b1[1]);
+    vp_wait8<0>(b0[2], b1[2]);
+    vp_wait8<0>(b0[3], b1[3]);
+  };
+
   for (int t = t_lo; t < t_hi; ++t) {
     const int par = t & 1;
     const uint4* h0p = reinterpret_cast<const uint4*>(st.hH[0][par]);          // layer 0 state at row t (both layers read it)
     const uint4* h1p = reinterpret_cast<const uint4*>(st.hH[1][par ^ 1]);      // layer 1 state at row t-1
-    for (int ct = c_lo; ct < c_hi; ++ct) {
-      int mi = 0;
-      for (int m = 1; m < VG_MAX_MEMBERS; ++m)
-        if (m < nmem && ct >= rec->mem[m].tile0) mi = m;
+    const float* hprev = fl ? st.hT[1][par ^ 1] : st.hT[0][par];
+    float* hnext = fl ? st.hT[1][par] : st.hT[0][par ^ 1];
+    uint16_t* gnext = fl ? st.hH[1][par] : st.hH[0][par ^ 1];
+    int ct = next_active(c_lo, t);
+    if (ct < c_hi) {
+      load_tile(h0p, h1p, ct * VG_TB);
+      all_landed();
+    }
+    while (ct < c_hi) {
+      const int mi = member_of(ct);
       const int N = rec->mem[mi].N, L = rec->mem[mi].L;
       const bool act0 = t < N, act1 = t >= 1 && t <= N;
-      if (!act0 && !act1) continue;
       const int tcol = ct * VG_TB;
-      // ---- state pieces of this wave's K quarter: [k-step][piece][column half]
-      vg_u32x4 b0[4][2][2], b1[4][2][2];
+      // what the finishing threads need of this tile - their previous state, layer 0's residue code - is requested
+      // now and lands under the MFMAs
+      const int b = tcol + fc;
+      const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
+      // four one-word loads: with the state's float4 as ONE vector asm output the compiler's packed-f32 gate arithmetic
+      // took element 0 for every row (v_pk_add_f32 ... op_sel_hi:[0,1]; found by substitution on the GPU, round 4)
+      float hp[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const int64_t off = (int64_t)(p * 64 + 16 * w + 4 * ks + lq) * Lb + tcol + nt * 16 + lr;
-            b0[ks][p][nt] = vp_load16_sc1(h0p + off);
-            b1[ks][p][nt] = vp_load16_sc1(act1 ? h1p + off : h0p + off);
-          }
+      for (int i = 0; i < 4; ++i)
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(hp[i]) : "v"(hprev + hoff + i) : "memory");
+      const int bm = (ct - rec->mem[mi].tile0) * VG_TB + fc;                   // the column in ITS alignment
+      unsigned codeu;
+      {
+        const uint8_t* q = rec->mem[mi].msa + (int64_t)(t < N ? t : 0) * L + (bm < L ? bm : 0);
+        asm volatile("global_load_ubyte %0, %1, off" : "=v"(codeu) : "v"(q) : "memory");
+      }
       vp_f32x4 a0[3][2], a1[4][2];                     // layer 0: r z hn; layer 1: r z hn in; x column half
 #pragma unroll
       for (int g = 0; g < 3; ++g) { a0[g][0] = vp_f32x4{0, 0, 0, 0}; a0[g][1] = vp_f32x4{0, 0, 0, 0}; }
 #pragma unroll
       for (int g = 0; g < 4; ++g) { a1[g][0] = vp_f32x4{0, 0, 0, 0}; a1[g][1] = vp_f32x4{0, 0, 0, 0}; }
-      auto kstep = [&](auto ksc) {
-        constexpr int ks = decltype(ksc)::value;
-        vp_wait8<8 * (3 - ks)>(b0[ks], b1[ks]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
         if (act0) {
           uint4 f[6];
 #pragma unroll
@@ -587,11 +642,12 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
               a1[qa][nt] = vp_mfma_a(WA[ks * 6 + g], b0[ks][0][nt], a1[qa][nt]);
             }
         }
-      };
-      kstep(std::integral_constant<int, 0>{});
-      kstep(std::integral_constant<int, 1>{});
-      kstep(std::integral_constant<int, 2>{});
-      kstep(std::integral_constant<int, 3>{});
+      }
+      vp_mfma_results_ready(a1);
+      // the next tile's pieces stream in under this tile's reduction (after its last tile an XCD re-reads that
+      // tile: the loads stay unconditional)
+      const int nx = next_active(ct + 1, t);
+      load_tile(h0p, h1p, (nx < c_hi ? nx : ct) * VG_TB);
       // ---- partial sums of the four K quarters meet in LDS
 #pragma unroll
       for (int g = 0; g < 3; ++g)
@@ -602,6 +658,8 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) red[(w * 14 + 6 + g * 2 + nt) * 64 + lane] = a1[g][nt];
       __syncthreads();
+      // previous state and residue code: older than the 32 loads just issued
+      asm volatile("s_waitcnt vmcnt(32)" : "+v"(hp[0]), "+v"(hp[1]), "+v"(hp[2]), "+v"(hp[3]), "+v"(codeu) :: "memory");
       if (fl ? act1 : act0) {
         const int nq = fl ? 4 : 3, base = fl ? 6 : 0;
         vp_f32x4 sum[4];
@@ -613,24 +671,14 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
                      red[(3 * 14 + a) * 64 + flane];
           }
         }
-        const int b = tcol + fc;
         if (fl == 0) {
-          const int bm = (ct - rec->mem[mi].tile0) * VG_TB + fc;              // the column in ITS alignment
-          const int code = bm < L ? (int)rec->mem[mi].msa[(int64_t)t * L + bm] : 0;
+          const int code = bm < L ? (int)(codeu & 0xffu) : 0;
           const float* tr = tab + (0 * 24 + code) * 16 + 4 * fg;
           const float* tz = tab + (1 * 24 + code) * 16 + 4 * fg;
           const float* tn = tab + (2 * 24 + code) * 16 + 4 * fg;
 #pragma unroll
           for (int i = 0; i < 4; ++i) { sum[0][i] += tr[i]; sum[1][i] += tz[i]; sum[3][i] = tn[i]; }
         }
-        const float* hprev = fl ? st.hT[1][par ^ 1] : st.hT[0][par];
-        float* hnext = fl ? st.hT[1][par] : st.hT[0][par ^ 1];
-        uint16_t* gnext = fl ? st.hH[1][par] : st.hH[0][par ^ 1];
-        const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
-        const vg_u32x4 hpu = vp_load16_sc1(hprev + hoff);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const float hp[4] = {__builtin_bit_cast(float, hpu.x), __builtin_bit_cast(float, hpu.y),
-                             __builtin_bit_cast(float, hpu.z), __builtin_bit_cast(float, hpu.w)};
         const float br[4] = {bR.x, bR.y, bR.z, bR.w}, bz[4] = {bZ.x, bZ.y, bZ.z, bZ.w};
         const float bi[4] = {bI.x, bI.y, bI.z, bI.w}, bh[4] = {bH.x, bH.y, bH.z, bH.w};
         float hn[4];
@@ -655,6 +703,8 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
             make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
       }
       __syncthreads();                                 // `red` is free for the next tile
+      all_landed();                                    // the next tile's pieces (and this tile's stores)
+      ct = nx;
     }
     // ---- row boundary: every workgroup of this XCD has written its rows of the new state
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
@@ -797,10 +847,25 @@ int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
     st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
     if (t_lo >= t_hi) return DMP_OK;
     VPSync* sync = reinterpret_cast<VPSync*>(lead->vgru_sync);
-    DMP_HIP(hipMemsetAsync(sync, 0, sizeof(VPSync), s));
-    hipLaunchKernelGGL(vgru_persist_kernel, dim3(VP_GRID), dim3(256), VP_LDS_BYTES, s, st, (const VGroupRec*)rec, sync,
-                       lead->seq_abort, t_lo, t_hi, nt);
-    DMP_LAUNCH_CHECK();
+    // One persistent chain at a time per device: a launch needs every one of its 256 workgroups resident (row
+    // barriers), and two such launches on different streams could each hold part of the CUs and wait for the rest
+    // forever.  Every launch therefore waits for the previous one of this process (whatever context and stream it ran
+    // on) and leaves its own completion event behind.  (Another PROCESS on the same GPU can still collide: the
+    // barriers then time out, the prediction is flagged DMP_FAULT_VGRU_HANDOFF and the Python layer repeats it with the
+    // launch-per-row form.)
+    {
+      static std::mutex mu;
+      static std::map<int, hipEvent_t> last;          // device -> completion of the most recent persistent launch
+      std::lock_guard<std::mutex> lock(mu);
+      hipEvent_t& ev = last[lead->device];
+      if (ev) DMP_HIP(hipStreamWaitEvent(s, ev, 0));
+      else DMP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      DMP_HIP(hipMemsetAsync(sync, 0, sizeof(VPSync), s));
+      hipLaunchKernelGGL(vgru_persist_kernel, dim3(VP_GRID), dim3(256), VP_LDS_BYTES, s, st, (const VGroupRec*)rec, sync,
+                         lead->seq_abort, t_lo, t_hi, nt);
+      DMP_LAUNCH_CHECK();
+      DMP_HIP(hipEventRecord(ev, s));
+    }
     return DMP_OK;
   }
   for (int t = t_lo; t < t_hi;) {

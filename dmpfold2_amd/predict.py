@@ -300,6 +300,14 @@ class Engine:
         coords, confs = self.predict_device(d_msa, template_ca, iterations, minsteps)
         bits = self.sync_faults()
         self.last_fallback = False
+        if bits & FAULT_VGRU_HANDOFF and self.get_option("vgru_persistent"):
+            # the persistent chain's row barriers timed out (its workgroups were not all resident: another process
+            # on this GPU holds CUs with a launch of the same kind): the launch-per-row form has no such requirement
+            print("dmpfold2_amd: the persistent vertical-GRU launch could not get the whole GPU; re-running this "
+                  "alignment (and every later one on this engine) with one launch per alignment row", file=sys.stderr)
+            self.set_option("vgru_persistent", 0)
+            coords, confs = self.predict_device(d_msa, template_ca, iterations, minsteps)
+            bits = self.sync_faults()
         if bits == FAULT_F16_RANGE and self.get_option("conv_mode") == 0:
             print("dmpfold2_amd: activations left the f16 range of the split-product convolution; "
                   "re-running this alignment with conv_mode=2 (bf16 split, no range limit)",
