@@ -463,15 +463,6 @@ __device__ __forceinline__ vp_f32x4 vp_mfma_a(vg_u32x4 a, vg_u32x4 b, vp_f32x4 c
 __device__ __forceinline__ vp_f32x4 vp_mfma_v(uint4 a, vg_u32x4 b, vp_f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vg_f16x8, a), __builtin_bit_cast(vg_f16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ vg_u32x4 vp_load16_sc1(const void* p) {                         // past the L1: served by the XCD's L2
-  vg_u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-template <int N> __device__ __forceinline__ void vp_wait8(vg_u32x4 (&b)[2][2], vg_u32x4 (&c)[2][2]) {
-  asm volatile("s_waitcnt vmcnt(%8)\n\ts_nop 1" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]),
-                                       "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]) : "n"(N) : "memory");
-}
 // The MFMAs of vp_mfma_a are inline assembly: the compiler's hazard recogniser does not see them, and the hardware
 // does not interlock a matrix-core result against a non-MFMA reader (the compiler puts `s_nop 7` between a
 // v_mfma_f32_16x16x32_f16 and a ds_write of its result).  Dependent MFMAs on the same accumulator need no wait states;
@@ -552,41 +543,43 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
     }
     return ct;
   };
-  // state pieces of this wave's K quarter for one column tile: [k-step][piece][column half].  Every load is
-  // unconditional and every one of them is waited for (vp_all_landed) in the same straight-line stretch that issued
-  // it - before the loop's back edge -, so the compiler never holds a copy of a register whose data is still in flight.
-  vg_u32x4 b0[4][2][2], b1[4][2][2];
-  auto load_tile = [&](const uint4* h0p, const uint4* h1p, int tcol) {
+  // State pieces of this wave's K quarter for one column tile: [k-step][piece][column half], as buffer loads the
+  // compiler tracks itself (raw_buffer_load with the sc1 bit: past the L1, served by the XCD's L2).  A first version
+  // used inline-assembly loads with hand-counted waits, as the launch-per-row kernel does; with registers carried
+  // around this loop's back edge that produced wrong values for every tile after an XCD's first (run-to-run
+  // different, invisible to a static in-flight-register check), so the waits are the compiler's here.
+  typedef unsigned vp_u32x4v __attribute__((vector_size(16)));
+  constexpr int VP_SC1 = 16;                            // cache-policy bit of the buffer load: agent scope
+  auto load_tile = [&](__amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, int tcol, vg_u32x4 (&d0)[4][2][2],
+                       vg_u32x4 (&d1)[4][2][2]) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const int64_t off = (int64_t)(p * 64 + 16 * w + 4 * ks + lq) * Lb + tcol + nt * 16 + lr;
-          b0[ks][p][nt] = vp_load16_sc1(h0p + off);
-          b1[ks][p][nt] = vp_load16_sc1(h1p + off);
+          const unsigned off = (unsigned)(((p * 64 + 16 * w + 4 * ks + lq) * Lb + tcol + nt * 16 + lr) * 16);
+          const vp_u32x4v x0 = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, VP_SC1);
+          const vp_u32x4v x1 = __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0, VP_SC1);
+          d0[ks][p][nt] = vg_u32x4{x0[0], x0[1], x0[2], x0[3]};
+          d1[ks][p][nt] = vg_u32x4{x1[0], x1[1], x1[2], x1[3]};
         }
   };
-  auto all_landed = [&]() {
-    vp_wait8<0>(b0[0], b1[0]);
-    vp_wait8<0>(b0[1], b1[1]);
-    vp_wait8<0>(b0[2], b1[2]);
-    vp_wait8<0>(b0[3], b1[3]);
-  };
+  const unsigned piece_bytes = (unsigned)(2 * 64 * Lb * 16);     // one layer / parity: [piece 2][k/8 64][Lb] x 16 bytes
+  const unsigned state_bytes = (unsigned)(128 * Lb * 16);        // [j/4 128][Lb] x float4
 
   for (int t = t_lo; t < t_hi; ++t) {
     const int par = t & 1;
-    const uint4* h0p = reinterpret_cast<const uint4*>(st.hH[0][par]);          // layer 0 state at row t (both layers read it)
-    const uint4* h1p = reinterpret_cast<const uint4*>(st.hH[1][par ^ 1]);      // layer 1 state at row t-1
-    const float* hprev = fl ? st.hT[1][par ^ 1] : st.hT[0][par];
+    // layer 0 state at row t (both layers read it), layer 1 state at row t-1, this thread's layer's previous state
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(st.hH[0][par], 0, piece_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(st.hH[1][par ^ 1], 0, piece_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh =
+        __builtin_amdgcn_make_buffer_rsrc(fl ? st.hT[1][par ^ 1] : st.hT[0][par], 0, state_bytes, 0x00020000);
     float* hnext = fl ? st.hT[1][par] : st.hT[0][par ^ 1];
     uint16_t* gnext = fl ? st.hH[1][par] : st.hH[0][par ^ 1];
     int ct = next_active(c_lo, t);
-    if (ct < c_hi) {
-      load_tile(h0p, h1p, ct * VG_TB);
-      all_landed();
-    }
+    vg_u32x4 b0[4][2][2], b1[4][2][2];
+    if (ct < c_hi) load_tile(r0, r1, ct * VG_TB, b0, b1);
     while (ct < c_hi) {
       const int mi = member_of(ct);
       const int N = rec->mem[mi].N, L = rec->mem[mi].L;
@@ -596,18 +589,14 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
       // now and lands under the MFMAs
       const int b = tcol + fc;
       const int64_t hoff = ((int64_t)(j4 >> 2) * Lb + b) * 4;
-      // four one-word loads: with the state's float4 as ONE vector asm output the compiler's packed-f32 gate arithmetic
-      // took element 0 for every row (v_pk_add_f32 ... op_sel_hi:[0,1]; found by substitution on the GPU, round 4)
+      // (four one-word loads: with the state's float4 as ONE 16-byte load the compiler's packed-f32 gate arithmetic took
+      // element 0 for every row - v_pk_add_f32 ... op_sel_hi:[0,1]; found by substitution on the GPU, twice)
       float hp[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(hp[i]) : "v"(hprev + hoff + i) : "memory");
+        hp[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (unsigned)(hoff * 4 + 4 * i), 0, VP_SC1));
       const int bm = (ct - rec->mem[mi].tile0) * VG_TB + fc;                   // the column in ITS alignment
-      unsigned codeu;
-      {
-        const uint8_t* q = rec->mem[mi].msa + (int64_t)(t < N ? t : 0) * L + (bm < L ? bm : 0);
-        asm volatile("global_load_ubyte %0, %1, off" : "=v"(codeu) : "v"(q) : "memory");
-      }
+      const int code = (fl == 0 && act0 && bm < L) ? (int)rec->mem[mi].msa[(int64_t)t * L + bm] : 0;
       vp_f32x4 a0[3][2], a1[4][2];                     // layer 0: r z hn; layer 1: r z hn in; x column half
 #pragma unroll
       for (int g = 0; g < 3; ++g) { a0[g][0] = vp_f32x4{0, 0, 0, 0}; a0[g][1] = vp_f32x4{0, 0, 0, 0}; }
@@ -644,10 +633,9 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
         }
       }
       vp_mfma_results_ready(a1);
-      // the next tile's pieces stream in under this tile's reduction (after its last tile an XCD re-reads that
-      // tile: the loads stay unconditional)
+      // the next tile's pieces stream in under this tile's reduction
       const int nx = next_active(ct + 1, t);
-      load_tile(h0p, h1p, (nx < c_hi ? nx : ct) * VG_TB);
+      if (nx < c_hi) load_tile(r0, r1, nx * VG_TB, b0, b1);        // (the MFMAs above were the last readers of b0 / b1)
       // ---- partial sums of the four K quarters meet in LDS
 #pragma unroll
       for (int g = 0; g < 3; ++g)
@@ -658,8 +646,6 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) red[(w * 14 + 6 + g * 2 + nt) * 64 + lane] = a1[g][nt];
       __syncthreads();
-      // previous state and residue code: older than the 32 loads just issued
-      asm volatile("s_waitcnt vmcnt(32)" : "+v"(hp[0]), "+v"(hp[1]), "+v"(hp[2]), "+v"(hp[3]), "+v"(codeu) :: "memory");
       if (fl ? act1 : act0) {
         const int nq = fl ? 4 : 3, base = fl ? 6 : 0;
         vp_f32x4 sum[4];
@@ -672,7 +658,6 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
           }
         }
         if (fl == 0) {
-          const int code = bm < L ? (int)(codeu & 0xffu) : 0;
           const float* tr = tab + (0 * 24 + code) * 16 + 4 * fg;
           const float* tz = tab + (1 * 24 + code) * 16 + 4 * fg;
           const float* tn = tab + (2 * 24 + code) * 16 + 4 * fg;
@@ -703,7 +688,6 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
             make_uint2((unsigned)q1[0] | ((unsigned)q1[1] << 16), (unsigned)q1[2] | ((unsigned)q1[3] << 16));
       }
       __syncthreads();                                 // `red` is free for the next tile
-      all_landed();                                    // the next tile's pieces (and this tile's stores)
       ct = nx;
     }
     // ---- row boundary: every workgroup of this XCD has written its rows of the new state

@@ -343,6 +343,47 @@ def test_config4_L1000_well_separated_spectrum_vs_reference(synth_sd):
         eng.close()
 
 
+@pytest.mark.parametrize("name,L", [("deep_L500_N5000_n30_m0", 500), ("deep_L1000_N2000_n10_m0", 1000)])
+def test_deep_recycling_at_the_large_configurations_vs_reference(synth_sd, name, L):
+    """the recycling loop (network.py:264-306) at DEPTH at the large configurations, through the
+    reference itself - configs[2] (L=500, 5000 rows cut to 3000) at 31 trunk passes and configs[4] (L=1000, the
+    well-separated seed 0) at 11 - every pass's trace and confidence mean.  One reference run takes most of an hour
+    in the build container (make_goldens.py: reference at 8 threads + one oracle run at 4 threads for the per-pass
+    floors).  The final structure at the plain tolerance where the fixture's own floor allows it, every pass at
+    max(1e-3, 4 x that pass's floor) (recycling is expansive over its early passes, test_gpu_headline._check_passes)."""
+    import hashlib
+    import os
+    from conftest import GOLDEN, load_golden
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated: " + name)
+    g = load_golden(name)
+    n = int(g["iterations"])
+    P = n + 1
+    alnmat = encode_aln(synth.synth_msa(L, int(g["msa_rows"]), int(g["msa_seed"])))
+    assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+    eng = Engine("cuda:0", L, alnmat.shape[0])
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+    try:
+        coords, confs = eng.predict(alnmat, None, n, 0)
+        eng.sync_check()
+        ca_pass = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
+        dev = np.array([ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P)])
+        floor = np.asarray(g["noise_ca_pass"])
+        means = eng.fetch("conf_means", P).cpu().numpy()
+        final = ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1])
+        dconf = float(np.abs(confs.cpu().numpy() - g["confs"]).max())
+        print(name, "per-pass CA-RMSD", np.array2string(dev, precision=2), "floors", np.array2string(floor, precision=2),
+              "final", final, "max|dconf|", dconf, "max|dmean|", float(np.abs(means - g["conf_mean_pass"]).max()))
+        assert (dev <= np.maximum(1e-3, 4.0 * floor)).all(), (dev, floor)
+        assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
+        assert final <= max(1e-3, 3.0 * float(g["noise_ca_rmsd"]))
+        assert dconf < max(1e-4, 3.0 * float(g["noise_conf"]))
+    finally:
+        eng.close()
+
+
 def test_above_the_former_length_limit_vs_reference(synth_sd):
     """L = 1344 > 1280 (the round-2 DMP_MAX_L): one trunk pass through the reference itself on an alignment whose top
     MDS eigenvalues are well separated (seed 4 of tools/screen_eig_gaps.py --L 1344 --N 1000: smallest relative gap
