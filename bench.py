@@ -263,6 +263,11 @@ def main(argv=None):
     ap.add_argument("--cpu-baseline", choices=("full", "sample", "none"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-f32 convolution leg")
+    ap.add_argument("--legs", choices=("both", "f16x3", "f32"), default="both",
+                    help="profiling: run only one arithmetic leg (f32 alone skips the verification and latency extras, "
+                         "so that a kernel-stats table of the run holds that leg's launches only)")
+    ap.add_argument("--vgru-per-row", action="store_true",
+                    help="A/B: the vertical GRU as one launch per alignment row (round 3) instead of the persistent launch")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -307,6 +312,9 @@ def main(argv=None):
     sd = synth.synth_weights(0, coord_scale=5.0)
     pipe = Pipeline(device, L_NS, N_NS, {k: torch.from_numpy(np.array(v)) for k, v in sd.items()},
                     streams=S)
+    if args.vgru_per_row:
+        for e in pipe.engines:
+            e.set_option("vgru_persistent", 0)
 
     # B synthetic targets per step and rank, all resident in HBM before the clock starts
     B = args.batch if args.batch > 0 else 2 * S
@@ -365,6 +373,23 @@ def main(argv=None):
             e.set_option("conv_mode", 0)
         return el, warm, timed, cnt, tot, union
 
+    only_f32 = args.legs == "f32"
+    if args.legs == "f16x3":
+        args.no_exact_f32 = True
+    if only_f32:
+        # profiling run of the exact-f32 leg alone: its numbers go into the f32 keys, nothing else is measured
+        exact, warm1, timed1, cnt1, tot1, union1 = timed_leg(1)
+        if rank == 0:
+            eff1 = union1 / cnt1 if cnt1 else 0.0
+            print(json.dumps({"metric": "structures/s at L=300, N_seq=2000, 10 iters+100 min", "legs": "f32",
+                              "value_f32": world * args.steps * B / exact, "ms_per_step_f32": exact / args.steps * 1e3,
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "roofline_f32": {"achieved": CONV_FLOP_PER_LAUNCH / (eff1 * 1e-3) / 1e12 if eff1 else 0.0,
+                                               "peak": PEAK_F32_MFMA_TFLOPS, "chip_ms_per_launch": eff1,
+                                               "avg_launch_ms": tot1 / cnt1 if cnt1 else 0.0, "launches_timed": cnt1}}), flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        return 0
     elapsed, outs, timed_outs, conv_cnt, conv_tot, conv_union = timed_leg(0)
     outs += timed_outs
     conv_ms = conv_tot / conv_cnt if conv_cnt else 0.0

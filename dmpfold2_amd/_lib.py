@@ -19,7 +19,6 @@ SIGNATURES = {
     "dmp_last_error": (C.c_char_p, []),
     "dmp_ctx_create": (_i, [_i, _i, _i, C.POINTER(_vp)]),
     "dmp_ctx_destroy": (None, [_vp]),
-    "dmp_ctx_device_bytes": (_i64, [_vp]),
     "dmp_ctx_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dmp_ctx_get_option": (_i, [_vp, C.c_char_p, C.POINTER(_i)]),
     "dmp_weights_set": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
@@ -38,6 +37,7 @@ SIGNATURES = {
     "dmp_stem_update": (_i, [_vp, _fp, _fp, _i, _fp, _vp]),
     "dmp_block_conv5x5_maxout": (_i, [_vp, _i, _fp, _i, _fp, _fp, _vp]),
     "dmp_block_norm_scse_residual": (_i, [_vp, _i, _fp, _fp, _fp, _i, _fp, _vp]),
+    "dmp_block_conv5x5_maxout_bwd": (_i, [_vp, _i, _fp, _fp, _i, _fp, _fp, _fp, _vp]),
     "dmp_head_gram": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
     "dmp_trunk_pass": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_eigh_top8": (_i, [_vp, _fp, _i, _fp, _vp]),

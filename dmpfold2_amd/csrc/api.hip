@@ -531,6 +531,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "conv_mode") { *h_value = ctx->conv_mode; return DMP_OK; }
   if (k == "conv_f32_exact") { *h_value = ctx->conv_mode == 1; return DMP_OK; }
   if (k == "act_scaling") { *h_value = ctx->act_scaling; return DMP_OK; }
+  if (k == "device_mib") { *h_value = (int)((ctx->bytes + (1 << 20) - 1) >> 20); return DMP_OK; }    // read only
   if (k == "vgru_persistent") { *h_value = ctx->vgru_persist && ctx->vgru_persist_ok; return DMP_OK; }
   if (k.rfind("act_scale_log2_block", 0) == 0) {      // read-only: log2 of the piece scale of block 1..16's input
     const int b = atoi(k.c_str() + 20);
@@ -563,6 +564,8 @@ int dmp_sync_faults(dmp_ctx* ctx, void* stream, int* h_bits) {
 
 void dmp_ctx_destroy(dmp_ctx* c) {
   if (!c) return;
+  if (c->bwd_ws) (void)hipFree(c->bwd_ws);
+  if (c->bwd_w) (void)hipFree(c->bwd_w);
   for (void* p : c->allocs) (void)hipFree(p);
   release_weights(c);
   for (void* e : c->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
@@ -577,7 +580,6 @@ void dmp_ctx_destroy(dmp_ctx* c) {
   delete c;
 }
 
-int64_t dmp_ctx_device_bytes(const dmp_ctx* c) { return c ? c->bytes : 0; }
 
 int dmp_weights_set(dmp_ctx* c, const char* key, const float* h_data, const int64_t* shape, int ndim) {
   DMP_ARG(c && key && h_data && shape, "null argument");
@@ -617,6 +619,7 @@ int dmp_weights_finalize(dmp_ctx* c) {
   }
   DMP_HIP(hipSetDevice(c->device));
   release_weights(c);
+  c->bwd_w_block = 0;                   // the unpacked weights of the training-side slice belong to the old set
   int rc = pack_weights(c);
   if (rc) return rc;
   c->W.host.clear();
@@ -636,6 +639,7 @@ int dmp_weights_share(dmp_ctx* dst, const dmp_ctx* src) {
   dst->W.host.clear();
   dst->W.shapes.clear();
   const std::shared_ptr<std::vector<void*>> hold = src->W.shared;
+  dst->bwd_w_block = 0;
   dst->W = src->W;                    // pointers, scales, hash
   dst->W.host.clear();
   dst->W.shapes.clear();
@@ -777,6 +781,14 @@ int dmp_block_norm_scse_residual(dmp_ctx* ctx, int block, const float* d_u, cons
   return act_unpad(ctx->xb, L, d_out, STREAM);
 }
 
+int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, const float* d_du, int L, float* d_dx,
+                                 float* d_dw, float* d_db, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(block >= 1 && block <= NBLOCK && d_x && d_du && d_dx && d_dw && d_db, "bad argument");
+  return conv5x5_maxout_bwd(ctx, block, d_x, d_du, L, d_dx, d_dw, d_db, STREAM);
+}
+
 int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M, void* stream) {
   CHECK_CAP(L, 1);
   CHECK_W();
@@ -885,7 +897,7 @@ static int issue_group_chain(dmp_ctx* c, int j, hipStream_t s) {
   // a real group's chain is ONE unit (every member waits for its end, and nothing else wants this stream
   // meanwhile): chunked, the chain stood still for 2-3 ms between chunks whenever the scheduler thread was busy
   // issuing the members' inverse units (kernel trace: 40 ms of a 97 ms front-end phase)
-  const bool whole = n + nr > 1;
+  const bool whole = n + nr > 1 || c->fe_vgru == 1;
   const int chunks = whole ? 1 : cdiv(c->vg_maxN + 1, FE_VGRU_STEPS);
   if (!rc) rc = whole ? vgru_group_steps(c, 0, c->vg_maxN + 1, s)
                       : vgru_group_steps(c, j * FE_VGRU_STEPS, (j + 1) * FE_VGRU_STEPS, s);
@@ -951,8 +963,9 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
       // the chain of the whole group: this context's units serve every member
       rc = issue_group_chain(c, j, s);
     } else {
-      rc = gru_vertical_steps(c, d_msa, N, L, j * FE_VGRU_STEPS, std::min((j + 1) * FE_VGRU_STEPS, N + 1),
-                              c->vout, s);
+      rc = c->fe_vgru == 1 ? gru_vertical_steps(c, d_msa, N, L, 0, N + 1, c->vout, s)
+                           : gru_vertical_steps(c, d_msa, N, L, j * FE_VGRU_STEPS, std::min((j + 1) * FE_VGRU_STEPS, N + 1),
+                                                c->vout, s);
     }
   } else {
     const float* inv = N > 1 ? c->cov : nullptr;
@@ -1010,7 +1023,9 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->fe_next = 0;
   c->fe_side = false;
   c->fe_inv = N > 1 ? cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
-  c->fe_vgru = cdiv(N + 1, FE_VGRU_STEPS);
+  // the vertical GRU in units of 128 rows (launch-per-row form: one graph replay each) - or, as the persistent launch,
+  // as ONE unit: every launch of that form loads the CUs' weight slices first
+  c->fe_vgru = (c->vgru_persist && c->vgru_persist_ok) ? 1 : cdiv(N + 1, FE_VGRU_STEPS);
   c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
   return DMP_OK;
 }
@@ -1049,7 +1064,7 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n) {
     dmp_ctx* c = ctxs[i];
     c->vg_leader = lead;
     c->vg_index = i;
-    c->fe_vgru = i == 0 ? (n > 1 ? 1 : cdiv(maxN + 1, FE_VGRU_STEPS)) : 0;
+    c->fe_vgru = i == 0 ? ((n > 1 || (lead->vgru_persist && lead->vgru_persist_ok)) ? 1 : cdiv(maxN + 1, FE_VGRU_STEPS)) : 0;
     c->fe_total = 1 + c->fe_inv + c->fe_vgru + 1;
   }
   return DMP_OK;

@@ -196,6 +196,10 @@ struct dmp_ctx {
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm
+  float* bwd_ws = nullptr;     // training-side slice (trunk.hip, conv5x5_maxout_bwd): patch matrix + conv output + routed
+  int64_t bwd_ws_floats = 0;   // gradient, allocated on first use
+  float* bwd_w = nullptr;      // [512][3200] raw weights of block bwd_w_block
+  int bwd_w_block = 0;
   float* head0 = nullptr;   // [L][L] head channel 0 (distances)
   float* head1 = nullptr;   // [L][L] head channel 1 (confidence logits)
   bool head_current = false;   // the last block's norm kernel already wrote head0 / head1 of the current activations
@@ -282,6 +286,8 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
 int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s, int block = 0);
 int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
                               const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s, bool head = false);
+int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_du, int L, float* d_dx, float* d_dw,
+                       float* d_db, hipStream_t s);
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
                      hipStream_t s);
 int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);

@@ -518,7 +518,7 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
     tab[(g * 24 + code) * 16 + row] = VGRU_STATE_SCALE * ((float)__builtin_bit_cast(_Float16, wp[e0]) + (float)__builtin_bit_cast(_Float16, wp[e1]));
   }
   // finishing thread: layer fl, rows j0 + 4 fg .. +3, column fc of the tile
-  const int fl = tid >> 7, fg = (tid >> 5) & 3, fc = tid & 31;
+  const int fl = __builtin_amdgcn_readfirstlane(tid >> 7), fg = (tid >> 5) & 3, fc = tid & 31;   // fl: uniform in a wave
   const int flane = 16 * fg + (fc & 15), fnt = fc >> 4;
   const int j4 = j0 + 4 * fg;
   const float4 bR = *reinterpret_cast<const float4*>(st.bias[fl] + j4);
@@ -608,28 +608,35 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
           uint4 f[6];
 #pragma unroll
           for (int pg = 0; pg < 6; ++pg) f[pg] = wl0[((w * 4 + ks) * 6 + pg) * 64 + lane];
+          // small products first (w0 h1, w1 h0, then w0 h0); per product the six accumulators (gate x column half) take
+          // their MFMA one after the other, so that a dependent MFMA is six instructions behind the one it waits for
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {              // small products first: w0 h1, w1 h0, then w0 h0
-              a0[g][nt] = vp_mfma_v(f[g], b0[ks][1][nt], a0[g][nt]);
-              a0[g][nt] = vp_mfma_v(f[3 + g], b0[ks][0][nt], a0[g][nt]);
-              a0[g][nt] = vp_mfma_v(f[g], b0[ks][0][nt], a0[g][nt]);
-            }
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int g = 0; g < 3; ++g)
+                a0[g][nt] = vp_mfma_v(f[pr == 1 ? 3 + g : g], b0[ks][pr == 0 ? 1 : 0][nt], a0[g][nt]);
         }
         if (act1) {
+          // recurrent product (into r, z, hn), then the input product (into r, z, in): the same order of additions per
+          // accumulator as one after the other, the MFMAs of a product interleaved over the accumulators
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-              const int qa = g == 2 ? 3 : g, qb = g;   // the third gate's input and recurrent sums stay apart
-              a1[qb][nt] = vp_mfma_a(WB[ks * 6 + g], b1[ks][1][nt], a1[qb][nt]);
-              a1[qb][nt] = vp_mfma_a(WB[ks * 6 + 3 + g], b1[ks][0][nt], a1[qb][nt]);
-              a1[qb][nt] = vp_mfma_a(WB[ks * 6 + g], b1[ks][0][nt], a1[qb][nt]);
-              a1[qa][nt] = vp_mfma_a(WA[ks * 6 + g], b0[ks][1][nt], a1[qa][nt]);
-              a1[qa][nt] = vp_mfma_a(WA[ks * 6 + 3 + g], b0[ks][0][nt], a1[qa][nt]);
-              a1[qa][nt] = vp_mfma_a(WA[ks * 6 + g], b0[ks][0][nt], a1[qa][nt]);
-            }
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int g = 0; g < 3; ++g)
+                a1[g][nt] = vp_mfma_a(WB[ks * 6 + (pr == 1 ? 3 + g : g)], b1[ks][pr == 0 ? 1 : 0][nt], a1[g][nt]);
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int g = 0; g < 3; ++g) {
+                const int qa = g == 2 ? 3 : g;         // the third gate's input and recurrent sums stay apart
+                a1[qa][nt] = vp_mfma_a(WA[ks * 6 + (pr == 1 ? 3 + g : g)], b0[ks][pr == 0 ? 1 : 0][nt], a1[qa][nt]);
+              }
         }
       }
       vp_mfma_results_ready(a1);

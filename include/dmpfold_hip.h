@@ -74,8 +74,7 @@ const char* dmp_last_error(void);
 #define DMP_MAX_L 2048
 int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out);
 void dmp_ctx_destroy(dmp_ctx* ctx);
-/* bytes of device memory held by the context */
-int64_t dmp_ctx_device_bytes(const dmp_ctx* ctx);
+/* (device memory held by the context: option "device_mib" of dmp_ctx_get_option, read only) */
 
 /* Options (additive).  "conv_mode" selects how the 5x5 convolutions form their float32 products:
  *   0 (default)  each float32 operand split into two f16 pieces, 3 f16 MFMA products, float32
@@ -194,6 +193,15 @@ int dmp_block_conv5x5_maxout(dmp_ctx* ctx, int block, const float* d_x, int L, f
 int dmp_block_norm_scse_residual(dmp_ctx* ctx, int block, const float* d_u,
                                  const double* d_stats, const float* d_x, int L, float* d_out,
                                  void* stream);
+/* Training-side slice: backward of the first half of ResNet block `block` - Maxout2d's convolution and
+ * max (network.py:25-31 with kernel 5), the piece of autograd train.py:318-344 runs through ResNet_Block
+ * (network.py:85-103).  d_x: the block's input (128 x L x L), d_du: gradient w.r.t. the maxout output (128 x L x L).
+ * Outputs: d_dx (128 x L x L) gradient w.r.t. the input, d_dw (512 x 128 x 5 x 5) and d_db (512) gradients of
+ * layer1.lin.weight / .bias (overwritten, not accumulated).  Float32 matrix-core products on an explicit patch
+ * matrix; ties of the max go to the first maximal channel, as torch.max.  Allocates its workspace ((3200 + 1024) L^2
+ * floats) on first use. */
+int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, const float* d_du, int L, float* d_dx,
+                                 float* d_dw, float* d_db, void* stream);
 /* Head 1x1 conv (network.py:207) + network.py:237-246: d_conf (L) = row means of channel 1,
  * d_M (L x L) = Gram matrix 0.5*(dm_0j^2 + dm_i0^2 - dm_ij^2) of dm = |sym(channel 0)|. */
 int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M,

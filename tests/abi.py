@@ -106,6 +106,12 @@ class Stages:
         self.call("dmp_block_norm_scse_residual", block, u, st, x, L, out)
         return out
 
+    def conv_bwd(self, block, x, du):
+        L = x.shape[-1]
+        dx, dw, db = self.f32(128, L, L), self.f32(512, 128, 5, 5), self.f32(512)
+        self.call("dmp_block_conv5x5_maxout_bwd", block, x, du, L, dx, dw, db)
+        return dx, dw, db
+
     def head_gram(self, x):
         L = x.shape[-1]
         conf, M = self.f32(L), self.f32(L, L)

@@ -449,21 +449,25 @@ def main():
     # THE HEADLINE SIZE AT FULL MDS GAIN: bench target 0 (L=300, N=2000), coord_fc fitted to the
     # protein-like trace as in fitns_*, but the coordinate GRU's 8 MDS input columns UNSCALED - the eigensolver ->
     # coordinate GRU -> distance map feedback of network.py:247-255, 272 at its real gain.  Depth / minimiser steps
-    # chosen where the reference's own thread-count noise stays small (DMP_FULLGAIN="n,m[;n,m...]", explored with
-    # tools/explore_fullgain.py).
+    # chosen where the reference's own thread-count noise stays small (DMP_FULLGAIN="n,m,ridge[;...]", explored with
+    # tools/explore_fullgain.py: at full gain the loop is only stable with a weak coord_fc - ridge 1e-3 (the fitns
+    # weights): the reference's 8- and 4-thread runs are 7.9e-3 A apart in the FIRST pass and 140 A after eleven; ridge
+    # 1: 6.6e-4 -> 2.6e-2 A over four passes; ridge 30: 2e-5 .. 8e-5 A through eleven passes and 3.6e-4 A after 2 x 5
+    # minimiser steps - a compact trace, Rg 3.5 A).
     for spec in [x for x in os.environ.get("DMP_FULLGAIN", "").split(";") if x]:
-        fn, fm = (int(v) for v in spec.split(","))
+        fn, fm, fridge = spec.split(",")
+        fn, fm, fridge = int(fn), int(fm), float(fridge)
         name = f"fullgain_L300_N2000_n{fn}_m{fm}"
         if not want(name):
             continue
         rows300 = synth.synth_msa(300, 2000, 0)
         sd6 = dict(sd)
-        sd6["coord_fc.weight"] = fit_coord_fc(sd6, rows300, protein_like_trace(300, 0), 1e-3)
+        sd6["coord_fc.weight"] = fit_coord_fc(sd6, rows300, protein_like_trace(300, 0), fridge)
         wf6 = f"/tmp/golden_weights_{name}.pt"
         synth.save_state_dict(wf6, sd6)
         capture_case(name, rows300, fn, fm, wf6, synth.weights_checksum(sd6), stages=False, report=report,
                      store_aln=False, noise_threads=(4, 5),
-                     extra={"coord_fc": sd6["coord_fc.weight"], "ridge": np.float64(1e-3),
+                     extra={"coord_fc": sd6["coord_fc.weight"], "ridge": np.float64(fridge),
                             "coord_gru_mds_scale": np.float64(1.0),
                             "msa_seed": np.int64(0), "msa_rows": np.int64(2000)})
 
@@ -500,6 +504,37 @@ def main():
         capture_case(name, synth.synth_msa(1344, 1000, seed1344), 0, 0, wfile, wsum, stages=False, report=report,
                      store_aln=False, oracle=False,
                      extra={"msa_seed": np.int64(seed1344), "msa_rows": np.int64(1000)})
+
+    # TRAINING-SIDE SLICE: the reference's own autograd through Maxout2d of residual block 3
+    # (network.py:25-31: conv 5x5 128->512, max over channel quadruples, InstanceNorm) - what train.py:318-344 runs
+    # through every ResNet_Block.  Inputs from the Philox generator; a pre-hook on the InstanceNorm hands out the
+    # maxout output u, whose gradient (the InstanceNorm's backward of a seeded upstream gradient) is the input of
+    # dmp_block_conv5x5_maxout_bwd; expected: x.grad, lin.weight.grad (sampled + sums), lin.bias.grad.
+    if want("bwd_block3_L24"):
+        Lb = 24
+        net = RN.GRUResNet(512, 128)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net.eval()
+        blk = net.resnet[3]
+        rng = np.random.Generator(np.random.Philox(key=0xB3D))
+        x = torch.from_numpy((2.0 * rng.random((1, 128, Lb, Lb)) - 1.0).astype(np.float32) * 3.0).requires_grad_(True)
+        G = torch.from_numpy((2.0 * rng.random((1, 128, Lb, Lb)) - 1.0).astype(np.float32))
+        grabbed = {}
+
+        def pre(_m, inp):
+            inp[0].retain_grad()
+            grabbed["u"] = inp[0]
+        h = blk.layer1.norm.register_forward_pre_hook(pre)
+        out = blk.layer1(x)
+        h.remove()
+        out.backward(G)
+        bw = {"block": np.int64(3), "L": np.int64(Lb), "x": x.detach()[0].numpy(), "du": grabbed["u"].grad[0].numpy(),
+              "dx": x.grad[0].numpy(), "db": blk.layer1.lin.bias.grad.numpy(),
+              "weights_sha256": np.frombuffer(wsum.encode(), dtype=np.uint8)}
+        pack_sample(bw, "dw", blk.layer1.lin.weight.grad)
+        np.savez_compressed(os.path.join(HERE, "bwd_block3_L24.npz"), **bw)
+        report.append("bwd_block3_L24           reference autograd through Maxout2d of block 3 (x 128x24x24): |dx| max %.3e, |dw| max %.3e"
+                      % (float(x.grad.abs().max()), float(blk.layer1.lin.weight.grad.abs().max())))
 
     # known-answer vectors for the minimiser and the backbone builder on a real CA trace
     if want("kat_refine_backbone"):

@@ -263,6 +263,27 @@ def test_block_odd_sizes(st, oracle_weights, L):
     assert np.abs(out - out_ref).max() <= scale_tol(out_ref, 1e-4)
 
 
+def test_block_conv_maxout_backward_vs_reference_autograd(st_engine):
+    """SURVEY 8f.4, second slice: dmp_block_conv5x5_maxout_bwd - input, weight and bias gradients
+    of a residual block's convolution + maxout - against the reference's own autograd through Maxout2d of block 3
+    (network.py:25-31; tests/golden/make_goldens.py, bwd_block3_L24).  1e-4 of each tensor's scale."""
+    g = load_golden("bwd_block3_L24")
+    st = st_engine
+    dx, dw, db = st.conv_bwd(int(g["block"]), st.to(g["x"]), st.to(g["du"]))
+    st.eng.sync_check()
+    dx, dw, db = dx.cpu().numpy(), dw.cpu().numpy(), db.cpu().numpy()
+    assert np.abs(dx - g["dx"]).max() <= 1e-4 * np.abs(g["dx"]).max()
+    assert np.abs(db - g["db"]).max() <= 1e-4 * np.abs(g["db"]).max()
+    got = dw.ravel()[g["dw.idx"]]
+    scale = float(np.abs(g["dw.val"]).max())
+    assert np.abs(got - g["dw.val"]).max() <= 1e-4 * scale
+    assert abs(float(dw.astype(np.float64).sum()) - float(g["dw.sum"])) <= 1e-4 * scale * np.sqrt(dw.size)
+    assert abs(float((dw.astype(np.float64) ** 2).sum()) - float(g["dw.sumsq"])) <= 1e-4 * float(g["dw.sumsq"])
+    # the maxout routes each gradient to ONE channel of its quadruple: the bias gradients of a quadruple sum to the
+    # gradient mass of its maxout channel
+    assert np.abs(db.reshape(128, 4).sum(axis=1) - g["du"].reshape(128, -1).sum(axis=1)).max() <= 1e-3 * np.abs(g["du"]).sum(axis=(1, 2)).max()
+
+
 def test_head_gram_and_trunk_pass(st, pf, ocap, oracle_weights):
     x = ocap["p0.block16"]
     y = O.head(oracle_weights, x)

@@ -56,8 +56,8 @@ def fixture(name):
         g = load_golden("fitns_L300_N2000_n10_m100")
         sd = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]))
         alnmat = encode_aln(synth.synth_msa(300, int(g["msa_rows"]), int(g["msa_seed"])))
-    elif name.startswith("fullgain"):
-        g = load_golden(name if name.endswith("m0") or "_m" in name else name)
+    elif name == "fullgain":
+        g = load_golden("fullgain_L300_N2000_n10_m5")
         sd = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]))
         alnmat = encode_aln(synth.synth_msa(300, int(g["msa_rows"]), int(g["msa_seed"])))
     elif name == "pf":

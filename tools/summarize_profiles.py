@@ -1,38 +1,39 @@
 #!/usr/bin/env python
-"""Turn the rocprofv3 outputs of tools/profile_bench.sh (gpurun_out/prof_bench, gpurun_out/pmc)
-into the small tracked files under profiles/:
+"""Turn the rocprofv3 outputs of tools/profile_r04.sh (gpurun_out/prof_bench, prof_bench_f32, pmc) into the small
+tracked files under profiles/:
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r04
 
-  profiles/<tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1`
-  profiles/<tag>_conv5x5_pmc.txt          PMC counters of conv5x5_f16x3_kernel (separate --pmc passes)
-  profiles/conv5x5_pmc.json               HBM traffic per conv launch, read by bench.py ("roofline.traffic")
+  profiles/<tag>_bench_kernel_stats_f16x3.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1 --legs f16x3`
+  profiles/<tag>_bench_kernel_stats_f32.csv     the same of `--legs f32` (the exact-f32 MFMA convolution)
+  profiles/<tag>_conv5x5_pmc.txt / _f32_pmc.txt PMC counters of conv5x5_f16x3_kernel / conv5x5_maxout_kernel (separate --pmc passes)
+  profiles/conv5x5_pmc.json, conv5x5_f32_pmc.json   HBM traffic per conv launch, read by bench.py (roofline.traffic, roofline_f32.traffic)
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in
-KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so it is doubled.  The
-WRITE_SIZE unit was checked here on kernels with exactly known traffic (a 256 MiB fill reads back as
-262144 KiB, a 46.08 MB randn as 45000 KiB).
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports half the bytes of wide coalesced reads, so it is doubled.  The WRITE_SIZE unit was checked here on
+kernels with exactly known traffic (a 256 MiB fill reads back as 262144 KiB).
 """
 import collections
 import csv
+import hashlib
 import json
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
-stats = os.path.join(G, "prof_bench", "bench_kernel_stats.csv")
-if os.path.exists(stats):
-    shutil.copy(stats, os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
-    log = os.path.join(G, "prof_bench", "bench_under_rocprof.log")
-    for line in open(log):
-        if line.startswith("{"):
-            open(os.path.join(P, f"{tag}_bench_under_rocprof.json"), "w").write(line)
+for sub, leg in (("prof_bench", "f16x3"), ("prof_bench_f32", "f32")):
+    stats = os.path.join(G, sub, "bench_kernel_stats.csv")
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(P, f"{tag}_bench_kernel_stats_{leg}.csv"))
+        for line in open(os.path.join(G, sub, "bench_under_rocprof.log")):
+            if line.startswith("{"):
+                open(os.path.join(P, f"{tag}_bench_under_rocprof_{leg}.json"), "w").write(line)
 
 
 def counters(name):
@@ -45,47 +46,49 @@ def counters(name):
     return agg
 
 
-lines = []
-conv = {}
-calib = {}
-for name in ("sq1", "sq2", "fetch", "write"):
-    for kern, cs in counters(name).items():
-        for c, vals in cs.items():
-            mean = sum(vals) / len(vals)
-            if "conv5x5_f16x3_kernel" in kern:
-                conv[c] = mean
-                lines.append(f"{name:6s} {c:28s} n={len(vals):2d} mean={mean:.6g} min={min(vals):.6g} max={max(vals):.6g}")
-            elif c in ("FETCH_SIZE", "WRITE_SIZE") and ("act_pad" in kern or "vectorized_elementwise" in kern
-                                                       or "distribution" in kern):
-                calib[f"{kern[:48]} {c}"] = mean
-if conv:
-    L = 300
+L = 300
+for sfx, kernel, src, out_txt, out_json, expect in (
+        ("", "conv5x5_f16x3_kernel", "dmpfold2_amd/csrc/conv_f16.h", f"{tag}_conv5x5_pmc.txt", "conv5x5_pmc.json",
+         1444 * 4 * 8 * 25 * 8 * 3),
+        ("_f32", "conv5x5_maxout_kernel", "dmpfold2_amd/csrc/trunk.hip", f"{tag}_conv5x5_f32_pmc.txt", "conv5x5_f32_pmc.json",
+         1444 * 4 * 64 * 25 * 8)):
+    lines, conv, calib = [], {}, {}
+    for name in ("sq1", "sq2", "fetch", "write"):
+        for kern, cs in counters(name + sfx).items():
+            for c, vals in cs.items():
+                mean = sum(vals) / len(vals)
+                if kernel in kern:
+                    conv[c] = mean
+                    lines.append(f"{name:6s} {c:28s} n={len(vals):2d} mean={mean:.6g} min={min(vals):.6g} max={max(vals):.6g}")
+                elif c in ("FETCH_SIZE", "WRITE_SIZE") and ("vectorized_elementwise" in kern or "FillFunctor" in kern):
+                    calib[f"{kern[:60]} {c}"] = mean
+    if not conv:
+        print("no PMC data for", kernel)
+        continue
     mfma = conv.get("SQ_INSTS_MFMA", 0.0)
     busy = conv.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     gui = conv.get("GRBM_GUI_ACTIVE", 0.0)
     fetch_kib, write_kib = conv.get("FETCH_SIZE", 0.0), conv.get("WRITE_SIZE", 0.0)
     hbm = (2.0 * fetch_kib + write_kib) * 1024.0
+    # algorithmic bytes per launch: input activations (f16x3: two f16 pieces = 4 B per value; f32: 4 B) + weights + output
     algo = 4.0 * (128 * L * L + 512 * 128 * 25 + 128 * L * L)
-    with open(os.path.join(P, f"{tag}_conv5x5_pmc.txt"), "w") as fh:
-        fh.write("# conv5x5_f16x3_kernel (default conv path), L=300, one launch; rocprofv3 --pmc passes (tools/profile_bench.sh)\n")
+    with open(os.path.join(P, out_txt), "w") as fh:
+        fh.write(f"# {kernel}, L=300, 16 launches of one trunk pass; rocprofv3 --pmc passes (tools/profile_r04.sh)\n")
         fh.write("\n".join(lines) + "\n")
         if gui and busy:
             # GRBM_GUI_ACTIVE sums the 8 XCDs; MFMA busy cycles sum over the 1024 SIMDs
             fh.write(f"# MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE/8) = "
                      f"{busy / (1024.0 * gui / 8.0):.3f}\n")
-        fh.write(f"# SQ_INSTS_MFMA = {mfma:.0f} (expected 1444 WG * 4 waves * 8 stages * 25 taps * 8 tiles * 3 products = {1444 * 4 * 8 * 25 * 8 * 3})\n")
-        fh.write(f"# HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB = {hbm / 1e6:.1f} MB; algorithmic "
-                 f"{algo / 1e6:.1f} MB (activation pieces 46.1 + weight pieces 6.6 + out 46.1)\n")
+        fh.write(f"# SQ_INSTS_MFMA = {mfma:.0f} per launch (expected {expect})\n")
+        fh.write(f"# HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB = {hbm / 1e6:.1f} MB; algorithmic {algo / 1e6:.1f} MB\n")
         for k, v in calib.items():
             fh.write(f"# calibration: {k} = {v:.6g} KiB\n")
-    json.dump({"kernel": "conv5x5_f16x3_kernel", "L": L, "hbm_bytes_per_launch": hbm,
-               "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
-               "algorithmic_bytes_per_launch": algo,
+    json.dump({"kernel": kernel, "L": L, "hbm_bytes_per_launch": hbm, "fetch_size_kib": fetch_kib,
+               "write_size_kib": write_kib, "algorithmic_bytes_per_launch": algo,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE half-count correction",
-               "source": f"profiles/{tag}_conv5x5_pmc.txt",
+               "source": f"profiles/{out_txt}",
                # the kernel's source at the time of the PMC passes: bench.py reports whether the tree still has it
-               "kernel_source": "dmpfold2_amd/csrc/conv_f16.h",
-               "kernel_source_sha256": __import__("hashlib").sha256(
-                   open(os.path.join(ROOT, "dmpfold2_amd", "csrc", "conv_f16.h"), "rb").read()).hexdigest()},
-              open(os.path.join(P, "conv5x5_pmc.json"), "w"), indent=1)
-print(open(os.path.join(P, f"{tag}_conv5x5_pmc.txt")).read() if conv else "no PMC data")
+               "kernel_source": src,
+               "kernel_source_sha256": hashlib.sha256(open(os.path.join(ROOT, src), "rb").read()).hexdigest()},
+              open(os.path.join(P, out_json), "w"), indent=1)
+    print(open(os.path.join(P, out_txt)).read())
