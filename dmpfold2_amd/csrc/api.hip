@@ -922,7 +922,9 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   // Only the single-target entry (dmp_predict_begin) forks: a scheduler that drives several contexts has
   // other targets to fill the machine, and a second stream per context would push the process past the
   // hardware queues (with 4 engines the unused side streams alone cost 10 % of the throughput).
-  const bool fork = c->fe_side && c->fe_inv > 0;
+  // (not beside the persistent vertical GRU: that launch holds every CU, and the inverse's kernels squeezed in between
+  // its row barriers took 27 ms instead of 9 - profiles/r04_single_target_timeline.txt; one after the other then)
+  const bool fork = c->fe_side && c->fe_inv > 0 && !(c->vgru_persist && c->vgru_persist_ok);
   if (fork && !c->side_stream) {
     hipStream_t st;
     DMP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
