@@ -38,6 +38,7 @@ SIGNATURES = {
     "dmp_block_conv5x5_maxout": (_i, [_vp, _i, _fp, _i, _fp, _fp, _vp]),
     "dmp_block_norm_scse_residual": (_i, [_vp, _i, _fp, _fp, _fp, _i, _fp, _vp]),
     "dmp_block_conv5x5_maxout_bwd": (_i, [_vp, _i, _fp, _fp, _i, _fp, _fp, _fp, _vp]),
+    "dmp_block_norm_scse_residual_bwd": (_i, [_vp, _i, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_head_gram": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
     "dmp_trunk_pass": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_eigh_top8": (_i, [_vp, _fp, _i, _fp, _vp]),
@@ -50,7 +51,6 @@ SIGNATURES = {
     "dmp_predict_next_unit": (_i, [_vp]),
     "dmp_predict_group_vgru": (_i, [C.POINTER(_vp), _i]),
     "dmp_predict_group_riders": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp)]),
-    "dmp_predict_chain_issued": (_i, [_vp]),
     "dmp_predict_set_vgru_result": (_i, [_vp, _fp, _vp]),
     "dmp_predict_issue_unit": (_i, [_vp, _vp]),
     "dmp_ctx_pending": (_i, [_vp]),

@@ -284,6 +284,11 @@ static int pack_weights(dmp_ctx* c) {
       gate[q] = 1.0f / (1.0f + std::exp(-a));
     }
     if ((rc = upload(pool, bytes, &B.cse, gate))) return rc;
+    {
+      std::vector<float> fc(w1);
+      fc.insert(fc.end(), w2.begin(), w2.end());
+      if ((rc = upload(pool, bytes, &B.cse_fc, fc))) return rc;
+    }
     if ((rc = upload(pool, bytes, &B.sse_w, H[p + ".scSE.sSE.conv.weight"]))) return rc;
     B.sse_b = H[p + ".scSE.sSE.conv.bias"][0];
   }
@@ -533,6 +538,9 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "act_scaling") { *h_value = ctx->act_scaling; return DMP_OK; }
   if (k == "device_mib") { *h_value = (int)((ctx->bytes + (1 << 20) - 1) >> 20); return DMP_OK; }    // read only
   if (k == "vgru_persistent") { *h_value = ctx->vgru_persist && ctx->vgru_persist_ok; return DMP_OK; }
+  // read-only: 1 once every launch of the group chain this context leads has been issued (the scheduler hands the
+  // riders' results over from then on)
+  if (k == "chain_issued") { *h_value = ctx->vg_leader == ctx && __atomic_load_n(&ctx->vg_done_issued, __ATOMIC_ACQUIRE) ? 1 : 0; return DMP_OK; }
   if (k.rfind("act_scale_log2_block", 0) == 0) {      // read-only: log2 of the piece scale of block 1..16's input
     const int b = atoi(k.c_str() + 20);
     DMP_ARG(b >= 1 && b <= NBLOCK && ctx->W.ready, "act_scale_log2_block<k>: k in 1..16, weights finalized");
@@ -787,6 +795,14 @@ int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, cons
   CHECK_W();
   DMP_ARG(block >= 1 && block <= NBLOCK && d_x && d_du && d_dx && d_dw && d_db, "bad argument");
   return conv5x5_maxout_bwd(ctx, block, d_x, d_du, L, d_dx, d_dw, d_db, STREAM);
+}
+
+int dmp_block_norm_scse_residual_bwd(dmp_ctx* ctx, int block, const float* d_u, const float* d_dout, int L,
+                                     float* d_du, float* d_dparams, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(block >= 1 && block <= NBLOCK && d_u && d_dout && d_du && d_dparams, "bad argument");
+  return norm_scse_residual_bwd(ctx, block, d_u, d_dout, L, d_du, d_dparams, STREAM);
 }
 
 int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M, void* stream) {
@@ -1099,10 +1115,6 @@ int dmp_predict_group_riders(dmp_ctx* lead, int n, const uint8_t* const* d_msas,
   lead->fe_vgru = 1;
   lead->fe_total = 1 + lead->fe_inv + lead->fe_vgru + 1;
   return DMP_OK;
-}
-
-int dmp_predict_chain_issued(const dmp_ctx* ctx) {
-  return ctx && ctx->vg_leader == ctx && vg_done(ctx) ? 1 : 0;
 }
 
 int dmp_predict_set_vgru_result(dmp_ctx* ctx, const float* d_vout, void* event) {

@@ -74,6 +74,7 @@ struct BlockW {
   float* gamma = nullptr;  // [128]
   float* beta = nullptr;   // [128]
   float* cse = nullptr;    // [128] channel gate sigma(W2 relu(W1 beta))
+  float* cse_fc = nullptr; // [8][128] fc.0.weight, [128][8] fc.2.weight as uploaded (the backward slice, train.hip)
   float* sse_w = nullptr;  // [128]
   float sse_b = 0.f;
 };
@@ -196,7 +197,7 @@ struct dmp_ctx {
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm
-  float* bwd_ws = nullptr;     // training-side slice (trunk.hip, conv5x5_maxout_bwd): patch matrix + conv output + routed
+  float* bwd_ws = nullptr;     // training-side slice (train.hip): patch matrix + conv output + routed
   int64_t bwd_ws_floats = 0;   // gradient, allocated on first use
   float* bwd_w = nullptr;      // [512][3200] raw weights of block bwd_w_block
   int bwd_w_block = 0;
@@ -288,6 +289,8 @@ int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const dou
                               const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s, bool head = false);
 int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_du, int L, float* d_dx, float* d_dw,
                        float* d_db, hipStream_t s);
+int norm_scse_residual_bwd(dmp_ctx* c, int block, const float* d_u, const float* d_dout, int L, float* d_du,
+                           float* d_dparams, hipStream_t s);
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
                      hipStream_t s);
 int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);

@@ -878,132 +878,4 @@ int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, floa
   return DMP_OK;
 }
 
-// ---------------------------------------------------------------------------------------
-// Training-side slice (reference train.py:318-344 running autograd through network.py:25-31):
-// backward of a block's convolution + maxout,  u[g] = max_q (conv(x, W)[4g+q] + b[4g+q]).
-//   dz[4g+q] = du[g] where q is the FIRST maximal channel of the quadruple (torch.max), 0 elsewhere
-//   dW[o][c,tap] = sum_p dz[o][p] x[c][p + tap]        (wgrad: GEMM over the pixels)
-//   db[o]        = sum_p dz[o][p]
-//   dx[c][p]     = sum_{o,tap} W[o][c,tap] dz[o][p - tap]   (dgrad: GEMM + gather)
-// Parity-first form: the 25-tap patches as an explicit matrix (im2col, 3200 x L^2) and three products on the float32
-// matrix cores (gemm_f32: exact fmaf chains); the winners are recomputed with the same float32 product, so a
-// near-tie can resolve differently from the inference kernels' split-f16 sums (measure-zero for the gradients' checks).
-// Workspace (3200 + 1024) x L^2 floats, allocated on first use (this entry point is outside the inference path's
-// "no allocation after dmp_ctx_create" rule).
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bwd_im2col_kernel(const float* __restrict__ x, int L, float* __restrict__ col) {
-  const int r = blockIdx.y;                              // c * 25 + tap
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int LL = L * L;
-  if (p >= LL) return;
-  const int c = r / 25, tap = r % 25, dy = tap / 5 - 2, dx = tap % 5 - 2;
-  const int y = p / L + dy, xx = p % L + dx;
-  col[(int64_t)r * LL + p] = (y >= 0 && y < L && xx >= 0 && xx < L) ? x[(int64_t)c * LL + y * L + xx] : 0.f;
-}
-
-__global__ __launch_bounds__(256) void bwd_maxout_route_kernel(const float* __restrict__ z, const float* __restrict__ bias,
-                                                               const float* __restrict__ du, int LL,
-                                                               float* __restrict__ dz) {
-  const int g = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= LL) return;
-  int win = 0;
-  float best = z[(int64_t)(4 * g) * LL + p] + bias[4 * g];
-#pragma unroll
-  for (int q = 1; q < 4; ++q) {
-    const float v = z[(int64_t)(4 * g + q) * LL + p] + bias[4 * g + q];
-    if (v > best) { best = v; win = q; }                 // strict: the first maximal value wins, as torch.max
-  }
-  const float d = du[(int64_t)g * LL + p];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dz[(int64_t)(4 * g + q) * LL + p] = q == win ? d : 0.f;
-}
-
-__global__ __launch_bounds__(256) void bwd_bias_kernel(const float* __restrict__ dz, int LL, float* __restrict__ db) {
-  __shared__ double red[256];
-  const int o = blockIdx.x;
-  double acc = 0.0;
-  for (int p = threadIdx.x; p < LL; p += 256) acc += (double)dz[(int64_t)o * LL + p];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) db[o] = (float)red[0];
-}
-
-__global__ __launch_bounds__(256) void bwd_col2im_kernel(const float* __restrict__ dcol, int L, float* __restrict__ dx) {
-  const int c = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int LL = L * L;
-  if (p >= LL) return;
-  const int y = p / L, x = p % L;
-  float acc = 0.f;
-#pragma unroll
-  for (int tap = 0; tap < 25; ++tap) {
-    const int yy = y - (tap / 5 - 2), xx = x - (tap % 5 - 2);      // the output pixel whose patch holds (y, x) at `tap`
-    if (yy >= 0 && yy < L && xx >= 0 && xx < L) acc += dcol[(int64_t)(c * 25 + tap) * LL + yy * L + xx];
-  }
-  dx[(int64_t)c * LL + p] = acc;
-}
-
-// the block's weights as the state_dict holds them, W[o][c*25 + tap], from the exact-f32 kernel's pack
-// [split 4][chunk 64][tap 25][cc 2][m 128] (the raw tensors are not kept after dmp_weights_finalize)
-__global__ __launch_bounds__(256) void bwd_unpack_weights_kernel(const float* __restrict__ wpack, float* __restrict__ w) {
-  const int i = blockIdx.x * 256 + threadIdx.x;           // o * 3200 + c * 25 + tap
-  if (i >= 512 * 3200) return;
-  const int o = i / 3200, r = i % 3200, cch = r / 25, tap = r % 25;
-  w[i] = wpack[((((int64_t)(o >> 7) * (CW / CONV_CC) + cch / CONV_CC) * 25 + tap) * CONV_CC + cch % CONV_CC) * 128 + (o & 127)];
-}
-
-int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_du, int L, float* d_dx, float* d_dw,
-                       float* d_db, hipStream_t s) {
-  const BlockW& B = c->W.blk[block - 1];
-  const int LL = L * L;
-  const int64_t need = (int64_t)(3200 + 1024) * LL;
-  if (c->bwd_ws_floats < need) {
-    if (c->bwd_ws) (void)hipFree(c->bwd_ws);
-    c->bwd_ws = nullptr;
-    c->bwd_ws_floats = 0;
-    DMP_HIP(hipMalloc((void**)&c->bwd_ws, sizeof(float) * (size_t)need));
-    c->bwd_ws_floats = need;
-  }
-  if (!c->bwd_w) {                                       // the block weights as uploaded (512 x 3200), once per context
-    DMP_HIP(hipMalloc((void**)&c->bwd_w, sizeof(float) * 512 * 3200));
-    c->bwd_w_block = 0;
-  }
-  if (c->bwd_w_block != block) {
-    hipLaunchKernelGGL(bwd_unpack_weights_kernel, dim3(cdiv(512 * 3200, 256)), dim3(256), 0, s, B.wpack, c->bwd_w);
-    DMP_LAUNCH_CHECK();
-    c->bwd_w_block = block;
-  }
-  float* col = c->bwd_ws;
-  float* z = col + (int64_t)3200 * LL;
-  float* dz = z + (int64_t)512 * LL;
-  hipLaunchKernelGGL(bwd_im2col_kernel, dim3(cdiv(LL, 256), 3200), dim3(256), 0, s, d_x, L, col);
-  DMP_LAUNCH_CHECK();
-  GemmArgs g{};
-  int rc;
-  // z = W col
-  g.A = c->bwd_w; g.sam = 3200; g.sak = 1; g.B = col; g.sbk = LL; g.sbn = 1; g.C = z; g.ldc = LL;
-  g.M = 512; g.N = LL; g.K = 3200; g.alpha = 1.f; g.beta = 0.f; g.bias_n = nullptr;
-  if ((rc = gemm_f32(g, s))) return rc;
-  hipLaunchKernelGGL(bwd_maxout_route_kernel, dim3(cdiv(LL, 256), 128), dim3(256), 0, s, z, B.bias, d_du, LL, dz);
-  DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bwd_bias_kernel, dim3(512), dim3(256), 0, s, dz, LL, d_db);
-  DMP_LAUNCH_CHECK();
-  // dW = dz col^T
-  g.A = dz; g.sam = LL; g.sak = 1; g.B = col; g.sbk = 1; g.sbn = LL; g.C = d_dw; g.ldc = 3200;
-  g.M = 512; g.N = 3200; g.K = LL;
-  if ((rc = gemm_f32(g, s))) return rc;
-  // dcol = W^T dz (over the patch matrix, which the weight gradient no longer needs)
-  g.A = c->bwd_w; g.sam = 1; g.sak = 3200; g.B = dz; g.sbk = LL; g.sbn = 1; g.C = col; g.ldc = LL;
-  g.M = 3200; g.N = LL; g.K = 512;
-  if ((rc = gemm_f32(g, s))) return rc;
-  hipLaunchKernelGGL(bwd_col2im_kernel, dim3(cdiv(LL, 256), 128), dim3(256), 0, s, col, L, d_dx);
-  DMP_LAUNCH_CHECK();
-  return DMP_OK;
-}
-
 }  // namespace dmp

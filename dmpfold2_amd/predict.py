@@ -592,7 +592,7 @@ class Pipeline:
                         break
                 _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
                 progressed = True
-                if self._rider_wait[s] is not None and lib.dmp_predict_chain_issued(e.ctx):
+                if self._rider_wait[s] is not None and e.get_option("chain_issued"):
                     # the riders' results are behind this point of the leader's stream
                     jobs, outs = self._rider_wait[s]
                     self._rider_wait[s] = None

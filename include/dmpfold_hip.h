@@ -202,6 +202,15 @@ int dmp_block_norm_scse_residual(dmp_ctx* ctx, int block, const float* d_u,
  * floats) on first use. */
 int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, const float* d_du, int L, float* d_dx,
                                  float* d_dw, float* d_db, void* stream);
+/* ... and of its second half - InstanceNorm (network.py:32), scSE (network.py:36-83) and the residual add
+ * (network.py:99-101).  d_u: the maxout output the forward normalised (128 x L x L; its statistics are recomputed),
+ * d_dout: gradient w.r.t. the block's output.  Outputs: d_du (128 x L x L) = gradient w.r.t. the maxout output (the
+ * d_du argument of the entry point above) and d_dparams (2433 floats, overwritten): layer1.norm.weight 128,
+ * layer1.norm.bias 128, scSE.cSE.fc.0.weight 8 x 128, scSE.cSE.fc.2.weight 128 x 8, scSE.sSE.conv.weight 128,
+ * scSE.sSE.conv.bias 1.  The residual branch is the identity: the gradient w.r.t. the block's input is d_dx of the
+ * first half plus d_dout (the caller's add).  Evaluation-mode block (the dropouts of network.py:96-97 are identities). */
+int dmp_block_norm_scse_residual_bwd(dmp_ctx* ctx, int block, const float* d_u, const float* d_dout, int L,
+                                     float* d_du, float* d_dparams, void* stream);
 /* Head 1x1 conv (network.py:207) + network.py:237-246: d_conf (L) = row means of channel 1,
  * d_M (L x L) = Gram matrix 0.5*(dm_0j^2 + dm_i0^2 - dm_ij^2) of dm = |sym(channel 0)|. */
 int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M,
@@ -269,13 +278,12 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n);
  * computed in the same launch chain as the group led by `lead` (members + riders <= 8; the chain's fixed cost per
  * alignment row - launch boundary, cold L2s - is shared by twice as many columns), their results (L_i x 512 each)
  * written to d_outs[i].  Call once, right after dmp_predict_group_vgru (a group of one is allowed), before the
- * leader issues a unit.  dmp_predict_chain_issued(lead) answers
+ * leader issues a unit.  The leader's read-only option "chain_issued" answers
  * 1 once the chain has been enqueued to its end on the stream of the leader's units: an event recorded on that
  * stream from then on is behind the riders' results, which go to their predictions through
  * dmp_predict_set_vgru_result.  Every result is bit-identical to the alignment's own chain. */
 int dmp_predict_group_riders(dmp_ctx* lead, int n, const uint8_t* const* d_msas, const int* Ns, const int* Ls,
                              float* const* d_outs);
-int dmp_predict_chain_issued(const dmp_ctx* ctx);
 /* The vertical GRU of this prediction has been (or is being) computed ahead of time by dmp_gru_vertical /
  * dmp_gru_vertical_group on the same alignment: d_vout (L x 512, device) is its result, `event` (hipEvent_t or
  * NULL) was recorded behind it.  Call right after dmp_predict_begin_units, before any unit is issued: the

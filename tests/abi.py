@@ -112,6 +112,12 @@ class Stages:
         self.call("dmp_block_conv5x5_maxout_bwd", block, x, du, L, dx, dw, db)
         return dx, dw, db
 
+    def norm_bwd(self, block, u, dout):
+        L = u.shape[-1]
+        du, dparams = self.f32(128, L, L), self.f32(2433)
+        self.call("dmp_block_norm_scse_residual_bwd", block, u, dout, L, du, dparams)
+        return du, dparams
+
     def head_gram(self, x):
         L = x.shape[-1]
         conf, M = self.f32(L), self.f32(L, L)

@@ -536,6 +536,43 @@ def main():
         report.append("bwd_block3_L24           reference autograd through Maxout2d of block 3 (x 128x24x24): |dx| max %.3e, |dw| max %.3e"
                       % (float(x.grad.abs().max()), float(blk.layer1.lin.weight.grad.abs().max())))
 
+    # ... and through the WHOLE ResNet_Block 3 (network.py:85-103, evaluation mode: the dropouts are identities):
+    # Maxout2d -> scSE -> + residual.  u (the maxout output before the InstanceNorm) and its gradient are the interface
+    # between dmp_block_norm_scse_residual_bwd and dmp_block_conv5x5_maxout_bwd; x.grad includes the residual branch.
+    if want("bwd_block3_full_L24"):
+        Lb = 24
+        net = RN.GRUResNet(512, 128)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net.eval()
+        blk = net.resnet[3]
+        rng = np.random.Generator(np.random.Philox(key=0xB3F))
+        x = torch.from_numpy((2.0 * rng.random((1, 128, Lb, Lb)) - 1.0).astype(np.float32) * 3.0).requires_grad_(True)
+        G = torch.from_numpy((2.0 * rng.random((1, 128, Lb, Lb)) - 1.0).astype(np.float32))
+        grabbed = {}
+
+        def pre2(_m, inp):
+            inp[0].retain_grad()
+            grabbed["u"] = inp[0]
+        h = blk.layer1.norm.register_forward_pre_hook(pre2)
+        for q in blk.parameters():
+            q.grad = None
+        out = blk(x)
+        h.remove()
+        out.backward(G)
+        u = grabbed["u"]
+        bw = {"block": np.int64(3), "L": np.int64(Lb), "x": x.detach()[0].numpy(), "dout": G[0].numpy(),
+              "u": u.detach()[0].numpy(), "du": u.grad[0].numpy(), "dx": x.grad[0].numpy(),
+              "db": blk.layer1.lin.bias.grad.numpy(),
+              "dgamma": blk.layer1.norm.weight.grad.numpy(), "dbeta": blk.layer1.norm.bias.grad.numpy(),
+              "dfc0": blk.scSE.cSE.fc[0].weight.grad.numpy(), "dfc2": blk.scSE.cSE.fc[2].weight.grad.numpy(),
+              "dsse_w": blk.scSE.sSE.conv.weight.grad.numpy().reshape(-1), "dsse_b": blk.scSE.sSE.conv.bias.grad.numpy(),
+              "weights_sha256": np.frombuffer(wsum.encode(), dtype=np.uint8)}
+        pack_sample(bw, "dw", blk.layer1.lin.weight.grad)
+        np.savez_compressed(os.path.join(HERE, "bwd_block3_full_L24.npz"), **bw)
+        report.append("bwd_block3_full_L24      reference autograd through ResNet_Block 3, eval mode (x 128x24x24): |dx| max %.3e, |du| max %.3e, |dgamma| max %.3e, |dfc0| max %.3e"
+                      % (float(x.grad.abs().max()), float(u.grad.abs().max()),
+                         float(blk.layer1.norm.weight.grad.abs().max()), float(blk.scSE.cSE.fc[0].weight.grad.abs().max())))
+
     # known-answer vectors for the minimiser and the backbone builder on a real CA trace
     if want("kat_refine_backbone"):
         t = torch.from_numpy(ca)

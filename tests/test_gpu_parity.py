@@ -284,6 +284,54 @@ def test_block_conv_maxout_backward_vs_reference_autograd(st_engine):
     assert np.abs(db.reshape(128, 4).sum(axis=1) - g["du"].reshape(128, -1).sum(axis=1)).max() <= 1e-3 * np.abs(g["du"]).sum(axis=(1, 2)).max()
 
 
+def test_block_backward_vs_reference_autograd_through_the_whole_block(st_engine):
+    """SURVEY 8f.4, second slice, both halves: dmp_block_norm_scse_residual_bwd (InstanceNorm +
+    scSE + residual, network.py:32, 36-83, 99-101) chained into dmp_block_conv5x5_maxout_bwd against the reference's
+    autograd through ResNet_Block 3 in evaluation mode (tests/golden/make_goldens.py, bwd_block3_full_L24): every
+    parameter gradient of the block, the gradient at the interface (the maxout output) and the gradient of the
+    block's input including the residual branch.  1e-4 of each tensor's scale, in both convolution modes (the
+    backward is float32 throughout; the mode must not matter)."""
+    g = load_golden("bwd_block3_full_L24")
+    st = st_engine
+    blk = int(g["block"])
+
+    def close(got, want, tol=1e-4):
+        want = np.asarray(want, dtype=np.float32)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= tol * max(np.abs(want).max(), 1e-30), (np.abs(got - want).max(), np.abs(want).max())
+
+    first = None
+    for mode in (0, 1):
+        st.eng.set_option("conv_mode", mode)
+        try:
+            du, dp = st.norm_bwd(blk, st.to(g["u"]), st.to(g["dout"]))
+            dx, dw, db = st.conv_bwd(blk, st.to(g["x"]), du)
+            st.eng.sync_check()
+        finally:
+            st.eng.set_option("conv_mode", 0)
+        du, dp, dx, dw, db = (t.cpu().numpy() for t in (du, dp, dx, dw, db))
+        close(du, g["du"])
+        close(dp[0:128], g["dgamma"])
+        close(dp[128:256], g["dbeta"])
+        close(dp[256:256 + 1024].reshape(8, 128), g["dfc0"])
+        close(dp[1280:1280 + 1024].reshape(128, 8), g["dfc2"])
+        close(dp[2304:2432], g["dsse_w"])
+        close(dp[2432:2433], g["dsse_b"])
+        close(dx + g["dout"], g["dx"])                      # the residual branch is the identity
+        close(db, g["db"])
+        scale = float(np.abs(g["dw.val"]).max())
+        assert np.abs(dw.ravel()[g["dw.idx"]] - g["dw.val"]).max() <= 1e-4 * scale
+        assert abs(float((dw.astype(np.float64) ** 2).sum()) - float(g["dw.sumsq"])) <= 1e-4 * float(g["dw.sumsq"])
+        if first is None:
+            first = (du, dp, dx)
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(first, (du, dp, dx)))
+    # InstanceNorm's backward removes the mean and the uh-component of the gradient per channel
+    uh = g["u"] - g["u"].mean(axis=(1, 2), keepdims=True)
+    assert np.abs(du.sum(axis=(1, 2))).max() <= 1e-3 * np.abs(du).sum(axis=(1, 2)).max()
+    assert np.abs((du * uh).sum(axis=(1, 2))).max() <= 1e-3 * (np.abs(du) * np.abs(uh)).sum(axis=(1, 2)).max()
+
+
 def test_head_gram_and_trunk_pass(st, pf, ocap, oracle_weights):
     x = ocap["p0.block16"]
     y = O.head(oracle_weights, x)
