@@ -437,10 +437,9 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(colmean, D);
   A_(xc, N * D);
   A_(cov, D * D);
-  A_(gj_p, GJ_NB * GJ_NB);
-  A_(gj_r, GJ_NB * D);
-  A_(gj_c, (int64_t)round_up((int)D, GJ_NB) * GJ_NB);
-  A_(gj_rt, (int64_t)round_up((int)D, GJ_NB) * GJ_NB);
+  A_(gj_p, 2 * GJ_NB * GJ_NB);                                    // two sets: the look-ahead prepares step k+1
+  A_(gj_c, 2 * (int64_t)round_up((int)D, GJ_NB) * GJ_NB);         // beside step k's trailing update (dca.hip)
+  A_(gj_rt, 2 * (int64_t)round_up((int)D, GJ_NB) * GJ_NB);
   A_(contacts, LL);
   A_(x3, LL);
   A_(apc_sums, 2 * L + 1);
@@ -499,6 +498,8 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
     c->unit_ev[i] = (void*)e;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
     c->side_ev[i] = (void*)e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dmp_ctx_destroy(c); return DMP_ERR_HIP; }
+    c->gj_ev[i] = (void*)e;
   }
   {
     hipEvent_t e;
@@ -518,6 +519,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "tridiag_cluster") { ctx->tridiag_cluster = value ? 1 : 0; return DMP_OK; }
   if (k == "cluster_local") { ctx->cluster_local = value ? 1 : 0; return DMP_OK; }
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
+  if (k == "gj_lookahead") { DMP_ARG(value >= 0 && value <= 2, "gj_lookahead must be 0, 1 or 2"); ctx->gj_lookahead = value; return DMP_OK; }
   if (k == "gj_diag_groups") { DMP_ARG(value == 2 || value == 4 || value == 8, "gj_diag_groups must be 2, 4 or 8"); ctx->gj_diag_groups = value; return DMP_OK; }
   if (k == "act_scaling") { ctx->act_scaling = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_persistent") { ctx->vgru_persist = value ? 1 : 0; return DMP_OK; }
@@ -554,6 +556,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "cluster_local") { *h_value = ctx->cluster_local; return DMP_OK; }
   if (k == "refine_single") { *h_value = ctx->refine_single; return DMP_OK; }
   if (k == "gj_diag_groups") { *h_value = ctx->gj_diag_groups; return DMP_OK; }
+  if (k == "gj_lookahead") { *h_value = ctx->gj_lookahead; return DMP_OK; }
   set_error("unknown option %s", name);
   return DMP_ERR_ARG;
 }
@@ -580,6 +583,8 @@ void dmp_ctx_destroy(dmp_ctx* c) {
   for (void* e : c->unit_ev)
     if (e) (void)hipEventDestroy((hipEvent_t)e);
   for (void* e : c->side_ev)
+    if (e) (void)hipEventDestroy((hipEvent_t)e);
+  for (void* e : c->gj_ev)
     if (e) (void)hipEventDestroy((hipEvent_t)e);
   if (c->vg_done_ev) (void)hipEventDestroy((hipEvent_t)c->vg_done_ev);
   if (c->side_stream) (void)hipStreamDestroy((hipStream_t)c->side_stream);
@@ -686,10 +691,29 @@ int dmp_cov_build(dmp_ctx* ctx, const uint8_t* d_msa, const float* d_w, int N, i
   return cov_build(ctx, d_msa, d_w, N, L, d_cov, STREAM);
 }
 
+// the context's second stream (created on first use): the look-ahead of the inverse where one prediction has the
+// device to itself, the covariance features beside the launch-per-row vertical GRU
+static int side_stream_of(dmp_ctx* c, hipStream_t* out) {
+  if (!c->side_stream) {
+    // highest priority: its kernels are small and on the critical path (the look-ahead's one-workgroup sweep must not
+    // queue behind the 1200 workgroups of the trailing update it runs beside)
+    int least = 0, greatest = 0;
+    DMP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t st;
+    DMP_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+    c->side_stream = (void*)st;
+  }
+  *out = (hipStream_t)c->side_stream;
+  return DMP_OK;
+}
+
 int dmp_spd_inverse(dmp_ctx* ctx, float* d_A, int D, void* stream) {
   DMP_ARG(ctx && d_A && D >= 1, "bad argument");
   if (D > NS * ctx->max_L) { set_error("D=%d exceeds capacity %d", D, NS * ctx->max_L); return DMP_ERR_CAPACITY; }
-  return spd_inverse(ctx, d_A, D, STREAM);
+  hipStream_t la = nullptr;
+  int rc;
+  if (ctx->gj_lookahead && (rc = side_stream_of(ctx, &la))) return rc;
+  return spd_inverse(ctx, d_A, D, STREAM, la);
 }
 
 int dmp_dca_contacts(dmp_ctx* ctx, const float* d_inv, int L, float* d_contacts, void* stream) {
@@ -708,7 +732,9 @@ int dmp_dca_features(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_
   int rc;
   if ((rc = msa_weights(ctx, d_msa, N, L, ctx->w, STREAM))) return rc;
   if ((rc = cov_build(ctx, d_msa, ctx->w, N, L, ctx->cov, STREAM))) return rc;
-  if ((rc = spd_inverse(ctx, ctx->cov, NS * L, STREAM))) return rc;
+  hipStream_t la = nullptr;
+  if (ctx->gj_lookahead && (rc = side_stream_of(ctx, &la))) return rc;
+  if ((rc = spd_inverse(ctx, ctx->cov, NS * L, STREAM, la))) return rc;
   if ((rc = dca_contacts(ctx, ctx->cov, L, ctx->contacts, STREAM))) return rc;
   return dca_features(ctx->cov, ctx->contacts, L, d_out, STREAM);
 }
@@ -941,14 +967,14 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
   // (not beside the persistent vertical GRU: that launch holds every CU, and the inverse's kernels squeezed in between
   // its row barriers took 27 ms instead of 9 - profiles/r04_single_target_timeline.txt; one after the other then)
   const bool fork = c->fe_side && c->fe_inv > 0 && !(c->vgru_persist && c->vgru_persist_ok);
-  if (fork && !c->side_stream) {
-    hipStream_t st;
-    DMP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    c->side_stream = (void*)st;
-  }
-  hipStream_t side = fork ? (hipStream_t)c->side_stream : s;
-  hipStream_t used = s;
+  // where the front end does not fork, a single prediction's inverse uses the second stream for its look-ahead
+  // (spd_inverse_steps): the next step's one-workgroup sweep and panels beside this step's trailing update
+  const bool ahead = c->fe_side && !fork && c->gj_lookahead && c->fe_inv > 0;
+  hipStream_t side = s, la = nullptr;
   int rc = DMP_OK;
+  if (fork && (rc = side_stream_of(c, &side))) return rc;
+  if (ahead && (rc = side_stream_of(c, &la))) return rc;
+  hipStream_t used = s;
   if (u == 0) {
     // the fault word of the previous prediction was latched by its dmp_predict_end
     DMP_HIP(hipMemsetAsync(c->seq_abort, 0, sizeof(int), s));
@@ -972,7 +998,7 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
     else { inv = c->fe_inv > m; j = m + (k - 2 * m); }
     if (inv) {
       used = side;
-      rc = spd_inverse_steps(c, c->cov, NS * L, j * FE_INV_BLOCKS, (j + 1) * FE_INV_BLOCKS, side);
+      rc = spd_inverse_steps(c, c->cov, NS * L, j * c->fe_inv_blocks, (j + 1) * c->fe_inv_blocks, side, la);
       if (!rc && j == c->fe_inv - 1) {
         rc = dca_contacts(c, c->cov, L, c->contacts, side);
         if (!rc && fork) DMP_HIP(hipEventRecord((hipEvent_t)c->side_ev[1], side));
@@ -1040,6 +1066,7 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
   c->run_template = d_template_ca;
   c->fe_next = 0;
   c->fe_side = false;
+  c->fe_inv_blocks = FE_INV_BLOCKS;
   c->fe_inv = N > 1 ? cdiv(cdiv(NS * L, GJ_NB), FE_INV_BLOCKS) : 0;
   // the vertical GRU in units of 128 rows (launch-per-row form: one graph replay each) - or, as the persistent launch,
   // as ONE unit: every launch of that form loads the CUs' weight slices first
@@ -1051,7 +1078,15 @@ int dmp_predict_begin_units(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, co
 static int predict_begin(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, const float* d_template_ca,
                          int Lt, int nloops, int refine_steps, void* stream) {
   int rc = dmp_predict_begin_units(ctx, d_msa, N, L, d_template_ca, Lt, nloops, refine_steps);
-  if (!rc) ctx->fe_side = true;
+  if (!rc) {
+    ctx->fe_side = true;
+    if (ctx->fe_inv > 0 && ctx->gj_lookahead && ctx->vgru_persist && ctx->vgru_persist_ok) {
+      // the whole inverse as one unit: its look-ahead does not reach across unit boundaries
+      ctx->fe_inv_blocks = cdiv(NS * L, GJ_NB);
+      ctx->fe_inv = 1;
+      ctx->fe_total = 1 + ctx->fe_inv + ctx->fe_vgru + 1;
+    }
+  }
   while (!rc && ctx->fe_next < ctx->fe_total) rc = issue_front_end_unit(ctx, STREAM);
   return rc;
 }

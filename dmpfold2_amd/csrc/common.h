@@ -136,8 +136,11 @@ struct dmp_ctx {
   float* colmean = nullptr; // [21L]
   float* xc = nullptr;      // [N][21L]
   float* cov = nullptr;     // [D][D]
-  float *gj_p = nullptr, *gj_r = nullptr;   // inverse of the diagonal block, row panel P A_k,:
+  float* gj_p = nullptr;                    // inverse of the diagonal block (two sets of each: step parity)
   float *gj_c = nullptr, *gj_rt = nullptr;  // column / row panels as k quads [32][Dp][4] (dca.hip)
+  void* gj_ev[2] = {nullptr, nullptr};      // look-ahead fork / join of the inverse (spd_inverse_steps)
+  int gj_lookahead = 1;                     // option: the next step's sweep and panels beside the trailing update (0 off, 1 from 64 tile rows on, 2 always)
+  int fe_inv_blocks = 6;                    // block steps per front-end unit of this prediction
   float* contacts = nullptr;  // [L][L]
   float* x3 = nullptr;
   double* apc_sums = nullptr;  // [2L+1]
@@ -257,9 +260,10 @@ int msa_weights(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_w, hipS
 int cov_build(dmp_ctx* c, const uint8_t* d_msa, const float* d_w, int N, int L, float* d_cov,
               hipStream_t s);
 int trunk_kernel_attrs(dmp_ctx* c);   // once per device, at context creation
-int spd_inverse(dmp_ctx* c, float* d_A, int D, hipStream_t s);
+int spd_inverse(dmp_ctx* c, float* d_A, int D, hipStream_t s, hipStream_t la = nullptr);
 // block steps [blk_lo, blk_hi) of the in-place inverse (GJ_NB columns each); all of them = spd_inverse
-int spd_inverse_steps(dmp_ctx* c, float* d_A, int D, int blk_lo, int blk_hi, hipStream_t s);
+// (`la`: a second stream for the look-ahead, or null)
+int spd_inverse_steps(dmp_ctx* c, float* d_A, int D, int blk_lo, int blk_hi, hipStream_t s, hipStream_t la = nullptr);
 int dca_contacts(dmp_ctx* c, const float* d_inv, int L, float* d_contacts, hipStream_t s);
 int dca_features(const float* d_inv, const float* d_contacts, int L, float* d_out, hipStream_t s);
 // gru.hip

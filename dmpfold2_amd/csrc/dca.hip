@@ -162,45 +162,107 @@ __global__ __launch_bounds__(128 * NH) void gj_diag_kernel(const float* __restri
   }
 }
 
-// Panels of a block step in the layout the trailing-update kernel loads with 16 bytes per lane:
-//   CT[k/4][i][4] = A[i][k0+k]  (column panel; zero for rows i inside the block and for k >= bs)
-//   RT[k/4][j][4] = R[k][j]     (row panel P A_k,: ; inside the block columns: P[k][j-k0], which makes
-//                                the trailing update of a zeroed block column produce -C P)
-// grid: Dp/64 blocks (64 rows / columns each)   block: 256
-__global__ __launch_bounds__(256) void gj_panels_kernel(const float* __restrict__ A, int D, int Dp, int k0,
-                                                        int bs, const float* __restrict__ P,
-                                                        const float* __restrict__ R,
-                                                        float4* __restrict__ CT, float4* __restrict__ RT) {
-  __shared__ float tile[64][GJ_NB + 1];
-  const int i0 = blockIdx.x * 64, tid = threadIdx.x;
-  for (int r = 0; r < 32; ++r) {                      // coalesced rows of the column panel
-    const int row = 2 * r + (tid >> 7), col = tid & 127, i = i0 + row;
-    const bool inblk = (i >= k0 && i < k0 + bs);
-    tile[row][col] = (i < D && col < bs && !inblk) ? A[(int64_t)i * D + k0 + col] : 0.f;
+typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
+
+// Everything of a block step between the diagonal block's inverse P and the trailing update, for one strip of 64
+// matrix rows / columns per workgroup (round 4: four launches before - the refresh of the stale upper triangle, the
+// row-panel GEMM, the panel re-layout and the write-back - each reading what the one before had just written):
+//   * the step's "cross" is read from the LOWER triangle only (the upper one is stale between the first and the last
+//     step, section comment of gj_trailing_kernel), with the sign rule M_ij = t_i t_j M_ji:
+//       strip below the block:   C[i][c] = A[i][k0+c],               S[c][i] = A[k0+c][i] =  A[i][k0+c]
+//       strip left of / above:   S[c][j] = A[k0+c][j] (lower),       C[j][c] = A[j][k0+c] = -A[k0+c][j]
+//       strip inside the block:  C = 0,  the row panel there is P itself
+//   * R[:, strip] = P S on the f32 matrix cores - the k pairing and order of gemm_kernel (lane half = k parity, k
+//     ascending), which computed this product in rounds 1-3: the same bits
+//   * CT / RT = the panels as k quads for the trailing kernel's 16-byte loads:
+//       CT[k/4][i][4] = C[i][k] (zero for rows inside the block and for k >= bs),  RT[k/4][j][4] = R[k][j]
+//   * A_k,: = R left of the block (the lower triangle's part of the row panel), A_kk = P
+// grid: Dp / 64 strips   block: 256 (wave w = rows 32w .. 32w+31 of R)   LDS: P^T 128 x 129 + S 128 x 65 floats
+constexpr int GJ_PP = GJ_NB + 1, GJ_SP = 64 + 1;       // odd pitches: the transposing stores and the reads are conflict-free
+constexpr int GJ_CROSS_LDS = (GJ_NB * GJ_PP + GJ_NB * GJ_SP) * 4;
+__global__ __launch_bounds__(256) void gj_cross_kernel(float* __restrict__ A, int D, int Dp, int k0, int bs,
+                                                       const float* __restrict__ P, float4* __restrict__ CT,
+                                                       float4* __restrict__ RT) {
+  extern __shared__ __attribute__((aligned(16))) float gj_smem[];
+  float* Ps = gj_smem;                                  // Ps[c][r] = P[r][c]
+  float* Ss = gj_smem + GJ_NB * GJ_PP;                  // Ss[c][x] = S[c][o + x]
+  const int o = blockIdx.x * 64, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool inblk = (o >= k0 && o < k0 + GJ_NB), above = (o < k0);
+  if (inblk) {
+    // row panel = P, column panel = 0, A_kk = P (its first 64 or last 64 columns)
+    const int x = tid & 63, j = o - k0 + x, gi = o + x;
+    for (int q = tid >> 6; q < 32; q += 4) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 4 * q + e;
+        v[e] = (gi < D && k < bs) ? P[k * GJ_NB + j] : 0.f;
+        if (gi < D && k < bs) A[(int64_t)(k0 + k) * D + gi] = v[e];
+      }
+      RT[(int64_t)q * Dp + gi] = make_float4(v[0], v[1], v[2], v[3]);
+      CT[(int64_t)q * Dp + gi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  for (int it = 0; it < 64; ++it) {                     // P, coalesced along its rows
+    const int r = 2 * it + (tid >> 7), c = tid & 127;
+    Ps[c * GJ_PP + r] = P[r * GJ_NB + c];
+  }
+  if (above) {
+    for (int it = 0; it < 32; ++it) {                   // rows of the block, coalesced along the strip
+      const int c = 4 * it + (tid >> 6), x = tid & 63;
+      Ss[c * GJ_SP + x] = (c < bs) ? A[(int64_t)(k0 + c) * D + o + x] : 0.f;
+    }
+  } else {
+    for (int it = 0; it < 32; ++it) {                   // rows of the strip, coalesced along the block's columns
+      const int x = 2 * it + (tid >> 7), c = tid & 127;
+      Ss[c * GJ_SP + x] = (o + x < D && c < bs) ? A[(int64_t)(o + x) * D + k0 + c] : 0.f;
+    }
   }
   __syncthreads();
-  const int i = tid & 63;
-  const int gi = i0 + i;
-  const bool inblk = (gi >= k0 && gi < k0 + bs);
-  for (int it = 0; it < 8; ++it) {
-    const int q = (tid >> 6) + 4 * it;
-    CT[(int64_t)q * Dp + gi] = make_float4(tile[i][4 * q], tile[i][4 * q + 1], tile[i][4 * q + 2], tile[i][4 * q + 3]);
-    float v[4];
+  {
+    const int x = tid & 63, gi = o + x;
+    const float sgn = above ? -1.f : 1.f;
+    for (int q = tid >> 6; q < 32; q += 4)
+      CT[(int64_t)q * Dp + gi] = make_float4(sgn * Ss[(4 * q) * GJ_SP + x], sgn * Ss[(4 * q + 1) * GJ_SP + x],
+                                             sgn * Ss[(4 * q + 2) * GJ_SP + x], sgn * Ss[(4 * q + 3) * GJ_SP + x]);
+  }
+  const int kk = lane >> 5, li = lane & 31;
+  gj_f32x16 acc[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = 4 * q + e;
-      v[e] = (gi < D && k < bs) ? (inblk ? P[k * GJ_NB + (gi - k0)] : R[(int64_t)k * D + gi]) : 0.f;
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < GJ_NB; k += 2) {
+    const float a = Ps[(k + kk) * GJ_PP + 32 * wave + li];
+    const float b0 = Ss[(k + kk) * GJ_SP + li], b1 = Ss[(k + kk) * GJ_SP + 32 + li];
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gi = o + 32 * j + li;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q = 8 * wave + 2 * g + kk;              // rows 4q .. 4q+3 of R
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (gi < D && 4 * q + e < bs) ? acc[j][4 * g + e] : 0.f;
+        if (above && 4 * q + e < bs) A[(int64_t)(k0 + 4 * q + e) * D + gi] = v[e];
+      }
+      RT[(int64_t)q * Dp + gi] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    RT[(int64_t)q * Dp + gi] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
-typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
 
 // Trailing update of a block step on the f32 matrix cores (exact: an MFMA chain is an fmaf chain):
 //   A[i][j] <- A[i][j] - sum_k C[i][k] R[k][j]     outside the block column,
 //   A[i][j] <-         - sum_k C[i][k] P[k][j-k0]  inside it (the old values are the panel C itself),
-// rows inside the block are left to gj_writeback_kernel.  K = 128; a workgroup owns a 128 x 128 tile
+// rows inside the block are left to gj_cross_kernel.  K = 128; a workgroup owns a 128 x 128 tile
 // (wave = 64 x 64 = 2 x 2 MFMA blocks), operands come straight from the L2-resident panels with one
 // 16-byte load per lane and k quad (MFMA e of an octet pairs k = 8o+e with 8o+4+e: the two lane
 // halves load consecutive quads).
@@ -208,41 +270,63 @@ typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
 // 224 us for the two updates this replaces).  Knobs that measured the same or worse: deeper source-level
 // prefetch (the compiler schedules the loads itself; pinning them with scheduling barriers: 150-240
 // us), register budgets for 3-5 waves per SIMD (165 us), reading the tile before the MFMA chain
-// (168 us).  A CU pulls 64 KB of panel per wave and tile from L2; sharing the panels
-// through LDS is the next step.
-// grid: (Dp/128)^2 blocks, row-block major   block: 256
+// (168 us), the panels through LDS (round 3: 11.1-12.1 against 10.8 ms per inverse).
+//
+// Gauss-Jordan on a symmetric matrix keeps M_ij = t_i t_j M_ji with t = -1 for processed blocks and +1
+// otherwise, so only the tiles on and below the diagonal are computed and (round 3) they are not mirrored into the
+// upper triangle at every block step (80 of the 240 MB a step moved at D = 6300): the upper triangle goes stale,
+// gj_cross_kernel forms a step's panels from the lower one, and gj_mirror_kernel rebuilds the upper triangle once at
+// the end.  The values used are the ones the mirrored matrix held: results are unchanged bit for bit.
+//
+// PHASE (round 4, look-ahead): 0 = every tile of the step; 1 = only the tiles the NEXT step's diagonal inverse and
+// panels read - block column kb+1 from the diagonal down and block row kb+1 left of it; 2 = all the others.  1 then 2
+// is 0 tile by tile, and between them the next step's gj_diag_kernel / gj_cross_kernel run on a second stream beside
+// phase 2 (spd_inverse_steps).
+// grid: PHASE 1: 4 Dp/128 workgroups of ONE wave (64 x 64 each: the Dp/128 tiles are on the critical path, as one-wave
+// workgroups they take a third of the time); else (Dp/128)(Dp/128 + 1)/2 lower-triangle tiles, row-block major, block 256
+template <int PHASE>
 __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__ A, int D, int Dp, int k0,
-                                                                   const float4* __restrict__ CT,
-                                                                   const float4* __restrict__ RT) {
-  const int nt = Dp >> 7;
-  const int tm = blockIdx.x / nt, tn = blockIdx.x % nt, kb = k0 >> 7;
+                                                             const float4* __restrict__ CT,
+                                                             const float4* __restrict__ RT) {
+  const int nt = Dp >> 7, kb = k0 >> 7, nb = kb + 1;
+  int tm, tn;
+  if constexpr (PHASE == 1) {
+    const int t = blockIdx.x >> 2;                        // one-wave workgroups: four to a tile
+    if (t < nt - nb) { tm = nb + t; tn = nb; }
+    else { tm = nb; tn = t - (nt - nb); }
+  } else {
+    const int t = blockIdx.x;
+    tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;            // (the float square root may be one off either way)
+    while (tm * (tm + 1) / 2 > t) --tm;
+    tn = t - tm * (tm + 1) / 2;
+    if (PHASE == 2 && (tm == nb || tn == nb)) return;
+  }
   if (tm == kb) return;
-  // Gauss-Jordan on a symmetric matrix keeps M_ij = t_i t_j M_ji with t = -1 for processed blocks and +1
-  // otherwise, so only the tiles on and below the diagonal are computed.  Round 3: they are no longer mirrored
-  // into the upper triangle at every block step (80 of the 240 MB a step moved at D = 6300): the upper triangle goes
-  // stale, gj_symm_kernel refreshes the two panels a block step reads from it - the block row right of the diagonal
-  // block and the block column above it - from the lower triangle before the step, and gj_mirror_kernel
-  // rebuilds the whole upper triangle once at the end.  The values read are the ones the mirrored matrix held:
-  // results are unchanged bit for bit.
-  if (tn > tm) return;                                  // upper triangle (for tn == kb: rows above the block)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = PHASE == 1 ? (int)(blockIdx.x & 3) : tid >> 6;
   const int kk = lane >> 5, li = lane & 31;
   const int m0 = tm * 128 + (wave >> 1) * 64, n0 = tn * 128 + (wave & 1) * 64;
   const bool blockcol = (tn == kb);
   const float4* cp = CT + (int64_t)kk * Dp + m0 + li;
   const float4* rp = RT + (int64_t)kk * Dp + n0 + li;
-  constexpr int PF = 1;      // k octets of operand loads in flight ahead of the MFMAs
-  float4 av[2][PF][2], bv[2][PF][2];
+  // Operand loads AHEAD k octets ahead of the MFMAs that use them, in a ring of AHEAD + 1 register sets.
+  // PHASE 0 / 2 (every tile resident at once at D = 6300: 92 registers, five waves per SIMD): one octet ahead, and the
+  // compiler is free to merge the two sets and issue an octet's loads behind the MFMAs of the one before - a wave then
+  // waits a trip to the L2 / Infinity Cache per octet (31 us per 64 x 64 wave tile against 6.8 us of MFMA time, kernel
+  // trace of one-wave workgroups), which the five waves of a SIMD cover for each other.  A real ring three octets ahead
+  // (142 registers, three waves) makes a lone wave faster (20 us) and the full update slower (90-96 against 80 us:
+  // gpurun r04i), so only PHASE 1 - a few one-wave workgroups on the critical path - uses it.
+  constexpr int AHEAD = PHASE == 1 ? 3 : 1, RING = AHEAD + 1;
+  float4 av[RING][2], bv[RING][2];
   auto load = [&](int buf, int c) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        av[buf][u][x] = cp[(int64_t)2 * (PF * c + u) * Dp + 32 * x];
-        bv[buf][u][x] = rp[(int64_t)2 * (PF * c + u) * Dp + 32 * x];
-      }
+    for (int x = 0; x < 2; ++x) {
+      av[buf][x] = cp[(int64_t)2 * c * Dp + 32 * x];
+      bv[buf][x] = rp[(int64_t)2 * c * Dp + 32 * x];
+    }
   };
-  load(0, 0);
+#pragma unroll
+  for (int c = 0; c < AHEAD; ++c) load(c, c);
   gj_f32x16 acc[2][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -251,23 +335,23 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 #pragma unroll
-  for (int c = 0; c < 16 / PF; ++c) {
-    if (c + 1 < 16 / PF) load((c + 1) & 1, c + 1);
+  for (int c = 0; c < 16; ++c) {
+    if (c + AHEAD < 16) load((c + AHEAD) % RING, c + AHEAD);
+    if constexpr (PHASE == 1) __builtin_amdgcn_sched_barrier(0);      // the loads stay where they are issued
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
+    for (int mi = 0; mi < 2; ++mi) {
+      const float4 a = av[c % RING][mi];
+      const float a4[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const float4 a = av[c & 1][u][mi];
-        const float a4[4] = {a.x, a.y, a.z, a.w};
+      for (int ni = 0; ni < 2; ++ni) {
+        const float4 b = bv[c % RING][ni];
+        const float b4[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const float4 b = bv[c & 1][u][ni];
-          const float b4[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[mi][ni], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[mi][ni], 0, 0, 0);
       }
+    }
+    if constexpr (PHASE == 1) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -277,11 +361,9 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
-        float v = 0.f;
         if (row < D && col < D) {
           float* p = A + (int64_t)row * D + col;
-          v = (blockcol ? 0.f : *p) - acc[mi][ni][r];
-          *p = v;
+          *p = (blockcol ? 0.f : *p) - acc[mi][ni][r];
         }
       }
     }
@@ -290,50 +372,9 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
 int gj_kernel_attrs(dmp_ctx* c) {
   static bool done[64] = {};
   if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
+  DMP_HIP(hipFuncSetAttribute((const void*)gj_cross_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GJ_CROSS_LDS));
   if (c->device >= 0 && c->device < 64) done[c->device] = true;
   return DMP_OK;
-}
-
-// Before block step k: the entries the step reads from the (stale) upper triangle, rebuilt from the lower one with
-// the sign rule M_ij = t_i t_j M_ji (block k itself not yet processed: t_k = +1):
-//   block row, right of the diagonal block   A[k0 + r][j] =  A[j][k0 + r]   (j >= k0 + bs, unprocessed: +1)
-//   block column, above the diagonal block   A[i][k0 + c] = -A[k0 + c][i]   (i < k0, processed: -1)
-// grid: ceil(D / 64) tiles of 64 matrix rows / columns outside the block   block: 256
-__global__ __launch_bounds__(256) void gj_symm_kernel(float* __restrict__ A, int D, int k0, int bs) {
-  __shared__ float tile[64][GJ_NB + 1];
-  const int o0 = blockIdx.x * 64, tid = threadIdx.x;
-  if (o0 + 64 <= k0) {
-    // columns i = o0 .. o0+63 left of the block: read A[k0 + c][i] (coalesced along i), write A[i][k0 + c] = -that
-    for (int it = 0; it < 32; ++it) {
-      const int c = 4 * it + (tid >> 6), x = tid & 63;
-      tile[x][c] = (c < bs) ? A[(int64_t)(k0 + c) * D + o0 + x] : 0.f;
-    }
-    __syncthreads();
-    for (int it = 0; it < 32; ++it) {
-      const int x = 2 * it + (tid >> 7), c = tid & 127;
-      if (c < bs) A[(int64_t)(o0 + x) * D + k0 + c] = -tile[x][c];
-    }
-  } else if (o0 >= k0 + bs) {
-    // rows j = o0 .. o0+63 below the block: read A[j][k0 + r] (coalesced along r), write A[k0 + r][j] = that
-    for (int it = 0; it < 32; ++it) {
-      const int x = 2 * it + (tid >> 7), r = tid & 127;
-      tile[x][r] = (o0 + x < D && r < bs) ? A[(int64_t)(o0 + x) * D + k0 + r] : 0.f;
-    }
-    __syncthreads();
-    for (int it = 0; it < 32; ++it) {
-      const int r = 4 * it + (tid >> 6), x = tid & 63;
-      if (r < bs && o0 + x < D) A[(int64_t)(k0 + r) * D + o0 + x] = tile[x][r];
-    }
-  } else {
-    // the 64-wide tile straddles the block's edges (k0 is a multiple of 128, so only its far edge when bs < 128, or
-    // nothing at all): element-wise, both rules
-    for (int e = tid; e < 64 * GJ_NB; e += 256) {
-      const int x = e / GJ_NB, c = e % GJ_NB, o = o0 + x;
-      if (c >= bs || o >= D) continue;
-      if (o < k0) A[(int64_t)o * D + k0 + c] = -A[(int64_t)(k0 + c) * D + o];
-      else if (o >= k0 + bs) A[(int64_t)(k0 + c) * D + o] = A[(int64_t)o * D + k0 + c];
-    }
-  }
 }
 
 // After the last block step every block is processed (t = -1 everywhere: t_i t_j = +1): upper = lower, transposed.
@@ -356,55 +397,65 @@ __global__ __launch_bounds__(256) void gj_mirror_kernel(float* __restrict__ A, i
   }
 }
 
-// A_k,: = R (outside the block), A_kk = P
-__global__ __launch_bounds__(256) void gj_writeback_kernel(float* __restrict__ A, int D, int k0,
-                                                           int bs, const float* __restrict__ R,
-                                                           const float* __restrict__ P) {
-  const int r = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= D || r >= bs) return;
-  const bool inblk = (j >= k0 && j < k0 + bs);
-  A[(int64_t)(k0 + r) * D + j] = inblk ? P[r * GJ_NB + (j - k0)] : R[(int64_t)r * D + j];
+int spd_inverse(dmp_ctx* c, float* A, int D, hipStream_t s, hipStream_t la) {
+  return spd_inverse_steps(c, A, D, 0, cdiv(D, GJ_NB), s, la);
 }
 
-int spd_inverse(dmp_ctx* c, float* A, int D, hipStream_t s) {
-  return spd_inverse_steps(c, A, D, 0, cdiv(D, GJ_NB), s);
-}
-
-int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipStream_t s) {
-  float *P = c->gj_p, *R = c->gj_r;
-  const int Dp = round_up(D, GJ_NB);
-  float4* CT = reinterpret_cast<float4*>(c->gj_c);
-  float4* RT = reinterpret_cast<float4*>(c->gj_rt);
-  for (int k0 = blk_lo * GJ_NB; k0 < D && k0 < blk_hi * GJ_NB; k0 += GJ_NB) {
-    const int bs = std::min(GJ_NB, D - k0);
-    if (k0 > 0 || k0 + bs < D) {
-      hipLaunchKernelGGL(gj_symm_kernel, dim3(cdiv(D, 64)), dim3(256), 0, s, A, D, k0, bs);
+// Block steps [blk_lo, blk_hi).  Per step: the diagonal block's inverse (one workgroup), the cross kernel (panels),
+// the trailing update - three launches (six in rounds 1-3).
+// `la` (a second stream, or null): LOOK-AHEAD inside the range.  The trailing update of step k is issued in two parts,
+// first the tiles step k+1's diagonal inverse and panels read (PHASE 1: Dp/128 tiles), then the rest; the moment the
+// first part is done, step k+1's diagonal inverse and cross kernel run on `la`, into the other set of panel buffers,
+// beside the second part.  The one-workgroup sweep (52 us of a step's 150 at D = 6300) and the panel kernel leave the
+// critical path; every tile sees the same operations in the same order: same bits as without.  Used where one
+// prediction has the machine to itself (dmp_predict, dmp_spd_inverse); a scheduler's engines keep one stream each.
+// Measured (tools/time_inverse.py, profiles/r04_inverse.txt): D = 10500: 23.5 against 25.4 ms, D = 21000: 169.5 against
+// 173.4; D = 6300: 8.7 against 7.7 - beside the trailing update the one-workgroup sweep takes 100 us instead of 52 (the
+// clocks under a chip full of f32 MFMAs, the shared CU), which at that size is longer than the update it hides behind.
+// So the look-ahead is used from 64 tile rows (D > 8064) on.
+constexpr int GJ_LOOKAHEAD_MIN_TILES = 64;
+int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipStream_t s, hipStream_t la) {
+  const int Dp = round_up(D, GJ_NB), nt = Dp / GJ_NB;
+  const int64_t pan = (int64_t)Dp * GJ_NB;
+  int rc;
+  auto Pb = [&](int k) { return c->gj_p + (int64_t)(k & 1) * GJ_NB * GJ_NB; };
+  auto CTb = [&](int k) { return reinterpret_cast<float4*>(c->gj_c + (k & 1) * pan); };
+  auto RTb = [&](int k) { return reinterpret_cast<float4*>(c->gj_rt + (k & 1) * pan); };
+  auto prepare = [&](int k, hipStream_t st) -> int {    // P, panels and row write-back of step k
+    const int k0 = k * GJ_NB, bs = std::min(GJ_NB, D - k0);
+    if (c->gj_diag_groups == 2) hipLaunchKernelGGL(gj_diag_kernel<2>, dim3(1), dim3(256), 0, st, A, D, k0, bs, Pb(k));
+    else if (c->gj_diag_groups == 8) hipLaunchKernelGGL(gj_diag_kernel<8>, dim3(1), dim3(1024), 0, st, A, D, k0, bs, Pb(k));
+    else hipLaunchKernelGGL(gj_diag_kernel<4>, dim3(1), dim3(512), 0, st, A, D, k0, bs, Pb(k));
+    DMP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gj_cross_kernel, dim3(Dp / 64), dim3(256), GJ_CROSS_LDS, st, A, D, Dp, k0, bs, Pb(k), CTb(k), RTb(k));
+    DMP_LAUNCH_CHECK();
+    return DMP_OK;
+  };
+  if (nt < (c->gj_lookahead == 2 ? 0 : GJ_LOOKAHEAD_MIN_TILES)) la = nullptr;     // option 2: at every size (tests)
+  const int k_end = std::min(blk_hi, cdiv(D, GJ_NB));
+  const dim3 lower(nt * (nt + 1) / 2);
+  for (int k = blk_lo; k < k_end; ++k) {
+    const int k0 = k * GJ_NB, bs = std::min(GJ_NB, D - k0);
+    const bool ahead = la && k + 1 < k_end;
+    if (k == blk_lo || !la) { if ((rc = prepare(k, s))) return rc; }
+    // A -= C R outside the block column, A[:, block] = -C P inside it
+    if (ahead) {
+      hipLaunchKernelGGL(gj_trailing_kernel<1>, dim3(4 * nt), dim3(64), 0, s, A, D, Dp, k0, CTb(k), RTb(k));
+      DMP_LAUNCH_CHECK();
+      DMP_HIP(hipEventRecord((hipEvent_t)c->gj_ev[0], s));
+      DMP_HIP(hipStreamWaitEvent(la, (hipEvent_t)c->gj_ev[0], 0));
+      if ((rc = prepare(k + 1, la))) return rc;
+      DMP_HIP(hipEventRecord((hipEvent_t)c->gj_ev[1], la));
+      hipLaunchKernelGGL(gj_trailing_kernel<2>, lower, dim3(256), 0, s, A, D, Dp, k0, CTb(k), RTb(k));
+      DMP_LAUNCH_CHECK();
+      DMP_HIP(hipStreamWaitEvent(s, (hipEvent_t)c->gj_ev[1], 0));
+    } else {
+      hipLaunchKernelGGL(gj_trailing_kernel<0>, lower, dim3(256), 0, s, A, D, Dp, k0, CTb(k), RTb(k));
       DMP_LAUNCH_CHECK();
     }
-    if (c->gj_diag_groups == 2) hipLaunchKernelGGL(gj_diag_kernel<2>, dim3(1), dim3(256), 0, s, A, D, k0, bs, P);
-    else if (c->gj_diag_groups == 8) hipLaunchKernelGGL(gj_diag_kernel<8>, dim3(1), dim3(1024), 0, s, A, D, k0, bs, P);
-    else hipLaunchKernelGGL(gj_diag_kernel<4>, dim3(1), dim3(512), 0, s, A, D, k0, bs, P);
-    DMP_LAUNCH_CHECK();
-    GemmArgs g{};
-    // R = P * A[k0:k0+bs, :]
-    g.A = P; g.sam = GJ_NB; g.sak = 1;
-    g.B = A + (int64_t)k0 * D; g.sbk = D; g.sbn = 1;
-    g.C = R; g.ldc = D; g.M = bs; g.N = D; g.K = bs; g.alpha = 1.f; g.beta = 0.f;
-    int rc = gemm_f32(g, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(gj_panels_kernel, dim3(Dp / 64), dim3(256), 0, s, A, D, Dp, k0, bs, P, R, CT, RT);
-    DMP_LAUNCH_CHECK();
-    // A -= C R outside the block column, A[:, block] = -C P inside it
-    const dim3 tgrid((Dp / 128) * (Dp / 128));
-    hipLaunchKernelGGL(gj_trailing_kernel, tgrid, dim3(256), 0, s, A, D, Dp, k0, CT, RT);
-    DMP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gj_writeback_kernel, dim3(cdiv(D, 256), bs), dim3(256), 0, s, A, D, k0, bs,
-                       R, P);
-    DMP_LAUNCH_CHECK();
     if (k0 + bs >= D && D > GJ_NB) {                   // the last block step: rebuild the upper triangle
-      const int nt = cdiv(D, 64);
-      hipLaunchKernelGGL(gj_mirror_kernel, dim3(nt, nt), dim3(256), 0, s, A, D);
+      const int n64 = cdiv(D, 64);
+      hipLaunchKernelGGL(gj_mirror_kernel, dim3(n64, n64), dim3(256), 0, s, A, D);
       DMP_LAUNCH_CHECK();
     }
   }

@@ -96,6 +96,10 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * agent-scope stores, the protocol that does not depend on placement.  Same bits, 1.84 against 2.8 us per GRU step.
  * "gj_diag_groups" = 2 / 4 / 8: threads (x 128) of the one-workgroup diagonal sweep of the inverse; same bits; 4 is the
  * default (8.9 against 10.0 ms per inverse at D = 6300 with 2, the form of rounds 1-3).
+ * "gj_lookahead" = 0 / 1 / 2: the inverse's look-ahead - the next block step's diagonal sweep and panels on the context's
+ * second stream beside this step's trailing update - where one prediction has the device to itself (dmp_predict,
+ * dmp_spd_inverse, dmp_dca_features): 0 never, 1 (default) from 64 tile rows on (D > 8064: 23.5 against 25.4 ms at
+ * D = 10500; at D = 6300 it loses, 8.7 against 7.7 ms), 2 at every size.  Same bits in every mode.
  * "act_scaling" (default 1): conv_mode 0 takes the f16 pieces of 2^e x activation, with e chosen per residual block
  * at dmp_weights_finalize from the InstanceNorm weights of the blocks before it (a bound of the residual stream), so the
  * low pieces of the bulk of the activations are normal f16 numbers whether the trunk sits at 1e-3 or at 1e4, and a trunk
