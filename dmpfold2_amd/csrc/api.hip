@@ -731,7 +731,7 @@ int dmp_dca_features(dmp_ctx* ctx, const uint8_t* d_msa, int N, int L, float* d_
   }
   int rc;
   if ((rc = msa_weights(ctx, d_msa, N, L, ctx->w, STREAM))) return rc;
-  if ((rc = cov_build(ctx, d_msa, ctx->w, N, L, ctx->cov, STREAM))) return rc;
+  if ((rc = cov_build(ctx, d_msa, ctx->w, N, L, ctx->cov, STREAM, true))) return rc;
   hipStream_t la = nullptr;
   if (ctx->gj_lookahead && (rc = side_stream_of(ctx, &la))) return rc;
   if ((rc = spd_inverse(ctx, ctx->cov, NS * L, STREAM, la))) return rc;
@@ -984,7 +984,7 @@ static int issue_front_end_unit(dmp_ctx* c, hipStream_t s) {
     }
     used = side;
     rc = msa_weights(c, d_msa, N, L, c->w, side);
-    if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, side);
+    if (!rc && N > 1) rc = cov_build(c, d_msa, c->w, N, L, c->cov, side, true);
   } else if (u <= c->fe_inv + c->fe_vgru) {
     // alternate GRU chunk / inverse chunk while both kinds remain
     const int k = u - 1, m = std::min(c->fe_inv, c->fe_vgru);

@@ -251,14 +251,17 @@ struct GemmArgs {
   int M, N, K;
   float alpha, beta;
   const float* bias_n;                // optional, added per column n
+  bool lower_tiles;                   // only the 128 x 128 tiles on / below the diagonal (a symmetric product whose
+                                      // consumer reads those alone: the covariance before its in-place inverse)
 };
 int gemm_f32(const GemmArgs& g, hipStream_t s);
 
 // msa.hip
 int msa_weights(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_w, hipStream_t s);
 // dca.hip
+// lower_only: leave the 128 x 128 tiles above the diagonal uncomputed (spd_inverse never reads them)
 int cov_build(dmp_ctx* c, const uint8_t* d_msa, const float* d_w, int N, int L, float* d_cov,
-              hipStream_t s);
+              hipStream_t s, bool lower_only = false);
 int trunk_kernel_attrs(dmp_ctx* c);   // once per device, at context creation
 int spd_inverse(dmp_ctx* c, float* d_A, int D, hipStream_t s, hipStream_t la = nullptr);
 // block steps [blk_lo, blk_hi) of the in-place inverse (GJ_NB columns each); all of them = spd_inverse

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (g.lower_tiles && (n0 >> 7) > (m0 >> 7)) return;     // (uniform: before any barrier)
 
   float ra[NLD], rb[NLD];
   auto load_tiles = [&](int k0) {
