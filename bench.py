@@ -626,7 +626,7 @@ def main(argv=None):
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA_TFLOPS / 3.0),
                          "traffic": traffic,
                          "traffic_source": "profiles/conv5x5_pmc.json (rocprofv3 --pmc passes of single "
-                                           "launches, tools/profile_bench.sh; a separate profiler run)",
+                                           "launches, tools/profile_r04.sh; a separate profiler run)",
                          "traffic_taken_from_this_kernel_source": traffic_current,
                          "launches_timed": conv_cnt,
                          "avg_launch_ms": conv_ms, "launches_in_flight": in_flight,

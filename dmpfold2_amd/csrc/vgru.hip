@@ -550,20 +550,19 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
   // different, invisible to a static in-flight-register check), so the waits are the compiler's here.
   typedef unsigned vp_u32x4v __attribute__((vector_size(16)));
   constexpr int VP_SC1 = 16;                            // cache-policy bit of the buffer load: agent scope
-  auto load_tile = [&](__amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, int tcol, vg_u32x4 (&d0)[4][2][2],
-                       vg_u32x4 (&d1)[4][2][2]) {
+  // one k-step (a quarter of this wave's K quarter) of a tile's pieces -> register slot ks
+  auto load_ks = [&](__amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, int tcol, int ks, vg_u32x4 (&d0)[4][2][2],
+                     vg_u32x4 (&d1)[4][2][2]) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const unsigned off = (unsigned)(((p * 64 + 16 * w + 4 * ks + lq) * Lb + tcol + nt * 16 + lr) * 16);
-          const vp_u32x4v x0 = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, VP_SC1);
-          const vp_u32x4v x1 = __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0, VP_SC1);
-          d0[ks][p][nt] = vg_u32x4{x0[0], x0[1], x0[2], x0[3]};
-          d1[ks][p][nt] = vg_u32x4{x1[0], x1[1], x1[2], x1[3]};
-        }
+      for (int nt = 0; nt < 2; ++nt) {
+        const unsigned off = (unsigned)(((p * 64 + 16 * w + 4 * ks + lq) * Lb + tcol + nt * 16 + lr) * 16);
+        const vp_u32x4v x0 = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, VP_SC1);
+        const vp_u32x4v x1 = __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0, VP_SC1);
+        d0[ks][p][nt] = vg_u32x4{x0[0], x0[1], x0[2], x0[3]};
+        d1[ks][p][nt] = vg_u32x4{x1[0], x1[1], x1[2], x1[3]};
+      }
   };
   const unsigned piece_bytes = (unsigned)(2 * 64 * Lb * 16);     // one layer / parity: [piece 2][k/8 64][Lb] x 16 bytes
   const unsigned state_bytes = (unsigned)(128 * Lb * 16);        // [j/4 128][Lb] x float4
@@ -579,8 +578,19 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
     uint16_t* gnext = fl ? st.hH[1][par] : st.hH[0][par ^ 1];
     int ct = next_active(c_lo, t);
     vg_u32x4 b0[4][2][2], b1[4][2][2];
-    if (ct < c_hi) load_tile(r0, r1, ct * VG_TB, b0, b1);
+    // The pieces stream through the four register slots THREE k-steps ahead of the MFMAs that read them - slot ks holds
+    // k-step ks of whichever tile is next to need it: k-step 0 issues the loads of this tile's k-step 3, k-steps 1..3 the
+    // loads of the NEXT tile's k-steps 0..2, each into the slot the k-step before has just read.  (Until round 4's last
+    // session a tile's 32 loads were issued together behind its last MFMA and waited for under the reduction: every CU
+    // of an XCD reads the tile's whole state, 4 MB per tile out of one L2 - 0.8 of a tile's 4.2 us.)  A row's first
+    // tile cannot be requested before the row barrier.
+    if (ct < c_hi) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) load_ks(r0, r1, ct * VG_TB, ks, b0, b1);
+    }
     while (ct < c_hi) {
+      const int nx = next_active(ct + 1, t);
+      const int ncol = (nx < c_hi ? nx : ct) * VG_TB;
       const int mi = member_of(ct);
       const int N = rec->mem[mi].N, L = rec->mem[mi].L;
       const bool act0 = t < N, act1 = t >= 1 && t <= N;
@@ -604,6 +614,10 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
       for (int g = 0; g < 4; ++g) { a1[g][0] = vp_f32x4{0, 0, 0, 0}; a1[g][1] = vp_f32x4{0, 0, 0, 0}; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
+        // (unconditional - the row's last tile requests its own pieces again: behind a branch the compiler cannot count
+        // the loads in flight and waits for all of them)
+        load_ks(r0, r1, ks == 0 ? tcol : ncol, (ks + 3) & 3, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);               // the loads stay where they are issued
         if (act0) {
           uint4 f[6];
 #pragma unroll
@@ -640,9 +654,6 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
         }
       }
       vp_mfma_results_ready(a1);
-      // the next tile's pieces stream in under this tile's reduction
-      const int nx = next_active(ct + 1, t);
-      if (nx < c_hi) load_tile(r0, r1, nx * VG_TB, b0, b1);        // (the MFMAs above were the last readers of b0 / b1)
       // ---- partial sums of the four K quarters meet in LDS
 #pragma unroll
       for (int g = 0; g < 3; ++g)

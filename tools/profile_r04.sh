@@ -1,18 +1,19 @@
 #!/bin/bash
 # GPU box: the round-4 profile set.  Kernel stats of the bench command per arithmetic leg (two tables), PMC passes of
 # both convolution kernels, single-target timeline, lane trace, the bench itself; summaries are copied to profiles/
-# by tools/summarize_profiles.py r04.
+# by tools/summarize_profiles.py r04.  Every step under its own timeout (a step that waits on an empty argument once
+# cost a whole GPU call).
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04prof; mkdir -p $O; cd $R
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_bench $R/gpurun_out/prof_bench_f32 $R/gpurun_out/pmc /tmp/single_prof
 mkdir -p $R/gpurun_out/prof_bench $R/gpurun_out/prof_bench_f32 $R/gpurun_out/pmc
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o bench -- \
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o bench -- \
   python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs f16x3 > $R/gpurun_out/prof_bench/bench_under_rocprof.log 2>&1
 echo "stats f16x3 rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench_f32 -o bench -- \
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench_f32 -o bench -- \
   python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs f32 > $R/gpurun_out/prof_bench_f32/bench_under_rocprof.log 2>&1
 echo "stats f32 rc=$?"
-run() { mode=$1; name=$2; shift; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc/$name -o $name -- python $R/tools/conv_only.py 1 300 $mode > $R/gpurun_out/pmc/$name.log 2>&1; echo "$name rc=$?"; }
+run() { mode=$1; name=$2; shift; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc/$name -o $name -- python $R/tools/conv_only.py 1 300 $mode > $R/gpurun_out/pmc/$name.log 2>&1; echo "$name rc=$?"; }
 for mode in 0 1; do
   sfx=$([ $mode = 1 ] && echo _f32 || echo "")
   run $mode sq1$sfx SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS
@@ -21,11 +22,12 @@ for mode in 0 1; do
   run $mode write$sfx WRITE_SIZE
 done
 find $R/gpurun_out/prof_bench $R/gpurun_out/prof_bench_f32 $R/gpurun_out/pmc -name "*kernel_trace.csv" -size +20M -delete
-rocprofv3 --kernel-trace --output-format csv -d /tmp/single_prof -o s -- python $R/tools/single_trace.py run 300 2000 10 100 4 > $O/single_run.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/single_prof -o s -- python $R/tools/single_trace.py run 300 2000 10 100 4 > $O/single_run.txt 2>&1
 f=$(find /tmp/single_prof -name "*kernel_trace.csv" | head -1)
-python $R/tools/single_trace.py analyse $f > $O/single_timeline.txt 2>&1
-python $R/tools/single_trace.py run 300 2000 10 100 6 > $O/single_run_noprof.txt 2>&1
-cd $R; python tools/lane_trace.py > $O/lane_trace.txt 2>&1
-python bench.py > $O/bench.json 2> $O/bench.err
-python tools/time_vgru_persist.py 8 300 2000 > $O/vgru_persist.txt 2>&1
+[ -n "$f" ] && timeout 120 python $R/tools/single_trace.py analyse "$f" > $O/single_timeline.txt 2>&1
+timeout 300 python $R/tools/single_trace.py run 300 2000 10 100 6 > $O/single_run_noprof.txt 2>&1
+cd $R; timeout 600 python tools/lane_trace.py > $O/lane_trace.txt 2>&1
+timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python tools/time_vgru_persist.py 8 300 2000 > $O/vgru_persist.txt 2>&1
+timeout 600 python tools/time_inverse.py 300 500 1000 > $O/inverse.txt 2>&1
 tail -c 600 $O/bench.json; tail -4 $O/single_run_noprof.txt; head -30 $O/single_timeline.txt
