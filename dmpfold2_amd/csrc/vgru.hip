@@ -452,6 +452,7 @@ constexpr int VP_WL0_SLOTS = 4 * 4 * 6 * 64;                 // [wave][k-step][p
 constexpr int VP_RED_SLOTS = 4 * 14 * 64;                    // [wave][accumulator][lane] float4: 57 344 B
 constexpr int VP_TAB_FLOATS = 3 * 24 * 16;                   // [gate][code][row] one-hot input terms: 4 608 B
 constexpr int VP_LDS_BYTES = (VP_WL0_SLOTS + VP_RED_SLOTS) * 16 + VP_TAB_FLOATS * 4;     // 160 256 of 163 840
+constexpr int VP_MAX_XCD_TILES = 64;                           // (+ 1.1 KB of static LDS: the XCD's tile table)
 constexpr int VP_GRID = 256;                                 // one workgroup per CU, 32 per XCD
 struct VPSync { unsigned count[8]; unsigned pad[24]; unsigned flag[8][32]; };              // zeroed before every launch
 static_assert(sizeof(VPSync) == 128 + 1024, "VPSync layout");
@@ -480,6 +481,11 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
   vp_f32x4* red = reinterpret_cast<vp_f32x4*>(vp_smem + VP_WL0_SLOTS * 16);
   float* tab = reinterpret_cast<float*>(vp_smem + (VP_WL0_SLOTS + VP_RED_SLOTS) * 16);
   __shared__ int sh_u;
+  // this XCD's column tiles: {rows N, columns L, first column of the tile in ITS alignment, member} and the members'
+  // alignments - from the group record in global memory once per launch (a tile's bookkeeping was a chain of four to
+  // six dependent scalar loads at the head of every tile before)
+  __shared__ int sh_tile[VP_MAX_XCD_TILES][4];
+  __shared__ unsigned long long sh_msa[VG_MAX_MEMBERS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned xcc;
@@ -536,9 +542,22 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
       if (m < nmem && ct >= rec->mem[m].tile0) mi = m;
     return mi;
   };
+  if (c_hi - c_lo > VP_MAX_XCD_TILES) {                 // (the host never builds such a group: 8 x 2048 columns = 64 tiles per XCD)
+    if (tid == 0) atomicOr(fault, DMP_FAULT_VGRU_HANDOFF);
+    return;
+  }
+  for (int i = tid; i < c_hi - c_lo; i += 256) {
+    const int mi = member_of(c_lo + i);
+    sh_tile[i][0] = rec->mem[mi].N;
+    sh_tile[i][1] = rec->mem[mi].L;
+    sh_tile[i][2] = (c_lo + i - rec->mem[mi].tile0) * VG_TB;
+    sh_tile[i][3] = mi;
+  }
+  if (tid < VG_MAX_MEMBERS) sh_msa[tid] = tid < nmem ? (unsigned long long)rec->mem[tid].msa : 0ull;
+  __syncthreads();
   auto next_active = [&](int ct, int t) {               // first tile >= ct of this XCD that is computed at row t, or c_hi
     for (; ct < c_hi; ++ct) {
-      const int N = rec->mem[member_of(ct)].N;
+      const int N = __builtin_amdgcn_readfirstlane(sh_tile[ct - c_lo][0]);
       if (t < N || (t >= 1 && t <= N)) break;
     }
     return ct;
@@ -567,6 +586,9 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
   const unsigned piece_bytes = (unsigned)(2 * 64 * Lb * 16);     // one layer / parity: [piece 2][k/8 64][Lb] x 16 bytes
   const unsigned state_bytes = (unsigned)(128 * Lb * 16);        // [j/4 128][Lb] x float4
 
+  uint4 f[6];                                          // layer 0's weight fragments of the k-step ahead (from LDS)
+#pragma unroll
+  for (int pg = 0; pg < 6; ++pg) f[pg] = wl0[((w * 4 + 0) * 6 + pg) * 64 + lane];
   for (int t = t_lo; t < t_hi; ++t) {
     const int par = t & 1;
     // layer 0 state at row t (both layers read it), layer 1 state at row t-1, this thread's layer's previous state
@@ -591,8 +613,8 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
     while (ct < c_hi) {
       const int nx = next_active(ct + 1, t);
       const int ncol = (nx < c_hi ? nx : ct) * VG_TB;
-      const int mi = member_of(ct);
-      const int N = rec->mem[mi].N, L = rec->mem[mi].L;
+      const int N = __builtin_amdgcn_readfirstlane(sh_tile[ct - c_lo][0]);
+      const int L = __builtin_amdgcn_readfirstlane(sh_tile[ct - c_lo][1]);
       const bool act0 = t < N, act1 = t >= 1 && t <= N;
       const int tcol = ct * VG_TB;
       // what the finishing threads need of this tile - their previous state, layer 0's residue code - is requested
@@ -605,8 +627,9 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         hp[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (unsigned)(hoff * 4 + 4 * i), 0, VP_SC1));
-      const int bm = (ct - rec->mem[mi].tile0) * VG_TB + fc;                   // the column in ITS alignment
-      const int code = (fl == 0 && act0 && bm < L) ? (int)rec->mem[mi].msa[(int64_t)t * L + bm] : 0;
+      const int bm = sh_tile[ct - c_lo][2] + fc;                              // the column in ITS alignment
+      const uint8_t* msa = reinterpret_cast<const uint8_t*>(sh_msa[sh_tile[ct - c_lo][3]]);
+      const int code = (fl == 0 && act0 && bm < L) ? (int)msa[(int64_t)t * L + bm] : 0;
       vp_f32x4 a0[3][2], a1[4][2];                     // layer 0: r z hn; layer 1: r z hn in; x column half
 #pragma unroll
       for (int g = 0; g < 3; ++g) { a0[g][0] = vp_f32x4{0, 0, 0, 0}; a0[g][1] = vp_f32x4{0, 0, 0, 0}; }
@@ -619,9 +642,6 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
         load_ks(r0, r1, ks == 0 ? tcol : ncol, (ks + 3) & 3, b0, b1);
         __builtin_amdgcn_sched_barrier(0);               // the loads stay where they are issued
         if (act0) {
-          uint4 f[6];
-#pragma unroll
-          for (int pg = 0; pg < 6; ++pg) f[pg] = wl0[((w * 4 + ks) * 6 + pg) * 64 + lane];
           // small products first (w0 h1, w1 h0, then w0 h0); per product the six accumulators (gate x column half) take
           // their MFMA one after the other, so that a dependent MFMA is six instructions behind the one it waits for
 #pragma unroll
@@ -632,6 +652,12 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
               for (int g = 0; g < 3; ++g)
                 a0[g][nt] = vp_mfma_v(f[pr == 1 ? 3 + g : g], b0[ks][pr == 0 ? 1 : 0][nt], a0[g][nt]);
         }
+        // layer 0's weight fragments of the NEXT k-step (of the next tile after the last one: they do not depend on the
+        // tile) leave the LDS under layer 1's MFMAs - requested at the head of a k-step they were waited for with the
+        // matrix pipe idle, four waves sharing one LDS port
+#pragma unroll
+        for (int pg = 0; pg < 6; ++pg) f[pg] = wl0[((w * 4 + ((ks + 1) & 3)) * 6 + pg) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
         if (act1) {
           // recurrent product (into r, z, hn), then the input product (into r, z, in): the same order of additions per
           // accumulator as one after the other, the MFMAs of a product interleaved over the accumulators
