@@ -2,8 +2,8 @@
 # scratch GPU job of the session (gpurun -- 'bash tools/gpu_job.sh'); every step under a timeout
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/job; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "vertical or grouped or rider or persistent" 2>&1 | tail -3
-for lib in tools/_bin/libdmp_prev.so dmpfold2_amd/libdmpfold_hip.so; do
-  echo "== $lib"
-  DMPFOLD_HIP_LIB=$PWD/$lib timeout 300 python tools/time_vgru_persist.py 8 300 2000 2>&1 | grep "vgru_persistent=1"
-done
+timeout 1500 python -m pytest tests -q -m gpu > $OUT/tests.log 2>&1
+echo "tests rc=$?" >> $OUT/tests.log
+tail -4 $OUT/tests.log
+timeout 2400 bash tools/profile_r04.sh > $OUT/profile.log 2>&1
+tail -30 $OUT/profile.log
