@@ -139,6 +139,7 @@ struct dmp_ctx {
   float* gj_p = nullptr;                    // inverse of the diagonal block (two sets of each: step parity)
   float *gj_c = nullptr, *gj_rt = nullptr;  // column / row panels as k quads [32][Dp][4] (dca.hip)
   void* gj_ev[2] = {nullptr, nullptr};      // look-ahead fork / join of the inverse (spd_inverse_steps)
+  int gj_pairs = 1;                         // option: block steps of the inverse in pairs, one pass over the tiles per pair (dca.hip)
   int gj_lookahead = 1;                     // option: the next step's sweep and panels beside the trailing update (0 off, 1 from 64 tile rows on, 2 always)
   int fe_inv_blocks = 6;                    // block steps per front-end unit of this prediction
   float* contacts = nullptr;  // [L][L]
@@ -279,6 +280,26 @@ int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo,
 // records of all members into the leader's buffer and clears their states, steps runs rows [t_lo, t_hi), output
 // hands a member its L x 512 result.
 int vgru_kernel_attrs(dmp_ctx* c);
+// Kernels whose workgroups wait for EACH OTHER inside the launch - the cluster kernels (sequence GRU, minimiser,
+// cluster tridiagonalisation: 32 workgroups that hand values over) and the persistent vertical GRU (256 workgroups
+// with row barriers, one per CU) - must not start while another such kernel holds part of what they need: launched
+// at the same moment from two streams, a cluster could get 20 of its 32 CUs and the persistent launch the other 236,
+// and both would wait for the rest until their time-outs (seen in round 4 as DMP_FAULT_VGRU_HANDOFF + a hand-off
+// time-out of a co-running engine's sequence GRU).  Within a process the launches are therefore ordered per device:
+// a persistent launch waits for every cluster kernel launched before it (whatever context and stream) and for the
+// persistent launch before it, a cluster kernel waits for the last persistent launch.  Clusters of different contexts
+// may still run beside each other (they are placed on different XCDs).  Usage: CoResident g(c, s, persistent); launch;
+// g.done().  (Another PROCESS on the same GPU is not covered: time-out, fault bit, the Python layer's fallback.)
+class CoResident {
+ public:
+  CoResident(dmp_ctx* c, hipStream_t s, bool persistent);
+  ~CoResident();
+  int status() const { return rc_; }
+  int done();
+ private:
+  dmp_ctx* c_; hipStream_t s_; bool persistent_, locked_; int rc_;
+};
+void coresident_forget(dmp_ctx* c);   // dmp_ctx_destroy
 int vgru_group_setup(dmp_ctx* lead, dmp_ctx* const* members, const uint8_t* const* msas, const int* Ns,
                      const int* Ls, int n, hipStream_t s);
 int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s);

@@ -338,11 +338,13 @@ int refine_coords(dmp_ctx* c, float* d_ca, int L, int steps, hipStream_t s) {
   a.abort_flag = c->seq_abort;
   a.allow_local = c->cluster_local;
   const int Lg = (L + RF_G - 1) / RF_G;
+  CoResident guard(c, s, false);                       // not beside a persistent vertical-GRU launch (common.h)
+  if (guard.status()) return guard.status();
   DMP_HIP(hipMemsetAsync(c->refine_gx, 0, sizeof(u64) * (2 * 3 * L + 2), s));
   hipLaunchKernelGGL(refine_cluster_kernel, dim3(8 * RF_G), dim3(RF_THREADS),
                      sizeof(float) * (3 * L + 3 * refine_slices(L) * Lg), s, a);
   DMP_LAUNCH_CHECK();
-  return DMP_OK;
+  return guard.done();
 }
 
 // ---------------------------------------------------------------------------------------

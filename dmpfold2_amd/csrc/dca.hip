@@ -375,6 +375,104 @@ __global__ __launch_bounds__(256, 2) void gj_trailing_kernel(float* __restrict__
     }
 }
 
+// TWO block steps' trailing updates in one pass over the tiles (round 4): a tile is read and written once for the
+// steps a = k0 / 128 and b = a + 1, each step's sum in its own MFMA chain, applied one after the other -
+//   v = (old - sum_a) - sum_b,  old - sum_a rounded to float32 exactly as step a stored it
+// - so the result is the two single-step updates bit for bit, with half the passes over the matrix (a block step
+// moves the whole lower triangle for 128 k per element: 32 FLOP per byte of read-modify-write).  Before it runs, the
+// tiles step b's diagonal inverse and panels read have had step a applied on their own (gj_trailing_kernel<1>) and
+// gj_cross_kernel of step b has written row block b and both panels; per tile:
+//   row block b            - nothing (written by step b's cross kernel)
+//   row block a            - step b only (the row holds step a's row panel)
+//   column block b, below  - step b only, as its block column (step a is already in)
+//   column block a, below  - step a as its block column, then step b
+//   elsewhere              - both
+// 247 registers (both steps' sums and the tile: two waves per SIMD; at three the compiler spills 76 words).
+// Measured (tools/time_inverse.py): D = 21 000: 119 against 173 ms (0.49 of the f32 MFMA peak counting D^3), D = 10 500:
+// 20.4 against 26.0, D = 6300: 7.67 against 7.64 - there the pass over 1225 tiles is 141 us against 2 x 80 and the extra
+// launch for step k+1's cross costs what that saves.
+// grid: (Dp/128)(Dp/128 + 1)/2 lower-triangle tiles, row-block major   block: 256
+__global__ __launch_bounds__(256, 2) void gj_trailing2_kernel(float* __restrict__ A, int D, int Dp, int k0,
+                                                              const float4* __restrict__ CTa,
+                                                              const float4* __restrict__ RTa,
+                                                              const float4* __restrict__ CTb,
+                                                              const float4* __restrict__ RTb) {
+  const int ka = k0 >> 7, kb = ka + 1;
+  const int t = blockIdx.x;
+  int tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+  while (tm * (tm + 1) / 2 > t) --tm;
+  const int tn = t - tm * (tm + 1) / 2;
+  if (tm == kb) return;
+  const bool do_a = (tm != ka) && (tn != kb), a_col = (tn == ka), b_col = (tn == kb);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 5, li = lane & 31;
+  const int m0 = tm * 128 + (wave >> 1) * 64, n0 = tn * 128 + (wave & 1) * 64;
+  auto chain = [&](const float4* __restrict__ CT, const float4* __restrict__ RT, gj_f32x16 (&acc)[2][2]) {
+    const float4* cp = CT + (int64_t)kk * Dp + m0 + li;
+    const float4* rp = RT + (int64_t)kk * Dp + n0 + li;
+    float4 av[2][2], bv[2][2];
+    auto load = [&](int buf, int c) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        av[buf][x] = cp[(int64_t)2 * c * Dp + 32 * x];
+        bv[buf][x] = rp[(int64_t)2 * c * Dp + 32 * x];
+      }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c + 1 < 16) load((c + 1) & 1, c + 1);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const float4 a = av[c & 1][mi];
+        const float a4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float4 b = bv[c & 1][ni];
+          const float b4[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+  gj_f32x16 v[2][2], acc[2][2];
+  if (do_a) chain(CTa, RTa, acc);
+  const bool need_old = !b_col && !(do_a && a_col);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + 32 * ni + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
+        const float old = (need_old && row < D && col < D) ? A[(int64_t)row * D + col] : 0.f;
+        v[mi][ni][r] = do_a ? old - acc[mi][ni][r] : old;
+      }
+    }
+  chain(CTb, RTb, acc);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + 32 * ni + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * mi + 8 * (r >> 2) + 4 * kk + (r & 3);
+        if (row < D && col < D) A[(int64_t)row * D + col] = (b_col ? 0.f : v[mi][ni][r]) - acc[mi][ni][r];
+      }
+    }
+}
+
 int gj_kernel_attrs(dmp_ctx* c) {
   static bool done[64] = {};
   if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
@@ -408,7 +506,8 @@ int spd_inverse(dmp_ctx* c, float* A, int D, hipStream_t s, hipStream_t la) {
 }
 
 // Block steps [blk_lo, blk_hi).  Per step: the diagonal block's inverse (one workgroup), the cross kernel (panels),
-// the trailing update - three launches (six in rounds 1-3).
+// the trailing update - three launches (six in rounds 1-3); by default (option gj_pairs) two steps share one pass of
+// the trailing update over the tiles.  With gj_pairs = 0:
 // `la` (a second stream, or null): LOOK-AHEAD inside the range.  The trailing update of step k is issued in two parts,
 // first the tiles step k+1's diagonal inverse and panels read (PHASE 1: Dp/128 tiles), then the rest; the moment the
 // first part is done, step k+1's diagonal inverse and cross kernel run on `la`, into the other set of panel buffers,
@@ -440,8 +539,41 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
   if (nt < (c->gj_lookahead == 2 ? 0 : GJ_LOOKAHEAD_MIN_TILES)) la = nullptr;     // option 2: at every size (tests)
   const int k_end = std::min(blk_hi, cdiv(D, GJ_NB));
   const dim3 lower(nt * (nt + 1) / 2);
-  for (int k = blk_lo; k < k_end; ++k) {
+  auto mirror_if_last = [&](int k) -> int {
     const int k0 = k * GJ_NB, bs = std::min(GJ_NB, D - k0);
+    if (k0 + bs >= D && D > GJ_NB) {                   // the last block step: rebuild the upper triangle
+      const int n64 = cdiv(D, 64);
+      hipLaunchKernelGGL(gj_mirror_kernel, dim3(n64, n64), dim3(256), 0, s, A, D);
+      DMP_LAUNCH_CHECK();
+    }
+    return DMP_OK;
+  };
+  if (c->gj_pairs) {
+    // block steps in PAIRS: step k's panels, step k applied to the tiles step k+1's sweep and panels read, step k+1's
+    // panels, then both steps' updates of everything else in one pass over the tiles (gj_trailing2_kernel)
+    int k = blk_lo;
+    while (k < k_end) {
+      const int k0 = k * GJ_NB;
+      if ((rc = prepare(k, s))) return rc;
+      if (k + 1 < k_end) {
+        hipLaunchKernelGGL(gj_trailing_kernel<1>, dim3(4 * nt), dim3(64), 0, s, A, D, Dp, k0, CTb(k), RTb(k));
+        DMP_LAUNCH_CHECK();
+        if ((rc = prepare(k + 1, s))) return rc;
+        hipLaunchKernelGGL(gj_trailing2_kernel, lower, dim3(256), 0, s, A, D, Dp, k0, CTb(k), RTb(k), CTb(k + 1), RTb(k + 1));
+        DMP_LAUNCH_CHECK();
+        if ((rc = mirror_if_last(k + 1))) return rc;
+        k += 2;
+      } else {
+        hipLaunchKernelGGL(gj_trailing_kernel<0>, lower, dim3(256), 0, s, A, D, Dp, k0, CTb(k), RTb(k));
+        DMP_LAUNCH_CHECK();
+        if ((rc = mirror_if_last(k))) return rc;
+        k += 1;
+      }
+    }
+    return DMP_OK;
+  }
+  for (int k = blk_lo; k < k_end; ++k) {
+    const int k0 = k * GJ_NB;
     const bool ahead = la && k + 1 < k_end;
     if (k == blk_lo || !la) { if ((rc = prepare(k, s))) return rc; }
     // A -= C R outside the block column, A[:, block] = -C P inside it
@@ -459,11 +591,7 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
       hipLaunchKernelGGL(gj_trailing_kernel<0>, lower, dim3(256), 0, s, A, D, Dp, k0, CTb(k), RTb(k));
       DMP_LAUNCH_CHECK();
     }
-    if (k0 + bs >= D && D > GJ_NB) {                   // the last block step: rebuild the upper triangle
-      const int n64 = cdiv(D, 64);
-      hipLaunchKernelGGL(gj_mirror_kernel, dim3(n64, n64), dim3(256), 0, s, A, D);
-      DMP_LAUNCH_CHECK();
-    }
+    if ((rc = mirror_if_last(k))) return rc;
   }
   return DMP_OK;
 }

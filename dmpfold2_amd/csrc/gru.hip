@@ -224,9 +224,15 @@ int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hip
     a.abort_flag = c->seq_abort;
     a.allow_local = c->cluster_local;
     a.xcd0 = c->seq_xcd0;
-    DMP_HIP(hipMemsetAsync(c->seq_hx, 0, sizeof(u64) * (2 * 2 * HID2 + 4), s));
-    hipLaunchKernelGGL(seq_gru_kernel, dim3(8 * SEQ_G), dim3(256), 0, s, a);
-    DMP_LAUNCH_CHECK();
+    {
+      CoResident guard(c, s, false);                   // not beside a persistent vertical-GRU launch (common.h)
+      if (guard.status()) return guard.status();
+      DMP_HIP(hipMemsetAsync(c->seq_hx, 0, sizeof(u64) * (2 * 2 * HID2 + 4), s));
+      hipLaunchKernelGGL(seq_gru_kernel, dim3(8 * SEQ_G), dim3(256), 0, s, a);
+      DMP_LAUNCH_CHECK();
+      int rc = guard.done();
+      if (rc) return rc;
+    }
     in = out;
   }
   return DMP_OK;

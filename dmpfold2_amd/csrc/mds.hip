@@ -952,9 +952,13 @@ int eigh_top8(dmp_ctx* c, const float* d_M, int L, float* d_mds, hipStream_t s) 
     TriClusterArgs ta{};
     ta.A = A; ta.d = d; ta.e = e; ta.tau = tau; ta.V = V;
     ta.gx = (tc_u64*)c->tri_gx; ta.abort_flag = c->seq_abort; ta.n = n; ta.xcd = (c->refine_xcd + 4) & 7; ta.allow_local = c->cluster_local;
+    CoResident guard(c, s, false);                     // not beside a persistent vertical-GRU launch (common.h)
+    if (guard.status()) return guard.status();
     DMP_HIP(hipMemsetAsync(c->tri_gx, 0, sizeof(tc_u64) * (8 * (size_t)n + 2), s));
     hipLaunchKernelGGL(tridiag_cluster_kernel, dim3(8 * TC_G), dim3(256), tri_cluster_lds_bytes(n), s, ta);
     DMP_LAUNCH_CHECK();
+    int grc = guard.done();
+    if (grc) return grc;
   } else {
     hipGraphExec_t ge;
     int rc = tridiag_graph(c, n, A, run, d, e, tau, V, P, &ge);

@@ -875,24 +875,17 @@ int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
     st.bias[0] = W.v_b0; st.bias[1] = W.v_b1;
     if (t_lo >= t_hi) return DMP_OK;
     VPSync* sync = reinterpret_cast<VPSync*>(lead->vgru_sync);
-    // One persistent chain at a time per device: a launch needs every one of its 256 workgroups resident (row
-    // barriers), and two such launches on different streams could each hold part of the CUs and wait for the rest
-    // forever.  Every launch therefore waits for the previous one of this process (whatever context and stream it ran
-    // on) and leaves its own completion event behind.  (Another PROCESS on the same GPU can still collide: the
-    // barriers then time out, the prediction is flagged DMP_FAULT_VGRU_HANDOFF and the Python layer repeats it with the
-    // launch-per-row form.)
+    // needs every one of its 256 workgroups resident (row barriers): ordered against the process's other persistent
+    // launches and cluster kernels on this device (CoResident, common.h)
     {
-      static std::mutex mu;
-      static std::map<int, hipEvent_t> last;          // device -> completion of the most recent persistent launch
-      std::lock_guard<std::mutex> lock(mu);
-      hipEvent_t& ev = last[lead->device];
-      if (ev) DMP_HIP(hipStreamWaitEvent(s, ev, 0));
-      else DMP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      CoResident guard(lead, s, true);
+      if (guard.status()) return guard.status();
       DMP_HIP(hipMemsetAsync(sync, 0, sizeof(VPSync), s));
       hipLaunchKernelGGL(vgru_persist_kernel, dim3(VP_GRID), dim3(256), VP_LDS_BYTES, s, st, (const VGroupRec*)rec, sync,
                          lead->seq_abort, t_lo, t_hi, nt);
       DMP_LAUNCH_CHECK();
-      DMP_HIP(hipEventRecord(ev, s));
+      int rc = guard.done();
+      if (rc) return rc;
     }
     return DMP_OK;
   }
@@ -942,6 +935,56 @@ int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo,
 
 int gru_vertical(dmp_ctx* c, const uint8_t* d_msa, int N, int L, float* d_out, hipStream_t s) {
   return gru_vertical_steps(c, d_msa, N, L, 0, N + 1, d_out, s);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// CoResident (common.h): per-device launch order of the kernels that wait for their own workgroups
+// ---------------------------------------------------------------------------------------
+namespace {
+struct CoResidentDevice {
+  hipEvent_t persist = nullptr;                       // completion of the most recent persistent launch
+  std::map<dmp_ctx*, hipEvent_t> cluster;             // per context: completion of its most recent cluster kernel
+};
+std::mutex co_mu;
+std::map<int, CoResidentDevice> co_dev;
+}  // namespace
+
+CoResident::CoResident(dmp_ctx* c, hipStream_t s, bool persistent)
+    : c_(c), s_(s), persistent_(persistent), locked_(true), rc_(DMP_OK) {
+  co_mu.lock();
+  CoResidentDevice& d = co_dev[c->device];
+  if (d.persist && hipStreamWaitEvent(s, d.persist, 0) != hipSuccess) rc_ = DMP_ERR_HIP;
+  if (persistent)
+    for (auto& kv : d.cluster)
+      if (hipStreamWaitEvent(s, kv.second, 0) != hipSuccess) rc_ = DMP_ERR_HIP;
+  if (rc_) set_error("hipStreamWaitEvent failed while ordering a co-resident launch");
+}
+
+int CoResident::done() {
+  CoResidentDevice& d = co_dev[c_->device];
+  hipEvent_t& ev = persistent_ ? d.persist : d.cluster[c_];
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) rc_ = DMP_ERR_HIP;
+  if (!rc_ && hipEventRecord(ev, s_) != hipSuccess) rc_ = DMP_ERR_HIP;
+  if (rc_) set_error("hipEventRecord failed while ordering a co-resident launch");
+  locked_ = false;
+  co_mu.unlock();
+  return rc_;
+}
+
+CoResident::~CoResident() {
+  if (locked_) co_mu.unlock();
+}
+
+void coresident_forget(dmp_ctx* c) {
+  std::lock_guard<std::mutex> lock(co_mu);
+  auto it = co_dev.find(c->device);
+  if (it == co_dev.end()) return;
+  auto e = it->second.cluster.find(c);
+  if (e != it->second.cluster.end()) {
+    (void)hipEventDestroy(e->second);
+    it->second.cluster.erase(e);
+  }
 }
 
 }  // namespace dmp

@@ -96,7 +96,10 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * agent-scope stores, the protocol that does not depend on placement.  Same bits, 1.84 against 2.8 us per GRU step.
  * "gj_diag_groups" = 2 / 4 / 8: threads (x 128) of the one-workgroup diagonal sweep of the inverse; same bits; 4 is the
  * default (8.9 against 10.0 ms per inverse at D = 6300 with 2, the form of rounds 1-3).
- * "gj_lookahead" = 0 / 1 / 2: the inverse's look-ahead - the next block step's diagonal sweep and panels on the context's
+ * "gj_pairs" (default 1): the inverse takes its 128-column block steps in pairs - one pass of the trailing update over
+ * the matrix tiles per two steps (119 against 173 ms at D = 21 000, 20.4 against 26.0 at D = 10 500, equal at D = 6300);
+ * 0 = one pass per step.  Same bits.
+ * "gj_lookahead" = 0 / 1 / 2 (with gj_pairs = 0 only): the inverse's look-ahead - the next block step's diagonal sweep and panels on the context's
  * second stream beside this step's trailing update - where one prediction has the device to itself (dmp_predict,
  * dmp_spd_inverse, dmp_dca_features): 0 never, 1 (default) from 64 tile rows on (D > 8064: 23.5 against 25.4 ms at
  * D = 10500; at D = 6300 it loses, 8.7 against 7.7 ms), 2 at every size.  Same bits in every mode.

@@ -121,27 +121,33 @@ def test_dca_features_single_sequence_is_zero(st):
     assert not st.dca_features(a).cpu().numpy().any()
 
 
-def test_spd_inverse_lookahead_is_bitwise_the_serial_order(st_engine):
-    """Option gj_lookahead (round 4): the next block step's diagonal sweep and panels on a second stream beside this
-    step's trailing update, the update issued in two parts - every tile sees the same operations: same bits, for a
-    single block, a ragged last block and the front end's 21 L sizes."""
+def test_spd_inverse_pairs_and_lookahead_are_bitwise_the_serial_order(st_engine):
+    """Option gj_pairs (round 4, the default): two block steps' trailing updates in one pass over the tiles, each step's
+    sum in its own MFMA chain.  Option gj_lookahead (round 4): the next block step's diagonal sweep and panels on a second stream beside this
+    step's trailing update, the update issued in two parts.  Every tile sees the same operations in every form: same
+    bits, for a single block, odd and even numbers of blocks, a ragged last block and the front end's 21 L sizes."""
     st = st_engine
     rng = np.random.default_rng(5)
     try:
-        for D in (100, 128, 300, 21 * 30 + 0, 21 * 61, 1536):
+        for D in (100, 128, 300, 512, 21 * 30 + 0, 21 * 61, 1536):
             X = rng.standard_normal((D, 2 * D)).astype(np.float32)
             A = st.to(X @ X.T / (2 * D) + 0.5 * np.eye(D, dtype=np.float32))
             out = {}
+            st.eng.set_option("gj_pairs", 0)
             for mode in (0, 2):
                 st.eng.set_option("gj_lookahead", mode)
                 out[mode] = st.spd_inverse(A).cpu().numpy()
+            st.eng.set_option("gj_pairs", 1)                 # block steps in pairs (the default): one pass per two steps
+            out["pairs"] = st.spd_inverse(A).cpu().numpy()
             st.eng.sync_check()
             assert np.array_equal(out[0], out[2]), D
+            assert np.array_equal(out[0], out["pairs"]), D
             assert np.abs(out[0] @ A.cpu().numpy() - np.eye(D)).max() < 2e-4
             if D > 128:          # (a single block is the sweep's result as it is; from two blocks on the upper
                 assert np.array_equal(out[0], out[0].T)      # triangle is the mirrored lower one)
     finally:
         st.eng.set_option("gj_lookahead", 1)
+        st.eng.set_option("gj_pairs", 1)
 
 
 def test_spd_inverse_identity_property(st):

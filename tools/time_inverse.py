@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """GPU box: the blocked Gauss-Jordan inverse (dmp_spd_inverse; reference predict.py:53, torch.inverse of the regularised
-covariance) at D = 21 L for L = 300, 500, 1000: time with and without the look-ahead (option gj_lookahead), the rate
-against the f32 MFMA peak, bit-identity of the two forms, residual |A inv(A) - I| against a float64 solve.
+covariance) at D = 21 L for L = 300, 500, 1000: time of its three forms - block steps in pairs (option gj_pairs, the default), single steps with the look-ahead
+(gj_lookahead), single steps in order, the rate
+against the f32 MFMA peak, bit-identity of the forms, residual |A inv(A) - I| against a float64 solve.
 
     python tools/time_inverse.py [L ...]
 """
@@ -27,8 +28,10 @@ for L in Ls:
     A = (X @ X.T / X.shape[1] + 4.5 * torch.eye(D) / np.sqrt(8.0)).float().to(dev)     # covariance-like + the reference's ridge
     del X
     res = {}
-    for la in (1, 0):
-        eng.set_option("gj_lookahead", 2 * la)           # 2: at every size (1 = the library's size policy)
+    modes = {"pairs": (1, 0), "lookahead": (0, 2), "serial": (0, 0)}
+    for name, (pairs, la) in modes.items():
+        eng.set_option("gj_pairs", pairs)
+        eng.set_option("gj_lookahead", la)                # 2: at every size (1 = the library's size policy)
         times = []
         for rep in range(6):
             a = A.clone()
@@ -38,18 +41,18 @@ for L in Ls:
                 _lib.check(eng.lib.dmp_spd_inverse(eng.ctx, a.data_ptr(), D, eng.stream()))
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) * 1e3)
-        res[la] = (a, min(times[1:]))
-    same = bool(torch.equal(res[1][0], res[0][0]))
-    inv = res[1][0]
+        res[name] = (a, min(times[1:]))
+    same = all(bool(torch.equal(res["serial"][0], res[m][0])) for m in ("pairs", "lookahead"))
+    inv = res["pairs"][0]
     sub = slice(0, min(D, 2048))
     err = float(((A[sub].double() @ inv.double())[:, sub] - torch.eye(D, device=dev, dtype=torch.float64)[sub, sub]).abs().max())
     sym = float((inv - inv.T).abs().max())
     flop = float(D) ** 3                                  # symmetric Gauss-Jordan: half of the 2 D^3 of the full one
-    for la in (1, 0):
-        ms = res[la][1]
-        print(f"L={L} D={D} gj_lookahead={la}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s (lower triangle, D^3) = "
+    for name in modes:
+        ms = res[name][1]
+        print(f"L={L} D={D} {name:9s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s (lower triangle, D^3) = "
               f"{flop / ms / 1e9 / 157.3:.3f} of the f32 MFMA peak", flush=True)
-    print(f"L={L} D={D}: look-ahead == serial bitwise: {same}; |A inv - I| max {err:.2e} (first 2048 rows); "
+    print(f"L={L} D={D}: pairs == look-ahead == serial bitwise: {same}; |A inv - I| max {err:.2e} (first 2048 rows); "
           f"|inv - inv^T| max {sym:.1e}", flush=True)
     eng.close()
     del A, res, inv
