@@ -123,6 +123,7 @@ def pin_rank_to_cores(local_rank: int, local_world: int, bdfs=None, sysfs_root: 
     DEFAULT whenever the topology can be read.  Where it cannot, nothing is changed unless DMP_PIN_CORES=1 asks for
     the r-th of `local_world` equal contiguous slices of the core list; DMP_PIN_CORES=0 switches pinning off.  No
     multi-GPU node was available to this build: the effect is unmeasured.
+    Fewer than four cores per rank: nothing is changed (the HIP runtime's helper threads need room beside the scheduler).
     Returns the cores now allowed (unchanged if the affinity was already restricted, the platform has no affinity
     call, or one rank only)."""
     import os
@@ -130,7 +131,7 @@ def pin_rank_to_cores(local_rank: int, local_world: int, bdfs=None, sysfs_root: 
         return []
     cores = sorted(os.sched_getaffinity(0))
     mode = os.environ.get("DMP_PIN_CORES", "")
-    if local_world <= 1 or mode == "0" or len(cores) != (os.cpu_count() or 0) or len(cores) < 2 * local_world:
+    if local_world <= 1 or mode == "0" or len(cores) != (os.cpu_count() or 0) or len(cores) < 4 * local_world:
         return cores
     if bdfs is None:
         bdfs = [device_bdf(i) for i in range(local_world)]
