@@ -89,7 +89,9 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * summation order (results agree to float64 rounding).
  * "tridiag_cluster" (default 1): orders up to 640 run
  * every Householder step in ONE launch on a cluster of 32 workgroups of one XCD; 0 = one launch per step (hipGraph
- * chain).  The two forms produce the same bits; the cluster is faster for one prediction (0.9 against 1.9 ms at
+ * chain).  The same algorithm with the float64 partial sums associated differently: the float32 results are the same bits
+ * on full-rank matrices, the near-null columns of a rank-deficient Gram matrix can differ in their last bits (a
+ * bit-for-bit comparison of two predictions needs the same setting); the cluster is faster for one prediction (0.9 against 1.9 ms at
  * order 300), the launches disturb the convolutions of other contexts less (the multi-engine scheduler sets 0).
  * "cluster_local" (default 1): the cluster kernels (sequence GRU, minimiser, tridiagonalisation) publish their
  * hand-off granules with plain stores when they find all their workgroups on one XCD (run-time check); 0 = always

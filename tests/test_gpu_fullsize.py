@@ -123,6 +123,10 @@ def test_ns_conv_block_vs_conv2d(ns, synth_sd, mode):
 def test_ns_end_to_end_deterministic_and_scheduler_equal(ns, ns_msa, synth_sd):
     """The north-star prediction twice on one engine, and through the 3-engine scheduler: same bits."""
     from dmpfold2_amd.predict import Pipeline
+    # like with like: the scheduler's engines tridiagonalise with one launch per Householder step; the lone engine's
+    # cluster launch is the same algorithm with float64 sums associated differently - the same float32 bits on almost
+    # every matrix, not on all (round 4: a benchmark target's minimised trace told them apart)
+    ns.eng.set_option("tridiag_cluster", 0)
     c1, f1 = ns.eng.predict(ns_msa, None, 10, 100)
     c2, f2 = ns.eng.predict(ns_msa, None, 10, 100)
     ns.eng.sync_check()
@@ -140,8 +144,9 @@ def test_ns_end_to_end_deterministic_and_scheduler_equal(ns, ns_msa, synth_sd):
     same = [bool(torch.equal(res[i][0], c1 if i % 2 == 0 else cb)) and
             bool(torch.equal(res[i][1], f1 if i % 2 == 0 else fb)) for i in range(5)]
     dev_max = [float((res[i][0] - (c1 if i % 2 == 0 else cb)).abs().max()) for i in range(5)]
-    assert all(same), (same, dev_max)
+    ns.eng.set_option("tridiag_cluster", 1)
     pipe.close()
+    assert all(same), (same, dev_max)
 
 
 def test_config1_L200_N1000_prefix_vs_oracle(synth_sd, oracle_weights):
@@ -238,8 +243,10 @@ def test_eigensolver_at_the_largest_order(synth_sd):
 def test_cluster_tridiagonalisation_is_bitwise_the_per_step_launches(synth_sd):
     """Orders up to 640 run every Householder step in ONE launch on a cluster of 32 workgroups of one XCD (rows in LDS,
     products and pivot row handed over per step as granules; option tridiag_cluster, default 1).  It repeats the
-    per-step launches operation for operation: the MDS coordinates must be the same bits.  Orders below, at and
-    above the cluster size, partial last row slots, the largest order."""
+    per-step launches operation for operation except for the association of the float64 partial sums: on these
+    full-rank (noisy) distance matrices the float32 MDS coordinates are the same bits.  (On rank-deficient Gram
+    matrices the near-null columns of the eight can differ in their last bits: tools/eigh_variants_bits.py.)  Orders
+    below, at and above the cluster size, partial last row slots, the largest order."""
     from abi import Stages
     st = Stages(synth_sd, max_L=640, max_N=4)
     try:

@@ -543,14 +543,19 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
                for n, g in zip(names, gs)]
     pipe.drain()
     pipe.sync_check()
-    for n, g, t in zip(names, gs, tickets):
-        coords, confs = pipe.result(t)
-        ref_c, ref_f = st_engine.eng.predict(g["alnmat"], None, *iters[n])
-        st_engine.eng.sync_check()
-        assert torch.equal(coords, ref_c) and torch.equal(confs, ref_f), n
-        if iters[n][1] == 0:
-            assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= 1e-3
-    pipe.close()
+    # like with like: the scheduler's engines tridiagonalise with one launch per Householder step (LIKE_PIPELINE)
+    st_engine.eng.set_option("tridiag_cluster", 0)
+    try:
+        for n, g, t in zip(names, gs, tickets):
+            coords, confs = pipe.result(t)
+            ref_c, ref_f = st_engine.eng.predict(g["alnmat"], None, *iters[n])
+            st_engine.eng.sync_check()
+            assert torch.equal(coords, ref_c) and torch.equal(confs, ref_f), n
+            if iters[n][1] == 0:
+                assert ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1]) <= 1e-3
+    finally:
+        st_engine.eng.set_option("tridiag_cluster", 1)
+        pipe.close()
 
 
 @pytest.mark.parametrize("persistent", [1, 0])
@@ -572,6 +577,7 @@ def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(synth_sd, monkeypatch
     single = Engine(dev, 128, 512)
     single.set_weights(synth_sd)
     single.set_option("vgru_persistent", persistent)
+    single.set_option("tridiag_cluster", 0)                 # as the scheduler's engines (LIKE_PIPELINE)
     pipe = Pipeline(dev, 128, 512, synth_sd, streams=4)
     for e in pipe.engines:
         e.set_option("vgru_persistent", persistent)
@@ -822,6 +828,7 @@ def test_scheduler_results_bitwise_stable_under_corunning_kernels(synth_sd):
     msas = [encode_aln(synth.synth_msa(L, N, seed=40 + i)) for i in range(4)]
     eng = Engine(dev, L, N)
     eng.set_weights(synth_sd)
+    eng.set_option("tridiag_cluster", 0)                    # as the scheduler's engines (LIKE_PIPELINE)
     refs = []
     for m in msas:
         c, f = eng.predict(m, None, 1, 100)

@@ -97,6 +97,18 @@ for persistent in (0, 1):
         times.append((k, timed(run)))
     print(f"L={L} N={N} vgru_persistent={persistent}: one chain for k targets:",
           "  ".join("%d: %.1f ms (%.1f us/row)" % (k, t, t * 1e3 / (N + 1)) for k, t in times), flush=True)
+# at full size too a member's bits do not depend on the chain it ran in, in either form
+for persistent in (1, 0):
+    ref0 = None
+    verdict = []
+    for k in range(1, K + 1):
+        run, outs = chain(msas[:k], persistent)
+        run()
+        torch.cuda.synchronize()
+        if ref0 is None:
+            ref0 = outs[0].clone()
+        verdict.append(bool(torch.equal(outs[0], ref0)))
+    print(f"L={L} N={N} vgru_persistent={persistent}: target 0 in a chain of k = 1..{K} has the bits of k = 1:", verdict, flush=True)
 print("faults:", lead.sync_faults())
 run_p, out_p = chain(msas[:K], 1)
 run_p()
