@@ -72,3 +72,11 @@ print(f"  idle between two convolutions of the SAME engine: {same:.1f} ms; of di
       f"{sum(g for g, a, b, _ in gaps if g > 0 and a != b):.1f} ms")
 print("  longest gaps (ms, engine before -> after, at ms):",
       [(round(g, 2), a, b, round(t)) for g, a, b, t in sorted(gaps, reverse=True)[:12]])
+# time by the number of convolutions in flight (sweep over the interval end points)
+ev = sorted([(a, 1) for a, b, _ in iv] + [(b, -1) for a, b, _ in iv])
+depth, last, at = 0, ev[0][0], {}
+for t, d in ev:
+    at[depth] = at.get(depth, 0.0) + (t - last)
+    depth += d
+    last = t
+print("  time with k convolutions in flight:", "  ".join(f"{k}: {v:.0f} ms ({100 * v / span:.1f} %)" for k, v in sorted(at.items())))
