@@ -15,10 +15,13 @@ collective, only the timing barrier.  `--gpus N` with N > 1 starts the N ranks i
 
 Two arithmetic flavours are measured, each for the full --steps with its own warm-up and its own HIP-event
 intervals around every convolution launch:
-  * `value` / `roofline`: the default convolution, float32 products formed from two f16 pieces per operand
-    (22 significand bits, float32 accumulate) on the f16 matrix cores - tolerance-qualified float32-GRADE arithmetic;
-  * `value_f32` / `roofline_f32`: the exact-f32 MFMA convolution (conv_mode 1, bitwise an fmaf chain) - the
-    reference's own arithmetic type, priced against the 157.3 TFLOP/s f32 matrix-core peak.
+  * `value` / `roofline`: option "precision" 0, the default - convolutions and vertical GRU form float32 products from
+    two f16 pieces per operand (22 significand bits, float32 accumulate) on the f16 matrix cores -
+    tolerance-qualified float32-GRADE arithmetic;
+  * `value_f32` / `roofline_f32`: option "precision" 1 - the reference's own arithmetic type END TO END: the exact-f32 MFMA
+    convolution (conv_mode 1, bitwise an fmaf chain) AND the float32 vertical GRU (v_mfma_f32_16x16x4_f32, library
+    expf / tanhf gates; round 5) - no f16 / bf16 matrix-core kernel runs in this leg; priced against the 157.3 TFLOP/s
+    f32 matrix-core peak.
 Rank 0 prints ONE JSON line with both, a verification of the outputs against the reference's golden vectors for this
 configuration (`verify`), and (N = 1 only) the CPU oracle timed on this host (`cpu_baseline`).
 """
@@ -340,7 +343,8 @@ def main(argv=None):
         by barrier + synchronize; HIP events around every convolution launch of the timed region (recorded on the
         launching streams).  -> (elapsed s, warm-up outputs, timed outputs, launches, mean launch ms, union ms)"""
         for e in pipe.engines:
-            e.set_option("conv_mode", conv_mode)
+            e.set_option("precision", conv_mode)          # 0: split f16; 1: float32 convolutions AND float32 vertical GRU
+            assert e.get_option("precision") == conv_mode and e.get_option("vgru_f32") == conv_mode
         warm = pipe.run(targets[:args.warmup * B], ITERS, MINSTEPS)
         sync_all()
         cap = 16 * (ITERS + 1) * (args.steps * B // S + 2)
@@ -373,7 +377,7 @@ def main(argv=None):
         tot, cnt = sum(b_ - a_ for a_, b_ in iv), len(iv)
         pipe.sync_check()
         for e in pipe.engines:
-            e.set_option("conv_mode", 0)
+            e.set_option("precision", 0)
         return el, warm, timed, cnt, tot, union
 
     only_f32 = args.legs == "f32"
@@ -561,6 +565,23 @@ def main(argv=None):
                 "note": "the two arithmetic flavours on the same target (10 + 100 on random weights: the minimiser on a "
                         "collapsed trace amplifies rounding differences; informational)"}
 
+        # the float32 leg's own check against the reference: bench target 0 at iterations=1, minsteps=0 in precision 1
+        gpath = os.path.join(ROOT, "tests", "golden", "synth_L300_N2000_n1_m0.npz")
+        if rank == 0 and os.path.exists(gpath):
+            g = np.load(gpath)
+            e0.set_option("precision", 1)
+            try:
+                gc, gf = e0.predict_device(targets[0], None, 1, 0)
+                e0.sync_check()
+            finally:
+                e0.set_option("precision", 0)
+            d = gc.cpu().numpy()[:, 1].astype(np.float64) - g["coords"][:, 1].astype(np.float64)
+            rmsd = float(np.sqrt((d ** 2).sum(-1).mean()))
+            dconf = float(np.abs(gf.cpu().numpy() - g["confs"]).max())
+            verify["reference_golden_L300_N2000_n1_m0_precision1"] = {
+                "ca_rmsd_A": rmsd, "max_dconf": dconf, "ok": bool(rmsd <= 1e-3 and dconf < 1e-4)}
+            ok = ok and verify["reference_golden_L300_N2000_n1_m0_precision1"]["ok"]
+
     if distributed:
         vals = [elapsed, exact if exact is not None else 0.0]
         t = torch.tensor(vals, dtype=torch.float64, device=red_device)
@@ -622,7 +643,8 @@ def main(argv=None):
             # `value` / `roofline`: float32-GRADE products from two f16 pieces per operand (22 significand bits) on the f16
             # matrix cores, float32 accumulate - NOT the f32 instruction; `value_f32` / `roofline_f32` (below) are the
             # same workload in exact f32 MFMA arithmetic, the reference's own type
-            "dtype": "f32-grade: 2xf16 split products (22-bit operands), f32 accumulate; exact f32 = value_f32",
+            "dtype": "f32-grade: 2xf16 split products (22-bit operands) in the convolutions and the vertical GRU, f32 "
+                     "accumulate; the reference's f32 arithmetic end to end = value_f32",
             "data": "synthetic",
             "finite_outputs": ok,
             "verify": verify,
@@ -682,7 +704,9 @@ def main(argv=None):
             v = world * args.steps * B / exact
             line["value_f32"] = v
             line["ms_per_step_f32"] = exact / args.steps * 1e3
-            line["dtype_f32"] = "f32 (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain)"
+            line["dtype_f32"] = ("f32 end to end (option precision = 1): convolutions on v_mfma_f32_32x32x2_f32 (bitwise an "
+                                 "fmaf chain), vertical GRU on v_mfma_f32_16x16x4_f32 with library expf / tanhf gates; no "
+                                 "f16 / bf16 matrix-core kernel runs in this leg")
             line["roofline_f32"] = {
                 "kernel": "conv5x5_maxout_kernel (5x5 conv 128->512 + bias + 4-way maxout on the f32 matrix cores)",
                 "bound": "mfma", "achieved": ach1, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -694,7 +718,8 @@ def main(argv=None):
                 "launches_in_flight": tot1 / union1 if union1 > 0 else 0.0, "chip_ms_per_launch": eff1,
                 "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH,
                 "whole_job_conv_tflops": v / world * 16 * (ITERS + 1) * CONV_FLOP_PER_LAUNCH / 1e12,
-                "note": "same workload, scheduler, --steps and --warmup as `value`, convolutions in conv_mode 1; "
+                "note": "same workload, scheduler, --steps and --warmup as `value`, option precision = 1 (conv_mode 1 + "
+                        "float32 vertical GRU); "
                         "achieved = algorithmic FLOP per launch / chip time per launch (union of the HIP-event "
                         "intervals / launches), as for `roofline`"}
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline

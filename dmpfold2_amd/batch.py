@@ -93,18 +93,30 @@ def scan_target(aln_path):
     out one or more rows short for such files, and the engines were then built too small for their deepest
     target).  Every rank scans every target so that all ranks compute the same partition; only the owner of a target
     decodes and encodes it.  An unreadable file scans as (0, 0): its owner reports the error when it reads it."""
+    a3m = aln_path.endswith(".a3m")
+    lines = headers = size = 0
+    head, last, prev_nl = b"", b"", True                  # prev_nl: the byte before this chunk was a newline (or none)
     try:
-        a3m = aln_path.endswith(".a3m")
         with open(aln_path, "rb") as fh:
-            data = fh.read()
+            while True:                                  # fixed-size chunks: a rank never holds a whole multi-GB a3m set
+                chunk = fh.read(1 << 20)
+                if not chunk:
+                    break
+                if len(head) < (1 << 16):
+                    head += chunk[:(1 << 16) - len(head)]
+                size += len(chunk)
+                lines += chunk.count(b"\n")
+                headers += chunk.count(b"\n>") + (1 if prev_nl and chunk.startswith(b">") and (size > len(chunk)) else 0)
+                prev_nl = chunk.endswith(b"\n")
+                last = chunk[-1:]
     except OSError:
         return 0, 0
-    if not data:
+    if not size:
         return 0, 0
-    lines = data.count(b"\n") + (0 if data.endswith(b"\n") else 1)
-    headers = data.count(b"\n>") + (1 if data.startswith(b">") else 0)
+    lines += 0 if last == b"\n" else 1
+    headers += 1 if head.startswith(b">") else 0
     L = 0
-    for raw in data.split(b"\n", 64):                    # the first sequence line is within the first few lines
+    for raw in head.split(b"\n", 64):                    # the first sequence line is within the first few lines
         if not raw.startswith(b">"):
             L = sum(1 for ch in raw.rstrip() if not (a3m and 97 <= ch <= 122))
             break
@@ -167,15 +179,12 @@ class _SharedQueue:
         nth = _SharedQueue._calls.get(tag, 0)
         _SharedQueue._calls[tag] = nth + 1
         self._order, self._store, self._key = list(order), store, f"dmpfold_batch_next/{tag}/{nth}"
-        self._first = True
 
     def take(self):
+        # an exhausted counter is a normal state, also at a rank's FIRST take (more ranks than targets, or a rank that
+        # starts after the others have taken everything): that rank has nothing to do and must still reach the job's
+        # summary reduction, so this never raises
         k = int(self._store.add(self._key, 1)) - 1
-        if self._first:
-            self._first = False
-            if k >= len(self._order) > 0:
-                raise RuntimeError(f"shared work queue {self._key!r} was already exhausted when this rank took its "
-                                   "first target: the ranks of the job are not calling run_batch in step")
         return self._order[k] if k < len(self._order) else None
 
 
@@ -402,6 +411,10 @@ def main(argv=None):
         for aln_path, exc in bf.failed:
             print(f"dmpfold-batch: {aln_path}: {type(exc).__name__}: {exc}", file=sys.stderr)
         n, elapsed, status = bf.n_done, bf.elapsed, 1
+    except Exception as exc:                         # noqa: BLE001 - whatever went wrong on THIS rank, the others are
+        # waiting in job_summary's reduction: report, take part in it, and fail the job through the exit status
+        print(f"dmpfold-batch: rank {rank}: {type(exc).__name__}: {exc}", file=sys.stderr)
+        n, elapsed, status = 0, 0.0, 2
     total, tmax = shard.job_summary(n, elapsed)
     if rank == 0:
         print(json.dumps({"targets": total, "seconds": tmax, "structures_per_s": total / tmax if tmax > 0 else 0.0,

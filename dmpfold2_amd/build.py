@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libdmpfold_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "msa.hip", "dca.hip", "gru.hip", "vgru.hip", "trunk.hip", "train.hip", "mds.hip",
+SOURCES = ["api.hip", "gemm.hip", "msa.hip", "dca.hip", "gru.hip", "vgru.hip", "vgru_f32.hip", "trunk.hip", "train.hip", "mds.hip",
            "coords.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # coords.hip: no SLP vectoriser = no packed-f32 instructions.  The vectoriser turns the cross products of the
@@ -50,7 +50,7 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_bf16.h", "conv_f16.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_bf16.h", "conv_f16.h", "vgru.h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "dmpfold_hip.h"))
     extra = os.environ.get("DMP_EXTRA_HIPCC_FLAGS", "").split()      # tuning experiments (-DVG_CH=1 ...)
     lib = os.environ.get("DMP_LIB_OUT", LIB)

@@ -157,6 +157,26 @@ static int pack_weights(dmp_ctx* c) {
     if ((rc = pieces(wi, l == 0 ? 22 : 512, l == 0 ? 32 : 512, scale, &W.v_wx[l]))) return rc;
     if ((rc = pieces(wh, 512, 512, scale, &W.v_wh[l]))) return rc;
   }
+  {
+    // the same weights as float32 operands of v_mfma_f32_16x16x4_f32 (vgru_f32.hip): one 16-byte load = the four k of a
+    // k quad for one hidden row
+    auto quads = [&](const std::vector<float>& w, float** out) -> int {     // w is [3*512][512]
+      std::vector<float> q((size_t)3 * 128 * 512 * 4);
+      for (int g = 0; g < 3; ++g)
+        for (int j = 0; j < 512; ++j)
+          for (int k = 0; k < 512; ++k)
+            q[(((size_t)g * 128 + k / 4) * 512 + j) * 4 + k % 4] = w[((size_t)g * 512 + j) * 512 + k];
+      return upload(pool, bytes, out, q);
+    };
+    if ((rc = quads(H["vgru.weight_hh_l0"], &W.v_f32[0]))) return rc;
+    if ((rc = quads(H["vgru.weight_ih_l1"], &W.v_f32[1]))) return rc;
+    if ((rc = quads(H["vgru.weight_hh_l1"], &W.v_f32[2]))) return rc;
+    std::vector<float> x0((size_t)3 * 22 * 512);
+    for (int g = 0; g < 3; ++g)
+      for (int code = 0; code < 22; ++code)
+        for (int j = 0; j < 512; ++j) x0[((size_t)g * 22 + code) * 512 + j] = wi0_folded[((size_t)g * 512 + j) * 22 + code];
+    if ((rc = upload(pool, bytes, &W.v_wx0f, x0))) return rc;
+  }
   for (int l = 0; l < 2; ++l) {
     const auto& bi = H["vgru.bias_ih_l" + std::to_string(l)];
     const auto& bh = H["vgru.bias_hh_l" + std::to_string(l)];
@@ -524,6 +544,15 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "gj_diag_groups") { DMP_ARG(value == 2 || value == 4 || value == 8, "gj_diag_groups must be 2, 4 or 8"); ctx->gj_diag_groups = value; return DMP_OK; }
   if (k == "act_scaling") { ctx->act_scaling = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_persistent") { ctx->vgru_persist = value ? 1 : 0; return DMP_OK; }
+  if (k == "vgru_f32") { DMP_ARG(value >= -1 && value <= 1, "vgru_f32 must be -1 (follow conv_mode), 0 or 1"); ctx->vgru_f32 = value; return DMP_OK; }
+  if (k == "precision") {
+    // 0: float32-grade split-f16 products in the convolutions and the vertical GRU (the default); 1: the reference's
+    // arithmetic end to end - float32 MFMAs in both, library gate functions
+    DMP_ARG(value == 0 || value == 1, "precision must be 0 (split f16) or 1 (float32)");
+    ctx->conv_mode = value;
+    ctx->vgru_f32 = -1;
+    return DMP_OK;
+  }
   if (k == "conv_mode") {
     DMP_ARG(value >= 0 && value <= 2, "conv_mode must be 0 (f16x3), 1 (exact f32) or 2 (bf16x6)");
     ctx->conv_mode = value;
@@ -541,6 +570,12 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "act_scaling") { *h_value = ctx->act_scaling; return DMP_OK; }
   if (k == "device_mib") { *h_value = (int)((ctx->bytes + (1 << 20) - 1) >> 20); return DMP_OK; }    // read only
   if (k == "vgru_persistent") { *h_value = ctx->vgru_persist && ctx->vgru_persist_ok; return DMP_OK; }
+  if (k == "vgru_f32") { *h_value = vgru_runs_f32(ctx); return DMP_OK; }          // what the next prediction will run
+  if (k == "precision") {                                                          // 1 / 0, or -1 for a mixed setting
+    const int v = vgru_runs_f32(ctx);
+    *h_value = (ctx->conv_mode == 1 && v) ? 1 : ((ctx->conv_mode != 1 && !v) ? 0 : -1);
+    return DMP_OK;
+  }
   // read-only: 1 once every launch of the group chain this context leads has been issued (the scheduler hands the
   // riders' results over from then on)
   if (k == "chain_issued") { *h_value = ctx->vg_leader == ctx && __atomic_load_n(&ctx->vg_done_issued, __ATOMIC_ACQUIRE) ? 1 : 0; return DMP_OK; }

@@ -89,6 +89,10 @@ struct Weights {
   uint16_t* v_wh[2] = {nullptr, nullptr};  // hidden weights
   float v_inv_scale[2] = {1.f, 1.f};       // 1 / (weight scale * state scale) per layer
   float *v_b0 = nullptr, *v_b1 = nullptr;  // [4][512]: r(bi+bh), z(bi+bh), in(bi), hn(bh)
+  // vertical GRU in float32 (vgru_f32.hip, option "precision" = 1): hh_l0, ih_l1, hh_l1 as [gate 3][k/4 128][512 j][4],
+  // ih_l0 with the embedding folded in as [gate 3][code 22][512 j]
+  float* v_f32[3] = {nullptr, nullptr, nullptr};
+  float* v_wx0f = nullptr;
   GruDirW hgru[2][2];                      // [layer][dir]
   GruDirW cgru[3][2];
   float* fc = nullptr;                     // [3][512]
@@ -152,6 +156,8 @@ struct dmp_ctx {
   uint8_t* vgru_sync = nullptr;            // VPSync of the persistent chain (vgru.hip): XCD arrival counters, row flags
   int vgru_persist = 1;                    // option "vgru_persistent": the chain as ONE weight-stationary launch (0: one launch per row)
   bool vgru_persist_ok = false;            // the device has the 256 CUs the persistent form is laid out for
+  int vgru_f32 = -1;                       // option "vgru_f32": 1 = float32 MFMAs + library gates (vgru_f32.hip), 0 = split-f16
+                                           // products, -1 (default) = follow the convolution: float32 with conv_mode 1
   int vg_ntiles = 0, vg_maxN = 0;          // group this context leads (vgru.hip): column tiles, deepest member alignment
   int vg_tile0[8] = {0};                   // ... first column tile of every member
   int vg_cap_cols = 0;                     // columns the state buffers hold (a group's members side by side)
@@ -280,6 +286,9 @@ int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo,
 // records of all members into the leader's buffer and clears their states, steps runs rows [t_lo, t_hi), output
 // hands a member its L x 512 result.
 int vgru_kernel_attrs(dmp_ctx* c);
+// the vertical GRU of this context's next prediction runs in float32 (vgru_f32.hip) - option "vgru_f32", or following
+// the convolution's mode when that option is -1
+inline int vgru_runs_f32(const dmp_ctx* c) { return c->vgru_f32 >= 0 ? c->vgru_f32 : (c->conv_mode == 1 ? 1 : 0); }
 // Kernels whose workgroups wait for EACH OTHER inside the launch - the cluster kernels (sequence GRU, minimiser,
 // cluster tridiagonalisation: 32 workgroups that hand values over) and the persistent vertical GRU (256 workgroups
 // with row barriers, one per CU) - must not start while another such kernel holds part of what they need: launched

@@ -10,10 +10,15 @@
 // the float32 accumulation of the 3200-term sums dominates both.  Cost: 3 f16 MFMAs per float32
 // MFMA-equivalent = 16/3 = 5.3x the f32 matrix-core rate.
 //
-// Range: activations are used unscaled, |x| must stay below 65504 (f16 max); the producer kernels
-// raise the context's fault flag if they ever see |x| >= 60000 (InstanceNorm keeps the trunk at
-// O(1)..O(100)).  Low pieces of |x| < 0.125 are f16 subnormals: their absolute error <= 3e-8 is far
-// below the float32 accumulation error of the sums they enter.
+// Range and activation scale (round 4).  The pieces are taken of 2^e x, with e chosen per residual block at
+// dmp_weights_finalize (api.hip: the largest e that keeps a bound of the block's input, built from the InstanceNorm
+// gamma / beta of the blocks before it, below 32768; undone exactly, together with the weight scale, in this kernel's
+// epilogue), so the low pieces of the bulk of the activations are NORMAL f16 numbers whatever scale the trunk sits at
+// (unscaled, a value below 0.125 has a subnormal low piece and one below 6e-5 a subnormal high piece: 25 x the
+// float32 kernel's error at trunk scale 2^-16, tests/test_gpu_parity.py::
+// test_unscaled_pieces_lose_precision_on_small_activations).  |2^e x| must stay below 65504 (f16 max): the producer
+// kernels raise the context's fault flag at |2^e x| >= 60000; a trunk that would leave the range unscaled is scaled
+// DOWN instead.  Option "act_scaling" = 0 restores unscaled pieces (e = 0).
 //
 // Workgroup = 4 waves x 32 conv channels x one 16x16 pixel tile (one of 4 channel splits); 8 input stages
 // of 16 channels, whose 20x20 halo tile (both pieces, 30 KB) is brought in by LDS-DMA.

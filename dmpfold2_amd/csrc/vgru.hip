@@ -24,29 +24,12 @@
 //   * one launch PER ROW (round 3, option "vgru_persistent" = 0 and the fallback on other devices): the
 //     group step kernel below, replayed from hipGraph chains of 128 (or 16) nodes.
 #include "common.h"
+#include "vgru.h"
 #include <type_traits>
 #include <map>
 #include <mutex>
 
 namespace dmp {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 vg_f16x8 __attribute__((ext_vector_type(8)));
-
-// Per-context constants of the step kernel (baked into the hipGraph nodes) ...
-struct VStatic {
-  const uint4* wx[2];       // [layer]: input weight pieces   [2][3][KQ][512] x 16 bytes (KQ = 4 / 64)
-  const uint4* wh[2];       // [layer]: hidden weight pieces  [2][3][64][512] x 16 bytes
-  const float* bias[2];     // [layer]: [4][512]: r (b_ir+b_hr), z (b_iz+b_hz), b_in, b_hn
-  float inv_scale[2];
-  float* hT[2][2];          // [layer][parity] float32 state [128][Lb][4]
-  uint16_t* hH[2][2];       // [layer][parity] f16 pieces of 1024*state [2][64][Lb][8]
-};
-constexpr int VG_TB = 32;              // columns per tile
-
-
-// column pitch of a member's state: whole 32-column tiles
-__host__ __device__ inline int vgru_pitch(int L) { return (L + VG_TB - 1) / VG_TB * VG_TB; }
 
 // =====================================================================================================
 // Round 3: the GROUP step kernel.  One launch per alignment row serves the columns of several targets
@@ -85,21 +68,10 @@ constexpr int VG_FRAGS = 6;                               // weight fragments pe
 constexpr int VG_NC = 32 / VG_CK;                         // slots per K = 512 product
 constexpr int VG_RING_SLOTS = VG_R * VG_CK * VG_FRAGS * 64;   // 16-byte slots of one product's ring (36 KB)
 constexpr int VG2_LDS_BYTES = 2 * VG_RING_SLOTS * 16;     // 73 728: two products
-constexpr int VG_MAX_MEMBERS = 8;                         // contexts served by one group launch
-
-// The state of a group lives in the LEADER's buffers as one wide alignment: member m owns the column tiles
-// [tile0, tile0 + ceil(L / 32)), the column pitch is 32 x (number of tiles of the group).  A step kernel therefore
-// derives every address of its main loop from its kernel arguments; the record below (device memory, cold at
-// every kernel start) is only needed for what happens after the loop: is the tile active at this row, and which
-// residue codes does layer 0 read.
-struct VMember { const uint8_t* msa; int N, L, tile0, pad; };
-struct VGroupRec { int t0, t_end, nmem, pad; VMember mem[VG_MAX_MEMBERS]; };
-static_assert(sizeof(VGroupRec) <= 256, "dmp_ctx_create sizes vgru_run for 256 bytes");
 
 __global__ void vgru_set_group_kernel(VGroupRec* rec, VGroupRec v) { *rec = v; }
 __global__ void vgru_set_run2_kernel(VGroupRec* rec, int t0, int t_end) { rec->t0 = t0; rec->t_end = t_end; }
 
-typedef unsigned vg_u32x4 __attribute__((ext_vector_type(4)));
 
 // Gate functions on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): sigma(x) =
 // 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 sigma(-2x).  Absolute error below 2e-7 over the whole range (saturating
@@ -447,16 +419,6 @@ __global__ __launch_bounds__(128 * NW) void vgru2_step_kernel(VStatic st, const 
 // so a member's result is the same bits whatever the grouping; against the per-row kernel (K in 32 ascending k-steps
 // of one accumulator) the results agree to float32 rounding (tests: 1e-5 against the oracle's nn.GRU either way).
 // ---------------------------------------------------------------------------------------------------------------
-typedef float vp_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int VP_WL0_SLOTS = 4 * 4 * 6 * 64;                 // [wave][k-step][piece x gate][lane] 16-byte slots: 98 304 B
-constexpr int VP_RED_SLOTS = 4 * 14 * 64;                    // [wave][accumulator][lane] float4: 57 344 B
-constexpr int VP_TAB_FLOATS = 3 * 24 * 16;                   // [gate][code][row] one-hot input terms: 4 608 B
-constexpr int VP_LDS_BYTES = (VP_WL0_SLOTS + VP_RED_SLOTS) * 16 + VP_TAB_FLOATS * 4;     // 160 256 of 163 840
-constexpr int VP_MAX_XCD_TILES = 64;                           // (+ 1.1 KB of static LDS: the XCD's tile table)
-constexpr int VP_GRID = 256;                                 // one workgroup per CU, 32 per XCD
-struct VPSync { unsigned count[8]; unsigned pad[24]; unsigned flag[8][32]; };              // zeroed before every launch
-static_assert(sizeof(VPSync) == 128 + 1024, "VPSync layout");
-
 __device__ __forceinline__ vp_f32x4 vp_mfma_a(vg_u32x4 a, vg_u32x4 b, vp_f32x4 c) {        // A from an AGPR quad
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "v"(b));
   return c;
@@ -473,6 +435,16 @@ __device__ __forceinline__ void vp_mfma_results_ready(vp_f32x4 (&a)[4][2]) {
                                        "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]));
 }
 
+// ... and the other direction (round 5, found in the float32 form of this kernel, vgru_f32.hip): the compiler sinks the
+// zero-initialisation of an accumulator (v_mov_b64) to just in front of its first assembly MFMA, which it does not know
+// to be a reader with a hazard - there, with nothing in between, the MFMA accumulated onto stale registers.  This
+// kernel's schedule happened to leave one instruction in between (and every test passed); the accumulators are now
+// pinned behind a statement that takes all of them and pads four wait states.  Same arithmetic, same bits.
+__device__ __forceinline__ void vp_accumulators_ready(vp_f32x4 (&a)[4][2]) {
+  asm volatile("s_nop 3" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
+                           "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]));
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* __restrict__ sync, int* __restrict__ fault,
                          int t_lo, int t_hi, int ntiles) {
@@ -480,7 +452,7 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
   uint4* wl0 = reinterpret_cast<uint4*>(vp_smem);
   vp_f32x4* red = reinterpret_cast<vp_f32x4*>(vp_smem + VP_WL0_SLOTS * 16);
   float* tab = reinterpret_cast<float*>(vp_smem + (VP_WL0_SLOTS + VP_RED_SLOTS) * 16);
-  __shared__ int sh_u;
+  __shared__ int sh_u, sh_abort;
   // this XCD's column tiles: {rows N, columns L, first column of the tile in ITS alignment, member} and the members'
   // alignments - from the group record in global memory once per launch (a tile's bookkeeping was a chain of four to
   // six dependent scalar loads at the head of every tile before)
@@ -491,7 +463,10 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
-  if (tid == 0) sh_u = (int)__hip_atomic_fetch_add(&sync->count[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    sh_u = (int)__hip_atomic_fetch_add(&sync->count[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_abort = 0;
+  }
   __syncthreads();
   const int u = sh_u;                                  // this workgroup's hidden-unit slice on its XCD
   if (u >= 32) {                                       // more than 32 workgroups landed on this XCD: another one is short
@@ -635,6 +610,7 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
       for (int g = 0; g < 3; ++g) { a0[g][0] = vp_f32x4{0, 0, 0, 0}; a0[g][1] = vp_f32x4{0, 0, 0, 0}; }
 #pragma unroll
       for (int g = 0; g < 4; ++g) { a1[g][0] = vp_f32x4{0, 0, 0, 0}; a1[g][1] = vp_f32x4{0, 0, 0, 0}; }
+      vp_accumulators_ready(a1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         // (unconditional - the row's last tile requests its own pieces again: behind a branch the compiler cannot count
@@ -742,14 +718,19 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
     if (w == 0) {
       const unsigned* fp = &sync->flag[xcc][lane & 31];
       bool ok = false;
-      for (unsigned spins = 0; spins < 4000000u && !ok; ++spins) {
+      for (unsigned spins = 0; spins < VP_BARRIER_SPINS && !ok; ++spins) {
         unsigned v;
         asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(fp) : "memory");
         ok = __builtin_amdgcn_ballot_w64(v < epoch) == 0ull;
       }
-      if (!ok && lane == 0) atomicOr(fault, DMP_FAULT_VGRU_HANDOFF);
+      if (!ok && lane == 0) { atomicOr(fault, DMP_FAULT_VGRU_HANDOFF); sh_abort = 1; }
     }
     __syncthreads();
+    // A workgroup of this XCD is missing for good (not resident, or one XCD got a 33rd workgroup and another is short):
+    // the fault bit is raised and the outputs of this prediction become NaN - leave the row loop now, the whole
+    // workgroup together, instead of waiting the full bound again at each of the up to 3001 rows that are left
+    // (seconds per row = a GPU that looks hung for hours before dmp_sync_faults returns).
+    if (sh_abort) break;
   }
 }
 
@@ -812,7 +793,7 @@ int vgru_kernel_attrs(dmp_ctx* c) {
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
-  return DMP_OK;
+  return vgru_f32_kernel_attrs(c);
 }
 
 // Group record of n member alignments (their column tiles one after the other in the LEADER's state buffers)
@@ -861,6 +842,7 @@ int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
   if (t_hi > lead->vg_maxN + 1) t_hi = lead->vg_maxN + 1;
   if (t_lo < 0) t_lo = 0;
   if (t_lo & 1) { set_error("vertical-GRU chunks start at even rows (got %d)", t_lo); return DMP_ERR_ARG; }
+  if (vgru_runs_f32(lead)) return vgru_f32_group_steps(lead, t_lo, t_hi, s);
   VGroupRec* rec = reinterpret_cast<VGroupRec*>(lead->vgru_run);
   if (lead->vgru_persist && lead->vgru_persist_ok) {
     // one launch for all the rows: XCD-local row barriers inside (vgru_persist_kernel)

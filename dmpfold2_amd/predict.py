@@ -694,6 +694,12 @@ class Pipeline:
                         coords, confs = eng.predict_device_checked(d_msa, d_tpl, nloops, minsteps)
                         if eng.last_fallback:
                             eng.set_option("conv_mode", 2)
+                        if not eng.get_option("vgru_persistent"):
+                            # the repeat fell back to one vertical-GRU launch per row (another process holds CUs of
+                            # this GPU): the other engines - and a group chain led by one of them - would only
+                            # fault again, target after target
+                            for other in self.engines:
+                                other.set_option("vgru_persistent", 0)
                     except (IndexError, _lib.DmpError) as exc:
                         out[t] = exc
                         continue

@@ -84,6 +84,17 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  *   1            the f32 matrix-core instruction (bitwise an fmaf chain);
  *   2            exact 3-way bf16 split, 6 bf16 MFMA products (no range limit, 2.7x the f32 rate).
  * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default).
+ * "precision" = 0 / 1 (round 5) is the end-to-end switch: 0 = the default above (split-f16 products in the convolutions
+ * AND in the vertical GRU, whose gates use the hardware v_exp_f32 / v_rcp_f32); 1 = the reference's arithmetic
+ * throughout - conv_mode 1 and the float32 vertical GRU (v_mfma_f32_16x16x4_f32 products, the device library's
+ * expf / tanhf in the gates: nn.GRU in float32, network.py:189, 223-224); with it no f16 / bf16 matrix-core kernel runs.
+ * Reads back 1 / 0, or -1 for a mixed setting.
+ * "vgru_f32" = -1 / 0 / 1: the vertical GRU alone; -1 (default) follows the convolution (float32 exactly when
+ * conv_mode is 1, so "conv_mode" 1 and "precision" 1 select the same thing), 0 / 1 force the split-f16 / the float32
+ * form whatever the convolution does.  Reads back what the next prediction will run (0 / 1).  The float32 form costs
+ * 5.3 x the matrix-core time of the split form (41 against 15 ms for one alignment of 2000 x 300, 196 against 72 ms
+ * for a chain of eight); its fallback without the persistent launch ("vgru_persistent" = 0) is the same kernel, one
+ * launch per row, the same bits.
  * "tridiag_single" = 1 runs the Householder tridiagonalisation of the MDS eigensolver in a single
  * workgroup (one launch) instead of one multi-workgroup launch per step; same algorithm, different
  * summation order (results agree to float64 rounding).

@@ -662,6 +662,75 @@ def test_persistent_vertical_gru_vs_oracle_and_launch_chain(st_engine, synth_sd,
         eng.set_option("vgru_persistent", 1)
 
 
+def test_float32_vertical_gru_is_the_references_arithmetic(st_engine, synth_sd, oracle_weights):
+    """Round 5: option "precision" = 1 runs the vertical GRU on float32 MFMAs with library gate
+    functions (vgru_persist_f32_kernel) - nn.GRU's arithmetic (network.py:189, 223-224) - together with the exact-f32
+    convolution.  Against the oracle's nn.GRU on a ragged group at a TIGHTER bound than the split-f16 form's 1e-5; the
+    launch-per-row fallback is the same kernel without the barrier: the same bits; a member's bits do not depend on its
+    group; the option reads back; "vgru_f32" overrides it per context."""
+    import ctypes as C
+    from dmpfold2_amd import _lib, synth
+    from dmpfold2_amd.predict import encode_aln
+    shapes = [(82, 100), (33, 7), (128, 64), (40, 1), (50, 257), (9, 300)]
+    msas = [encode_aln(synth.synth_msa(L, N, 70 + i)) for i, (L, N) in enumerate(shapes)]
+    st = st_engine
+    eng = st.eng
+
+    def chain(ms, persistent):
+        eng.set_option("vgru_persistent", persistent)
+        k = len(ms)
+        d = [st.to(m, torch.uint8) for m in ms]
+        outs = [st.f32(m.shape[1], 512) for m in ms]
+        ctxs = (C.c_void_p * k)(*[eng.ctx] * k)
+        mp = (C.c_void_p * k)(*[x.data_ptr() for x in d])
+        op = (C.c_void_p * k)(*[x.data_ptr() for x in outs])
+        Ns = (C.c_int * k)(*[m.shape[0] for m in ms])
+        Ls = (C.c_int * k)(*[m.shape[1] for m in ms])
+        _lib.check(st.lib.dmp_gru_vertical_group(ctxs, k, mp, Ns, Ls, op, eng.stream()))
+        torch.cuda.synchronize()
+        return outs
+    g64 = torch.nn.GRU(22, 512, num_layers=2).double().eval()               # the same recurrence in float64
+    g64.load_state_dict({k[5:]: v.double() for k, v in oracle_weights.items() if k.startswith("vgru.")})
+    try:
+        assert eng.get_option("precision") == 0 and eng.get_option("vgru_f32") == 0
+        split = chain(msas, 1)
+        eng.set_option("precision", 1)
+        assert eng.get_option("precision") == 1 and eng.get_option("vgru_f32") == 1 and eng.get_option("conv_mode") == 1
+        grouped = chain(msas, 1)
+        assert eng.sync_faults() == 0
+        rows = chain(msas, 0)
+        worst = 0.0
+        for m, a, b, h in zip(msas, grouped, rows, split):
+            x = oracle_weights["embed.weight"][torch.from_numpy(m.astype(np.int64))]
+            ref = O._gru(oracle_weights, "vgru", x, 22, 512, 2, False, False)[-1]
+            with torch.no_grad():
+                ref64 = g64(x.double())[0][-1]
+            worst = max(worst, float((a.cpu() - ref).abs().max()))
+            assert float((a.cpu() - ref).abs().max()) < 3e-6, m.shape          # float32 against float32
+            # ... and as close to the float64 recurrence as the reference's own float32 run is (x 2)
+            assert float((a.cpu().double() - ref64).abs().max()) <= 2.0 * float((ref.double() - ref64).abs().max()) + 1e-7
+            assert torch.equal(a, b), m.shape                                  # per-row launches: the same kernel
+            assert float((a - h).abs().max()) < 1e-5 and not torch.equal(a, h)  # the split-f16 form is another arithmetic
+        print("float32 vertical GRU: max |dev| from the oracle's nn.GRU", worst)
+        for i, m in enumerate(msas):
+            alone = chain([m], 1)[0]
+            assert torch.equal(alone, grouped[i]), i
+            pair = chain([msas[(i + 1) % len(msas)], m], 1)[1]
+            assert torch.equal(pair, grouped[i]), i
+        assert eng.sync_faults() == 0
+        # "vgru_f32" overrides: float32 convolutions with the split-f16 GRU (the round-4 meaning of conv_mode 1) ...
+        eng.set_option("vgru_f32", 0)
+        assert eng.get_option("precision") == -1
+        assert torch.equal(chain(msas[:2], 1)[0], split[0])
+        # ... and back to following the convolution's mode
+        eng.set_option("precision", 0)
+        assert eng.get_option("precision") == 0 and eng.get_option("conv_mode") == 0
+        assert torch.equal(chain(msas[:2], 1)[0], split[0])
+    finally:
+        eng.set_option("precision", 0)
+        eng.set_option("vgru_persistent", 1)
+
+
 def test_gru_vertical_group_stage_call(st, synth_sd):
     """dmp_gru_vertical_group (the stage-level form): three alignments of different shape through one chain,
     each result bit-identical to dmp_gru_vertical alone and within 1e-5 of the oracle's GRU."""

@@ -624,6 +624,80 @@ def test_shared_work_queue_over_gloo_world_size_2(tmp_path):
     assert len(os.listdir(tmp_path / "out")) == 40
 
 
+class _FakeStore:
+    """torch.distributed.Store.add semantics for the host-logic tests"""
+
+    def __init__(self):
+        self.kv = {}
+
+    def add(self, key, n):
+        self.kv[key] = self.kv.get(key, 0) + n
+        return self.kv[key]
+
+
+def test_shared_queue_exhausted_at_first_take_is_not_an_error():
+    """8 ranks and 5 targets - or a rank that starts after the others took everything - find the
+    counter past the end at their FIRST take.  That rank has nothing to do; it must not raise (it would skip the job's
+    summary reduction and hang the other ranks)."""
+    from dmpfold2_amd import batch
+    store = _FakeStore()
+    queues = [batch._SharedQueue(list(range(5)), store, "job") for _ in range(8)]
+    batch._SharedQueue._calls.pop("job", None)         # the eight objects stand for eight processes' first queue
+    for q in queues:
+        q._key = "dmpfold_batch_next/job/0"
+    got = [q.take() for q in queues]
+    assert sorted(x for x in got if x is not None) == [0, 1, 2, 3, 4] and got[5:] == [None, None, None]
+    assert all(q.take() is None for q in queues)       # and stays exhausted, quietly
+
+
+def test_run_batch_rank_without_targets_returns_empty(tmp_path):
+    """the same through run_batch: the late rank returns (0, 0.0, [])-like counts instead of raising"""
+    from dmpfold2_amd import batch
+    d = tmp_path / "msas"
+    d.mkdir()
+    targets = _write_synth_targets(d, 3)
+    store = _FakeStore()
+    real = batch.Pipeline
+    batch.Pipeline = _FakePipeline
+    try:
+        n0, _, outs0 = batch.run_batch(targets, str(tmp_path / "o"), 1, 0, state_dict={}, device="cpu", rank=0, world=2,
+                                       store=store)
+        batch._SharedQueue._calls.clear()              # rank 1 is another process: its first queue over this list
+        n1, _, outs1 = batch.run_batch(targets, str(tmp_path / "o"), 1, 0, state_dict={}, device="cpu", rank=1, world=2,
+                                       store=store)
+    finally:
+        batch.Pipeline = real
+    assert n0 == 3 and len(outs0) == 3 and n1 == 0 and outs1 == []
+
+
+def test_scan_target_counts_in_chunks(tmp_path):
+    """scan_target reads fixed-size chunks; a header line that starts exactly at a chunk boundary, a missing
+    final newline and CRLF blanks are counted as the whole-file scan counted them."""
+    from dmpfold2_amd import batch
+    row = b"ACDEFGHIKLMNPQRSTVWY" * 5                   # 100 columns
+    for tail in (b"\n", b""):
+        for pad in (0, 1, 2):
+            # headers so long that a '>' lands on byte 1 << 20 exactly for one of the pads
+            body = b""
+            n_rows = 0
+            while len(body) < (1 << 20) - 200:
+                body += b">s%d\n" % n_rows + row + b"\n"
+                n_rows += 1
+            fill = (1 << 20) - len(body) - 1 + pad
+            body += b">" + b"x" * (fill - 2) + b"\n"   # a header that ends right at / around the boundary
+            body += b">next\n" + row + b"\n>last\n" + row + tail
+            n_rows += 3
+            p = tmp_path / f"t{pad}{len(tail)}.aln"
+            p.write_bytes(body)
+            data = p.read_bytes()
+            want = (data.count(b"\n") + (0 if data.endswith(b"\n") else 1)) - (data.count(b"\n>") + 1)
+            assert batch.scan_target(str(p)) == (100, want), (pad, tail)
+    a3m = tmp_path / "x.a3m"
+    a3m.write_bytes(b">q\nACDaaEF-G\n>h\nAC-EFGG\n")
+    assert batch.scan_target(str(a3m)) == (7, 2)
+    assert batch.scan_target(str(tmp_path / "missing.aln")) == (0, 0)
+
+
 def test_core_slices_follow_the_numa_node_of_each_gpu(tmp_path):
     """shard.plan_core_slices / gpu_local_cores on a made-up sysfs tree: 8 GPUs, four per NUMA node, 2 x 16 cores -
     every rank gets 4 cores of ITS GPU's node, disjoint; a GPU whose node is not stated (-1) is left alone."""

@@ -1,18 +1,26 @@
 #!/usr/bin/env python
-"""GPU box: time the other configurations of BASELINE.json on one MI355X.
+"""GPU box: every configuration of BASELINE.json on one MI355X, each with a roofline fraction of
+its dominant kernel - in both arithmetic settings (option "precision" 0: split-f16 products, 1: the reference's float32).
 
-    python tools/bench_configs.py [--c4 256]
+    python tools/bench_configs.py [--c4 256] [--skip-c5-f32]  > profiles/r05_configs.jsonl
 
 C1  PF10963 (L=82, N=252), -n 0 -m 0             single target, latency
-C2  L=200, N=1000, 10 + 100                       single target, latency and 4-stream throughput
+C2  L=200, N=1000, 10 + 100                       single target latency; 12 targets through the 4-engine scheduler
 NS  L=300, N=2000, 10 + 100                       (bench.py's workload) single-target latency
 C3  L=500, N=5000 -> 3000, 30 + 200               single target, latency
-C4  256 targets, L uniform in [100, 300], N=2000  4-stream scheduler, structures/s
+C4  256 targets, L uniform in [100, 300], N=2000  4-engine scheduler, structures/s
 C5  L=1000, N=2000, 100 + 1000                    single target, latency
-Prints one JSON line per configuration.  Weights: synthetic seed 0; inputs: synth_msa.
+One JSON line per (configuration, precision).  Per line: seconds per structure; the convolution's chip time per launch
+from the HIP events recorded on the launching stream around every launch (dmp_profile_*: union of the intervals /
+launches, as bench.py); `frac` = 2*128*512*25*L^2 FLOP / that time against the f16 dense peak / 3 (precision 0: three
+f16 MFMA products per float32 product) or the 157.3 TFLOP/s f32 MFMA peak (precision 1); the tile quantisation of the
+launch - (ceil(L/16))^2 pixel tiles x 4 channel splits workgroups on 512 slots (2 per CU) - and the fraction of the
+tile area that is real pixels.  Weights: synthetic seed 0; inputs: synth_msa.
 """
 import argparse
+import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -23,25 +31,64 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see bench.py
-from dmpfold2_amd import synth                       # noqa: E402
+from dmpfold2_amd import synth, _lib                 # noqa: E402
 from dmpfold2_amd.predict import Engine, Pipeline, encode_aln, read_aln   # noqa: E402
 
+PEAK = {0: 2500.0 / 3.0, 1: 157.3}                   # TFLOP/s the algorithmic float32 FLOPs are priced against
+lib = _lib.load()
 
-def single(eng, msa, n, m, reps=2):
+
+def union_ms(iv):
+    tot, end = 0.0, -1e30
+    for a, b in sorted(iv):
+        if b > end:
+            tot += b - max(a, end)
+            end = b
+    return tot
+
+
+def conv_intervals(engines, cap):
+    iv = []
+    for e in engines:
+        a, b, n = (C.c_float * cap)(), (C.c_float * cap)(), C.c_int()
+        _lib.check(lib.dmp_profile_conv_intervals(e.ctx, engines[0].ctx, a, b, cap, C.byref(n)))
+        iv += [(a[i], b[i]) for i in range(n.value)]
+    return iv
+
+
+def quantisation(L):
+    t = math.ceil(L / 16)
+    wgs = 4 * t * t
+    return {"pixel_tiles": t * t, "workgroups": wgs, "rounds_of_512": wgs / 512.0,
+            "slot_fill_of_last_round": round(wgs / (math.ceil(wgs / 512) * 512), 3),
+            "real_pixels_per_tile_area": round(L * L / float(t * t * 256), 3)}
+
+
+def single(eng, msa, n, m, reps, warm=True):
     d = torch.from_numpy(msa).cuda()
-    eng.predict_device(d, None, n, m)
-    eng.sync_check()
+    L = msa.shape[1]
+    if warm:
+        eng.predict_device(d, None, min(n, 1), min(m, 5))
+        eng.sync_check()
+    cap = 16 * (n + 1) * reps + 16
+    _lib.check(lib.dmp_profile_enable(eng.ctx, 1, cap))
     t0 = time.perf_counter()
     for _ in range(reps):
         out = eng.predict_device(d, None, n, m)
     eng.sync_check()
+    dt = (time.perf_counter() - t0) / reps
+    iv = conv_intervals([eng], cap)
+    _lib.check(lib.dmp_profile_enable(eng.ctx, 0, 0))
     assert bool(torch.isfinite(out[0]).all())
-    return (time.perf_counter() - t0) / reps
+    ms = union_ms(iv) / max(1, len(iv))
+    flop = 2.0 * 128 * 512 * 25 * L * L
+    return dt, ms, flop / (ms * 1e-3) / 1e12 if ms else 0.0, len(iv)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c4", type=int, default=256)
+    ap.add_argument("--skip-c5-f32", action="store_true", help="C5 in float32 takes about 40 s of GPU time")
     ap.add_argument("--scheduler-only", action="store_true", help="skip the single-target latencies")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -50,47 +97,60 @@ def main():
     def report(name, **kw):
         print(json.dumps({"config": name, **kw}), flush=True)
 
-    pf = os.path.join(ROOT, "tests", "golden", "PF10963.aln")
-    if args.scheduler_only:
-        return scheduler_configs(args, dev, sd, report)
-    eng = Engine(dev, 1000, 3000)
-    eng.set_weights(sd)
-    t = single(eng, encode_aln(read_aln(pf)), 0, 0, reps=5)
-    report("C1 PF10963 L=82 N=252 n=0 m=0", seconds_per_structure=t)
-    for name, L, N, n, m, reps in [("C2 L=200 N=1000 10+100", 200, 1000, 10, 100, 3),
-                                   ("NS L=300 N=2000 10+100", 300, 2000, 10, 100, 3),
-                                   ("C3 L=500 N=5000->3000 30+200", 500, 3000, 30, 200, 2),
-                                   ("C5 L=1000 N=2000 100+1000", 1000, 2000, 100, 1000, 1)]:
-        msa = encode_aln(synth.synth_msa(L, N, seed=1))
-        t = single(eng, msa, n, m, reps=reps)
-        report(name, seconds_per_structure=t, structures_per_s_single_stream=1.0 / t)
-    eng.close()
-    return scheduler_configs(args, dev, sd, report)
+    if not args.scheduler_only:
+        eng = Engine(dev, 1000, 3000)
+        eng.set_weights(sd)
+        pf = encode_aln(read_aln(os.path.join(ROOT, "tests", "golden", "PF10963.aln")))
+        cases = [("C1 PF10963 L=82 N=252 n=0 m=0", pf, 0, 0, 5),
+                 ("C2 L=200 N=1000 10+100", encode_aln(synth.synth_msa(200, 1000, seed=1)), 10, 100, 3),
+                 ("NS L=300 N=2000 10+100", encode_aln(synth.synth_msa(300, 2000, seed=1)), 10, 100, 3),
+                 ("C3 L=500 N=5000->3000 30+200", encode_aln(synth.synth_msa(500, 3000, seed=1)), 30, 200, 2),
+                 ("C5 L=1000 N=2000 100+1000", encode_aln(synth.synth_msa(1000, 2000, seed=1)), 100, 1000, 1)]
+        for prec in (0, 1):
+            eng.set_option("precision", prec)
+            for name, msa, n, m, reps in cases:
+                if prec == 1 and name.startswith("C5") and args.skip_c5_f32:
+                    continue
+                L = msa.shape[1]
+                dt, ms, tf, cnt = single(eng, msa, n, m, reps)
+                report(name, precision=prec, seconds_per_structure=dt, structures_per_s_single_stream=1.0 / dt,
+                       conv_chip_ms_per_launch=ms, conv_launches_timed=cnt, conv_tflops=tf, peak_tflops=PEAK[prec],
+                       frac=tf / PEAK[prec], conv_share_of_time=ms * 1e-3 * 16 * (n + 1) / dt, **quantisation(L))
+        eng.close()
 
-
-def scheduler_configs(args, dev, sd, report):
+    # ---- through the 4-engine scheduler
     pipe = Pipeline(dev, 300, 2000, sd, streams=4)
-    tg = [torch.from_numpy(encode_aln(synth.synth_msa(200, 1000, seed=10 + i))).to(dev) for i in range(12)]
-    pipe.run(tg[:3], 10, 100)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pipe.run(tg, 10, 100)
-    torch.cuda.synchronize()
-    report("C2 x12 through the 4-stream scheduler", structures_per_s=12 / (time.perf_counter() - t0))
-
+    c2 = [torch.from_numpy(encode_aln(synth.synth_msa(200, 1000, seed=10 + i))).to(dev) for i in range(12)]
     rng = np.random.default_rng(0)
     lens = rng.integers(100, 301, size=args.c4)
-    tg = [torch.from_numpy(encode_aln(synth.synth_msa(int(L), 2000, seed=1000 + i))).to(dev)
-          for i, L in enumerate(lens)]
-    order = sorted(range(len(tg)), key=lambda i: -int(lens[i]))          # longest first, as shard.py deals them
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pipe.run([tg[i] for i in order], 10, 100)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    pipe.sync_check()
-    report(f"C4 {args.c4} targets L in [100,300] N=2000 10+100, one GPU", seconds=dt,
-           structures_per_s=args.c4 / dt, mean_L=float(lens.mean()))
+    c4 = [torch.from_numpy(encode_aln(synth.synth_msa(int(L), 2000, seed=1000 + i))).to(dev) for i, L in enumerate(lens)]
+    order = sorted(range(len(c4)), key=lambda i: -int(lens[i]))          # longest first, as shard.py deals them
+    for prec in (0, 1):
+        for e in pipe.engines:
+            e.set_option("precision", prec)
+        for name, tg, flops in (("C2 x12 through the 4-engine scheduler", c2, [2.0 * 128 * 512 * 25 * 200 * 200] * 12),
+                                (f"C4 {args.c4} targets L in [100,300] N=2000 10+100 through the 4-engine scheduler",
+                                 [c4[i] for i in order], [2.0 * 128 * 512 * 25 * float(lens[i]) ** 2 for i in order])):
+            if prec == 1 and name.startswith("C4"):
+                tg, flops = tg[:64], flops[:64]          # (the 64 longest: a quarter of the job is enough for the rate)
+            pipe.run(tg[:3], 10, 100)
+            torch.cuda.synchronize()
+            cap = 16 * 11 * (len(tg) // 4 + 8)
+            for e in pipe.engines:
+                _lib.check(lib.dmp_profile_enable(e.ctx, 1, cap))
+            t0 = time.perf_counter()
+            pipe.run(tg, 10, 100)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            iv = conv_intervals(pipe.engines, cap)
+            for e in pipe.engines:
+                _lib.check(lib.dmp_profile_enable(e.ctx, 0, 0))
+            pipe.sync_check()
+            u = union_ms(iv)
+            tf = 176.0 * sum(flops) / (u * 1e-3) / 1e12 if u else 0.0
+            report(name, precision=prec, targets=len(tg), seconds=dt, structures_per_s=len(tg) / dt,
+                   mean_L=float(np.mean([t.shape[1] for t in tg])), conv_launches_timed=len(iv),
+                   conv_busy_share_of_time=u * 1e-3 / dt, conv_tflops_while_busy=tf, peak_tflops=PEAK[prec], frac=tf / PEAK[prec])
     pipe.close()
     return 0
 

@@ -3,7 +3,7 @@
 launch chain of rounds 2-3 (= 0): results (max |difference|, grouping bit-identity, a small case against the oracle's
 nn.GRU) and the time of one chain serving k = 1 .. K targets.
 
-    python tools/time_vgru_persist.py [K=8] [L=300] [N=2000]
+    [VGRU_F32=1] python tools/time_vgru_persist.py [K=8] [L=300] [N=2000]
 """
 import ctypes as C
 import os
@@ -27,7 +27,9 @@ sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_
 lead = Engine(dev, L, N, stream=torch.cuda.Stream(dev))
 lead.set_weights(sd)
 lib = lead.lib
-print("persistent form available:", lead.get_option("vgru_persistent"), flush=True)
+if os.environ.get("VGRU_F32") == "1":                    # the float32 form (vgru_f32.hip) instead of the split-f16 one
+    lead.set_option("vgru_f32", 1)
+print("persistent form available:", lead.get_option("vgru_persistent"), " float32:", lead.get_option("vgru_f32"), flush=True)
 
 
 def chain(msas, persistent):
