@@ -37,8 +37,10 @@ SIGNATURES = {
     "dmp_stem_update": (_i, [_vp, _fp, _fp, _i, _fp, _vp]),
     "dmp_block_conv5x5_maxout": (_i, [_vp, _i, _fp, _i, _fp, _fp, _vp]),
     "dmp_block_norm_scse_residual": (_i, [_vp, _i, _fp, _fp, _fp, _i, _fp, _vp]),
-    "dmp_block_conv5x5_maxout_bwd": (_i, [_vp, _i, _fp, _fp, _i, _fp, _fp, _fp, _vp]),
+    "dmp_block_conv5x5_maxout_bwd": (_i, [_vp, _i, _fp, _fp, _vp, _i, _fp, _fp, _fp, _vp]),
+    "dmp_block_conv5x5_maxout_winners": (_i, [_vp, _i, _fp, _i, _fp, _vp, _vp]),
     "dmp_block_norm_scse_residual_bwd": (_i, [_vp, _i, _fp, _fp, _i, _fp, _fp, _vp]),
+    "dmp_head_conv_bwd": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_head_gram": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
     "dmp_trunk_pass": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_eigh_top8": (_i, [_vp, _fp, _i, _fp, _vp]),
@@ -62,7 +64,7 @@ SIGNATURES = {
     "dmp_profile_conv_intervals": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
 }
 
-ABI_VERSION = 3      # include/dmpfold_hip.h DMP_ABI_VERSION
+ABI_VERSION = 4      # include/dmpfold_hip.h DMP_ABI_VERSION
 
 _lib = None
 

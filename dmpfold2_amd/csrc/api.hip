@@ -614,7 +614,6 @@ void dmp_ctx_destroy(dmp_ctx* c) {
   if (!c) return;
   coresident_forget(c);
   if (c->bwd_ws) (void)hipFree(c->bwd_ws);
-  if (c->bwd_w) (void)hipFree(c->bwd_w);
   for (void* p : c->allocs) (void)hipFree(p);
   release_weights(c);
   for (void* e : c->prof_ev) (void)hipEventDestroy((hipEvent_t)e);
@@ -853,12 +852,20 @@ int dmp_block_norm_scse_residual(dmp_ctx* ctx, int block, const float* d_u, cons
   return act_unpad(ctx->xb, L, d_out, STREAM);
 }
 
-int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, const float* d_du, int L, float* d_dx,
-                                 float* d_dw, float* d_db, void* stream) {
+int dmp_block_conv5x5_maxout_winners(dmp_ctx* ctx, int block, const float* d_x, int L, float* d_u, uint8_t* d_idx,
+                                     void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(block >= 1 && block <= NBLOCK && d_x && d_u && d_idx, "bad argument");
+  return conv5x5_maxout_fwd_winners(ctx, block, d_x, L, d_u, d_idx, STREAM);
+}
+
+int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, const float* d_du, const uint8_t* d_idx, int L,
+                                 float* d_dx, float* d_dw, float* d_db, void* stream) {
   CHECK_CAP(L, 1);
   CHECK_W();
   DMP_ARG(block >= 1 && block <= NBLOCK && d_x && d_du && d_dx && d_dw && d_db, "bad argument");
-  return conv5x5_maxout_bwd(ctx, block, d_x, d_du, L, d_dx, d_dw, d_db, STREAM);
+  return conv5x5_maxout_bwd(ctx, block, d_x, d_du, d_idx, L, d_dx, d_dw, d_db, STREAM);
 }
 
 int dmp_block_norm_scse_residual_bwd(dmp_ctx* ctx, int block, const float* d_u, const float* d_dout, int L,
@@ -867,6 +874,13 @@ int dmp_block_norm_scse_residual_bwd(dmp_ctx* ctx, int block, const float* d_u, 
   CHECK_W();
   DMP_ARG(block >= 1 && block <= NBLOCK && d_u && d_dout && d_du && d_dparams, "bad argument");
   return norm_scse_residual_bwd(ctx, block, d_u, d_dout, L, d_du, d_dparams, STREAM);
+}
+
+int dmp_head_conv_bwd(dmp_ctx* ctx, const float* d_x, const float* d_g, int L, float* d_dx, float* d_dparams, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_x && d_g && d_dx && d_dparams, "null argument");
+  return head_conv_bwd(ctx, d_x, d_g, L, d_dx, d_dparams, STREAM);
 }
 
 int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M, void* stream) {

@@ -207,10 +207,9 @@ struct dmp_ctx {
   double* part = nullptr;   // [tiles][128][2]
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm
-  float* bwd_ws = nullptr;     // training-side slice (train.hip): patch matrix + conv output + routed
-  int64_t bwd_ws_floats = 0;   // gradient, allocated on first use
-  float* bwd_w = nullptr;      // [512][3200] raw weights of block bwd_w_block
-  int bwd_w_block = 0;
+  float* bwd_ws = nullptr;     // training-side slice (train.hip): the one workspace of both backward halves, allocated at
+  int64_t bwd_ws_floats = 0;   // the first call for max_L
+  int bwd_w_block = 0;         // the block whose flipped weight pack the workspace holds (0: none)
   float* head0 = nullptr;   // [L][L] head channel 0 (distances)
   float* head1 = nullptr;   // [L][L] head channel 1 (confidence logits)
   bool head_current = false;   // the last block's norm kernel already wrote head0 / head1 of the current activations
@@ -322,12 +321,15 @@ int stem_update_padded(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L
 int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u,
                           double* d_stats, hipStream_t s, bool reduce);
 int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s, int block = 0);
+int conv5x5_maxout_winners(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u, uint8_t* d_idx, hipStream_t s);
 int norm_scse_residual_padded(dmp_ctx* c, int block, const float* d_u, const double* d_stats,
                               const float* d_xpad_in, int L, float* d_xpad_out, hipStream_t s, bool head = false);
-int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_du, int L, float* d_dx, float* d_dw,
-                       float* d_db, hipStream_t s);
+int conv5x5_maxout_fwd_winners(dmp_ctx* c, int block, const float* d_x, int L, float* d_u, uint8_t* d_idx, hipStream_t s);
+int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_du, const uint8_t* d_idx, int L, float* d_dx,
+                       float* d_dw, float* d_db, hipStream_t s);
 int norm_scse_residual_bwd(dmp_ctx* c, int block, const float* d_u, const float* d_dout, int L, float* d_du,
                            float* d_dparams, hipStream_t s);
+int head_conv_bwd(dmp_ctx* c, const float* d_x, const float* d_g, int L, float* d_dx, float* d_dparams, hipStream_t s);
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
                      hipStream_t s);
 int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);

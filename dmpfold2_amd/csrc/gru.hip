@@ -57,7 +57,13 @@ struct SeqArgs {
 };
 
 // grid: 8 * SEQ_G blocks (only ids with (id % 8 - xcd0) % 8 < 2 work: that is the direction)   block: 256
+#ifndef SEQ_PRIO
+#define SEQ_PRIO 0
+#endif
 __global__ __launch_bounds__(256) void seq_gru_kernel(SeqArgs a) {
+#if SEQ_PRIO
+  __builtin_amdgcn_s_setprio(SEQ_PRIO);
+#endif
   __shared__ __attribute__((aligned(16))) float hs[4][HID2];
   __shared__ int sh_local;
   const int dir = ((int)(blockIdx.x & 7) - a.xcd0) & 7, g = blockIdx.x >> 3;

@@ -1,142 +1,452 @@
 // Training-side slice (reference train.py:318-344 runs autograd through every ResNet_Block,
-// network.py:85-103): the backward of ONE residual block as two entry points that mirror the forward's two kernels,
+// network.py:85-103): the backward of a residual block as two entry points that mirror the forward's two kernels,
 //   dmp_block_norm_scse_residual_bwd   d(out) -> d(u), d(gamma, beta, cSE fc, sSE conv)      (this file, second half)
 //   dmp_block_conv5x5_maxout_bwd       d(u)   -> d(x), d(W), d(b)                            (this file, first half)
-// and the residual branch is the identity: d(block input) = d(x) of the convolution + d(out).
-// Parity-first, float32 arithmetic with float64 reductions; none of this is on the inference path (the workspace is
-// allocated on first use, outside the "no allocation after dmp_ctx_create" rule of the prediction entry points).
+// the residual branch is the identity: d(block input) = d(x) of the convolution + d(out); and the 1x1 head's backward
+// (dmp_head_conv_bwd), so that a test can chain the sixteen blocks and the head of net.resnet.
+// EVALUATION MODE ONLY: in training mode the reference's ResNet_Block applies Dropout(0.2) / Dropout2d(0.2) ahead of
+// layer1 (network.py:85-103); neither the masks nor their backward exist here.
+// float32 arithmetic (exact-f32 matrix cores: an MFMA chain is an fmaf chain) with float64 reductions; none of this is on
+// the inference path.  One workspace per context, sized for the context's max_L at the first call (no reallocation
+// when L changes between calls).
 #include "common.h"
 
 #pragma clang fp contract(off)
 
 namespace dmp {
 
-static int bwd_workspace(dmp_ctx* c, int64_t need_floats) {
-  if (c->bwd_ws_floats >= need_floats) return DMP_OK;
-  if (c->bwd_ws) (void)hipFree(c->bwd_ws);
-  c->bwd_ws = nullptr;
-  c->bwd_ws_floats = 0;
-  DMP_HIP(hipMalloc((void**)&c->bwd_ws, sizeof(float) * (size_t)need_floats));
-  c->bwd_ws_floats = need_floats;
-  return DMP_OK;
-}
+typedef float tr_f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------
 // First half (network.py:25-31): backward of a block's convolution + maxout,  u[g] = max_q (conv(x, W)[4g+q] + b[4g+q]).
 //   dz[4g+q] = du[g] where q is the FIRST maximal channel of the quadruple (torch.max), 0 elsewhere
-//   dW[o][c,tap] = sum_p dz[o][p] x[c][p + tap]        (wgrad: GEMM over the pixels)
 //   db[o]        = sum_p dz[o][p]
-//   dx[c][p]     = sum_{o,tap} W[o][c,tap] dz[o][p - tap]   (dgrad: GEMM + gather)
-// Parity-first form: the 25-tap patches as an explicit matrix (im2col, 3200 x L^2) and three products on the float32
-// matrix cores (gemm_f32: exact fmaf chains); the winners are recomputed with the same float32 product, so a
-// near-tie can resolve differently from the inference kernels' split-f16 sums (measure-zero for the gradients' checks).
-// Workspace (3200 + 1024) x L^2 floats, allocated on first use (this entry point is outside the inference path's
-// "no allocation after dmp_ctx_create" rule).
+//   dx[c][p]     = sum_{o,tap} W[o][c,tap] dz[o][p - tap]   (dgrad)
+//   dW[o][c,tap] = sum_p dz[o][p] x[c][p + tap]             (wgrad)
+// Round 5: implicit GEMMs on the float32 matrix cores in the forward kernel's tile structure, no patch matrix (round 4:
+// im2col (3200 + 1024) L^2 floats = 1.5 GB at L = 300 and three library-style GEMMs).  The routed gradient dz is never
+// materialised either: it is 75 % structural zeros, so it travels in GATHERED form - du (128 planes) + the winner of
+// every quadruple (one byte per maxout channel and pixel, written by the forward kernel's <IDX> instantiation) - and is
+// expanded to its dense (channel pair x halo tile) form only in LDS, where the MFMAs read it.  (The FLOPs stay dense:
+// which of a quadruple's four weight rows a pixel uses differs from pixel to pixel, and an MFMA's A operand is shared by
+// its 32 pixel columns.  The 1-of-4 pattern is a special case of the 2:4 sparsity v_smfmac accepts on its A operand -
+// half the dense work, f16 only - not built.)
+//   1. winners   conv5x5_maxout_kernel<true> (trunk.hip) on the padded input: the forward in float32 + idx
+//   2. db        per maxout channel four float64 sums over the pixels
+//   3. dgrad     conv5x5_dgrad_kernel: "a 5x5 convolution 512 -> 128 with flipped taps" - M = 64 of the 128 input
+//                channels per workgroup, N = one 16x16 pixel tile, K = 256 stages of (2 convolution channels x 25 taps);
+//                722 workgroups at L = 300, four per CU
+//   4. wgrad     conv5x5_wgrad_kernel: K = the PIXELS; workgroup = 32 convolution channels x 32 input channels x 25 taps
+//                (five waves, one tap row each: five accumulators), looping over 8 x 16 pixel tiles whose dz tile and
+//                x halo tile it stages in LDS (next tile requested under this tile's MFMAs); the tiles are split over
+//                WG_KSPLIT workgroups whose partial sums are reduced in fixed order (deterministic)
+// Workspace: the padded input (128 P^2 floats: 1.06 activation tensors), the winners when the caller did not keep them
+// (128 L^2 bytes: a quarter), and an L-independent 85 MB - the flipped weight pack (6.8 MB) and the wgrad partial sums
+// (WG_KSPLIT x 6.5 MB): 145 MB at L = 300, 165 MB at the 350 crop (round 4: 1.5 GB / 2.1 GB).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bwd_im2col_kernel(const float* __restrict__ x, int L, float* __restrict__ col) {
-  const int r = blockIdx.y;                              // c * 25 + tap
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int LL = L * L;
-  if (p >= LL) return;
-  const int c = r / 25, tap = r % 25, dy = tap / 5 - 2, dx = tap % 5 - 2;
-  const int y = p / L + dy, xx = p % L + dx;
-  col[(int64_t)r * LL + p] = (y >= 0 && y < L && xx >= 0 && xx < L) ? x[(int64_t)c * LL + y * L + xx] : 0.f;
+constexpr int DG_MB = 2;                          // 32-row MFMA blocks per workgroup
+constexpr int DG_M = 32 * DG_MB;                  // input channels (c) per workgroup: 64 of the 128
+constexpr int DG_MSPLIT = CW / DG_M;              // 2
+constexpr int DG_NCHUNK = 4 * CW / CONV_CC;       // 256 stages of two convolution channels
+constexpr int DG_WSLAB = 3328;                    // floats per stage: 25 taps x 2 x 64 = 3200, padded to 13 KB of LDS-DMA
+constexpr int DG_HALO = CONV_TILE + 4, DG_IP = 24;
+constexpr int DG_IN = CONV_CC * DG_HALO * DG_IP;  // 960 floats
+constexpr int WG_KSPLIT = 12;                     // 64 x 12 = 768 workgroups = three per CU
+constexpr int WG_TY = 8, WG_TX = 16, WG_HY = WG_TY + 4, WG_HX = WG_TX + 4;
+constexpr int WG_LP = 33;                         // LDS pitch of the wgrad tiles: [position][32 channels | 1 pad]
+constexpr int DB_CHUNKS = 16;                     // pixel chunks of the bias gradient's first stage
+
+struct BwdWs { float* norm; float* xpad; float* wd; float* part; uint8_t* idx; };
+
+static int64_t norm_ws_floats(int L) {
+  const int64_t LL = (int64_t)L * L, nch = cdiv64(LL, 4096);
+  return ((2 * LL + 512 + 1024 + 3) & ~(int64_t)3) + 2 * (int64_t)CW * nch * 8 + 16;
 }
 
-__global__ __launch_bounds__(256) void bwd_maxout_route_kernel(const float* __restrict__ z, const float* __restrict__ bias,
-                                                               const float* __restrict__ du, int LL,
-                                                               float* __restrict__ dz) {
-  const int g = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= LL) return;
-  int win = 0;
-  float best = z[(int64_t)(4 * g) * LL + p] + bias[4 * g];
-#pragma unroll
-  for (int q = 1; q < 4; ++q) {
-    const float v = z[(int64_t)(4 * g + q) * LL + p] + bias[4 * g + q];
-    if (v > best) { best = v; win = q; }                 // strict: the first maximal value wins, as torch.max
-  }
-  const float d = du[(int64_t)g * LL + p];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dz[(int64_t)(4 * g + q) * LL + p] = q == win ? d : 0.f;
-}
-
-__global__ __launch_bounds__(256) void bwd_bias_kernel(const float* __restrict__ dz, int LL, float* __restrict__ db) {
-  __shared__ double red[256];
-  const int o = blockIdx.x;
-  double acc = 0.0;
-  for (int p = threadIdx.x; p < LL; p += 256) acc += (double)dz[(int64_t)o * LL + p];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) db[o] = (float)red[0];
-}
-
-__global__ __launch_bounds__(256) void bwd_col2im_kernel(const float* __restrict__ dcol, int L, float* __restrict__ dx) {
-  const int c = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const int LL = L * L;
-  if (p >= LL) return;
-  const int y = p / L, x = p % L;
-  float acc = 0.f;
-#pragma unroll
-  for (int tap = 0; tap < 25; ++tap) {
-    const int yy = y - (tap / 5 - 2), xx = x - (tap % 5 - 2);      // the output pixel whose patch holds (y, x) at `tap`
-    if (yy >= 0 && yy < L && xx >= 0 && xx < L) acc += dcol[(int64_t)(c * 25 + tap) * LL + yy * L + xx];
-  }
-  dx[(int64_t)c * LL + p] = acc;
-}
-
-// the block's weights as the state_dict holds them, W[o][c*25 + tap], from the exact-f32 kernel's pack
-// [split 4][chunk 64][tap 25][cc 2][m 128] (the raw tensors are not kept after dmp_weights_finalize)
-__global__ __launch_bounds__(256) void bwd_unpack_weights_kernel(const float* __restrict__ wpack, float* __restrict__ w) {
-  const int i = blockIdx.x * 256 + threadIdx.x;           // o * 3200 + c * 25 + tap
-  if (i >= 512 * 3200) return;
-  const int o = i / 3200, r = i % 3200, cch = r / 25, tap = r % 25;
-  w[i] = wpack[((((int64_t)(o >> 7) * (CW / CONV_CC) + cch / CONV_CC) * 25 + tap) * CONV_CC + cch % CONV_CC) * 128 + (o & 127)];
-}
-
-int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_du, int L, float* d_dx, float* d_dw,
-                       float* d_db, hipStream_t s) {
-  const BlockW& B = c->W.blk[block - 1];
-  const int LL = L * L;
-  int rc;
-  if ((rc = bwd_workspace(c, (int64_t)(3200 + 1024) * LL))) return rc;
-  if (!c->bwd_w) {                                       // the block weights as uploaded (512 x 3200), once per context
-    DMP_HIP(hipMalloc((void**)&c->bwd_w, sizeof(float) * 512 * 3200));
+// the one workspace of the context, sized for max_L (both halves and every L <= max_L use the same carving)
+static int bwd_workspace(dmp_ctx* c, BwdWs* w) {
+  const int64_t L = c->max_L, P = act_pitch(c->max_L);
+  const int64_t n_norm = (norm_ws_floats(c->max_L) + 3) & ~(int64_t)3, n_xpad = (int64_t)CW * P * P;
+  const int64_t n_wd = (int64_t)DG_MSPLIT * DG_NCHUNK * DG_WSLAB, n_part = (int64_t)WG_KSPLIT * 512 * 3200;
+  const int64_t n_idx = ((int64_t)CW * L * L + 3) / 4;
+  const int64_t need = n_norm + n_xpad + n_wd + n_part + n_idx;
+  if (!c->bwd_ws) {
+    DMP_HIP(hipMalloc((void**)&c->bwd_ws, sizeof(float) * (size_t)need));
+    c->bwd_ws_floats = need;
     c->bwd_w_block = 0;
   }
-  if (c->bwd_w_block != block) {
-    hipLaunchKernelGGL(bwd_unpack_weights_kernel, dim3(cdiv(512 * 3200, 256)), dim3(256), 0, s, B.wpack, c->bwd_w);
+  w->norm = c->bwd_ws;
+  w->xpad = w->norm + n_norm;
+  w->wd = w->xpad + n_xpad;
+  w->part = w->wd + n_wd;
+  w->idx = reinterpret_cast<uint8_t*>(w->part + n_part);
+  return DMP_OK;
+}
+
+// Wd[ms][chunk][tap][cc][m] = W[o = 2 chunk + cc][c = 64 ms + m][24 - tap] from the exact-f32 forward pack
+// [split = o / 128][c / 2][tap][c % 2][o % 128] (the raw tensors are not kept after dmp_weights_finalize)
+__global__ __launch_bounds__(256) void bwd_pack_dgrad_weights_kernel(const float* __restrict__ wpack, float* __restrict__ wd) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= DG_MSPLIT * DG_NCHUNK * DG_WSLAB) return;
+  const int r = i % DG_WSLAB, chunk = (i / DG_WSLAB) % DG_NCHUNK, ms = i / (DG_WSLAB * DG_NCHUNK);
+  float v = 0.f;
+  if (r < 25 * CONV_CC * DG_M) {
+    const int m = r % DG_M, cc = (r / DG_M) % CONV_CC, tap = r / (DG_M * CONV_CC);
+    const int o = 2 * chunk + cc, ch = ms * DG_M + m, t = 24 - tap;
+    v = wpack[((((int64_t)(o >> 7) * (CW / CONV_CC) + ch / CONV_CC) * 25 + t) * CONV_CC + ch % CONV_CC) * 128 + (o & 127)];
+  }
+  wd[i] = v;
+}
+
+// db[4g + q] = sum over the pixels won by q of du[g]: float64 partial sums per pixel chunk, then in chunk order
+// grid: (DB_CHUNKS, 128)   block: 256      part[g][chunk][4]
+__global__ __launch_bounds__(256) void bwd_bias_kernel(const float* __restrict__ du, const uint8_t* __restrict__ idx, int LL,
+                                                       double* __restrict__ part) {
+  __shared__ double red[4][4];
+  const int g = blockIdx.y, ch = blockIdx.x;
+  const int p0 = (int)((int64_t)LL * ch / DB_CHUNKS), p1 = (int)((int64_t)LL * (ch + 1) / DB_CHUNKS);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    const double d = (double)du[(int64_t)g * LL + p];
+    const int w = idx[(int64_t)g * LL + p];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += w == q ? d : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = wave_sum_f64(acc[q]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[threadIdx.x >> 6][q] = acc[q];
+  __syncthreads();
+  if (threadIdx.x < 4)
+    part[((int64_t)g * DB_CHUNKS + ch) * 4 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+// grid: 2   block: 256 (thread = convolution channel o)
+__global__ __launch_bounds__(256) void bwd_bias_finish_kernel(const double* __restrict__ part, float* __restrict__ db) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+  for (int ch = 0; ch < DB_CHUNKS; ++ch) s += part[((int64_t)(o >> 2) * DB_CHUNKS + ch) * 4 + (o & 3)];
+  db[o] = (float)s;
+}
+
+// grid: round_up(tiles^2 x DG_MSPLIT, 8)   block: 256   (the forward kernel's structure: conv5x5_maxout_kernel, trunk.hip)
+__global__ __launch_bounds__(256, 4) void conv5x5_dgrad_kernel(const float* __restrict__ du, const uint8_t* __restrict__ idx,
+                                                               const float* __restrict__ wd, int L, int tiles, int nwork,
+                                                               float* __restrict__ dx) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * DG_WSLAB + 2 * DG_IN];
+  float (*w_lds)[DG_WSLAB] = reinterpret_cast<float (*)[DG_WSLAB]>(smem);
+  float (*in_lds)[DG_IN] = reinterpret_cast<float (*)[DG_IN]>(smem + 2 * DG_WSLAB);
+  // XCD-aware remap: block b runs on XCD b % 8; each XCD gets a contiguous range of work items
+  const int id = blockIdx.x, per = gridDim.x >> 3;
+  const int work = (id & 7) * per + (id >> 3);
+  if (work >= nwork) return;
+  const int tile = work / DG_MSPLIT, ms = work % DG_MSPLIT;
+  const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 5, li = lane & 31;
+  const int64_t LL = (int64_t)L * L;
+
+  // staging of the (2 convolution channels x 20 x 20) halo tile of the ROUTED gradient: slot = (cc, yy, xx); both
+  // channels of a stage belong to one maxout channel g (o = 4 g + q), so the slot loads du[g] and the winner at its
+  // pixel and keeps the value where the winner is its own q.  Every load is unconditional (clamped offset).
+  int in_off[4], in_dst[4], in_q[4];
+  bool in_ok[4], in_img[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = tid + e * 256;                          // < 800 valid
+    in_ok[e] = i < CONV_CC * DG_HALO * DG_HALO;
+    const int ic = in_ok[e] ? i : 0;
+    const int cc = ic / (DG_HALO * DG_HALO), rem = ic % (DG_HALO * DG_HALO);
+    const int yy = rem / DG_HALO, xx = rem % DG_HALO;
+    const int gy = ty0 + yy - 2, gx = tx0 + xx - 2;
+    in_img[e] = gy >= 0 && gy < L && gx >= 0 && gx < L;
+    in_off[e] = in_img[e] ? gy * L + gx : 0;
+    in_dst[e] = cc * DG_HALO * DG_IP + yy * DG_IP + xx;
+    in_q[e] = cc;
+  }
+  const float4* wsrc = reinterpret_cast<const float4*>(wd + (int64_t)ms * DG_NCHUNK * DG_WSLAB);
+  float ireg[4];
+  int wreg[4];
+  auto prefetch = [&](int chunk) {
+    const float4* ws = wsrc + (int64_t)chunk * (DG_WSLAB / 4);
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    float* dst = w_lds[chunk & 1] + (size_t)wave * 256;
+    // the weight slab of the stage by LDS-DMA: 13 wave-instructions of 1 KB (lane-linear destination)
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + e * 256), (lptr_t)(dst + e * 1024), 16, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((gptr_t)(ws + tid + 3 * 256), (lptr_t)(dst + 3 * 1024), 16, 0, 0);
+    const int64_t gb = (int64_t)(chunk >> 1) * LL;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ireg[e] = du[gb + in_off[e]];
+      wreg[e] = idx[gb + in_off[e]];
+    }
+  };
+  auto commit = [&](int buf, int chunk) {
+    const int q0 = (chunk & 1) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (in_ok[e]) in_lds[buf][in_dst[e]] = (in_img[e] && wreg[e] == q0 + in_q[e]) ? ireg[e] : 0.f;
+  };
+
+  int b_off[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int nb = 2 * wave + q;
+    const int y = (nb >> 1) * 4 + (li >> 3), x = (nb & 1) * 8 + (li & 7);
+    b_off[q] = kk * DG_HALO * DG_IP + y * DG_IP + x;
+  }
+  const int a_off = kk * DG_M + li;
+  tr_f32x16 acc[DG_MB][2];
+#pragma unroll
+  for (int mb = 0; mb < DG_MB; ++mb)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][q][r] = 0.f;
+
+  prefetch(0);
+  commit(0, 0);
+  __syncthreads();
+  for (int chunk = 0; chunk < DG_NCHUNK; ++chunk) {
+    const int buf = chunk & 1;
+    if (chunk + 1 < DG_NCHUNK) prefetch(chunk + 1);
+    const float* wl = w_lds[buf] + a_off;
+    const float* il = in_lds[buf];
+#pragma unroll
+    for (int tap = 0; tap < 25; ++tap) {
+      const int dy = tap / 5, dxx = tap % 5;
+      float a[DG_MB], b[2];
+#pragma unroll
+      for (int mb = 0; mb < DG_MB; ++mb) a[mb] = wl[tap * CONV_CC * DG_M + mb * 32];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) b[q] = il[b_off[q] + dy * DG_IP + dxx];
+#pragma unroll
+      for (int mb = 0; mb < DG_MB; ++mb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[mb][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[q], acc[mb][q], 0, 0, 0);
+    }
+    if (chunk + 1 < DG_NCHUNK) commit(buf ^ 1, chunk + 1);
+    __syncthreads();
+  }
+  // accumulator register r of lane (kk, li): channel 64 ms + 32 mb + 8 (r / 4) + 4 kk + (r % 4), pixel li of patch nb
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int nb = 2 * wave + q;
+    const int y = ty0 + (nb >> 1) * 4 + (li >> 3), x = tx0 + (nb & 1) * 8 + (li & 7);
+    if (y < L && x < L) {
+#pragma unroll
+      for (int mb = 0; mb < DG_MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = ms * DG_M + mb * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
+          dx[(int64_t)ch * LL + (int64_t)y * L + x] = acc[mb][q][r];
+        }
+    }
+  }
+}
+
+// grid: 64 x WG_KSPLIT   block: 320 (wave = tap row dy)      part[ks][o 512][tap 25][c 128]
+// Three workgroups per CU (48.6 KB of LDS each): 15 waves on the four SIMDs (4 / 4 / 4 / 3) - with two the five waves of a
+// workgroup left one SIMD with twice the others' MFMAs (first version: 3.46 ms at L = 300, 0.54 of the peak).  The next
+// tile's operands are requested before this tile's MFMAs and written to LDS behind them: the x halo tile as 16-byte
+// loads of the padded planes (rows of 20 = 5 x float4, aligned: P and the tile origin are multiples of 4), the dz tile as
+// du + winner byte, expanded at the LDS write.  LDS layout [position][32 channels | 1 pad]: the 32 lanes of an MFMA
+// operand read 32 consecutive words.
+__global__ __launch_bounds__(320, 4) void conv5x5_wgrad_kernel(const float* __restrict__ xpad, const float* __restrict__ du,
+                                                               const uint8_t* __restrict__ idx, int L, int P, int tx_tiles,
+                                                               int ntiles, float* __restrict__ part) {
+  __shared__ float a_lds[WG_TY * WG_TX * WG_LP];          // dz tile  [pixel 128][o 32 | pad]
+  __shared__ float b_lds[WG_HY * WG_HX * WG_LP];          // x halo   [position 240][c 32 | pad]
+  const int ks = blockIdx.x >> 6, rb = blockIdx.x & 63, ob = rb >> 2, cb = rb & 3;
+  const int t_lo = (int)((int64_t)ntiles * ks / WG_KSPLIT), t_hi = (int)((int64_t)ntiles * (ks + 1) / WG_KSPLIT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int dy = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kk = lane >> 5, li = lane & 31;
+  const int64_t LL = (int64_t)L * L, PP = (int64_t)P * P;
+  // staging slots: six float4 of the halo tile (i = tid + 320 e < 32 x 12 x 5 = 1920 exactly: channel i / 60, row, float4
+  // of the row) and up to four (maxout channel, pixel) items of dz (i < 1024).  The slot arithmetic is redone at every
+  // use - divisions by constants under 320 MFMAs per wave and tile - instead of being kept in 30 registers: with the 80
+  // accumulator registers and the 32 of the prefetch the kernel has to stay within the 128 of four waves per SIMD.
+  const float* xb = xpad + (int64_t)cb * 32 * PP;
+  const float* dub = du + (int64_t)ob * 8 * LL;
+  const uint8_t* idb = idx + (int64_t)ob * 8 * LL;
+  float4 breg[6];
+  float areg[4];
+  int wreg[4];                                           // the winner, or -1 for a pixel outside the image
+  auto prefetch = [&](int t) {
+    const int ty0 = (t / tx_tiles) * WG_TY, tx0 = (t % tx_tiles) * WG_TX;
+    const float* xt = xb + (int64_t)ty0 * P + tx0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      int i = tid + e * 320;
+      asm volatile("" : "+v"(i));                        // (keeps the slot arithmetic inside the loop: see above)
+      const int cl = i / 60, rem = i % 60, row = rem / 5, f4 = rem % 5;
+      breg[e] = *reinterpret_cast<const float4*>(xt + ((int64_t)cl * PP + (int64_t)row * P + 4 * f4));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int i = tid + e * 320;
+      asm volatile("" : "+v"(i));
+      const int g = (i >> 7) & 7, p = i & 127;
+      const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
+      const bool real = y < L && x < L;
+      const int64_t off = (int64_t)g * LL + (real ? y * L + x : 0);
+      areg[e] = dub[off];
+      const int w = idb[off];
+      wreg[e] = real ? w : -1;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      int i = tid + e * 320;
+      asm volatile("" : "+v"(i));
+      const int cl = i / 60, rem = i % 60, row = rem / 5, f4 = rem % 5;
+      float* d = b_lds + (row * WG_HX + 4 * f4) * WG_LP + cl;
+      d[0] = breg[e].x;
+      d[WG_LP] = breg[e].y;
+      d[2 * WG_LP] = breg[e].z;
+      d[3 * WG_LP] = breg[e].w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int i = tid + e * 320;
+      asm volatile("" : "+v"(i));
+      if (i < 8 * WG_TY * WG_TX) {
+        float* d = a_lds + (i & 127) * WG_LP + (i >> 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = wreg[e] == q ? areg[e] : 0.f;
+      }
+    }
+  };
+  tr_f32x16 acc[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  if (t_lo < t_hi) prefetch(t_lo);
+  for (int t = t_lo; t < t_hi; ++t) {
+    __syncthreads();                                     // the previous tile's MFMAs are done with the LDS tiles
+    commit();
+    __syncthreads();
+    if (t + 1 < t_hi) prefetch(t + 1);
+#pragma unroll 4
+    for (int s = 0; s < WG_TY * WG_TX / 2; ++s) {
+      const int p = 2 * s + kk;
+      const float a = a_lds[p * WG_LP + li];
+      const float* bp = b_lds + (((p >> 4) + dy) * WG_HX + (p & 15)) * WG_LP + li;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[d * WG_LP], acc[d], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 5; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
+      part[(((int64_t)ks * 512 + o) * 25 + dy * 5 + d) * CW + cb * 32 + li] = acc[d][r];
+    }
+}
+
+// dW[o][c 25 + tap] = sum_ks part[ks][o][tap][c], ks ascending          grid: 512 x 25 x 128 / 256   block: 256
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;           // (o 25 + tap) 128 + c
+  const int c = i & 127, ot = i >> 7, tap = ot % 25, o = ot / 25;
+  float s = part[i];
+#pragma unroll
+  for (int ks = 1; ks < WG_KSPLIT; ++ks) s += part[(int64_t)ks * 512 * 3200 + i];
+  dw[(int64_t)o * 3200 + c * 25 + tap] = s;
+}
+
+// The forward a trainer runs: the block's convolution + maxout in float32 AND the winner of every quadruple (what
+// autograd saves for the backward of torch.max, network.py:31): u (128 x L x L), idx (128 x L x L bytes, 0..3).
+int conv5x5_maxout_fwd_winners(dmp_ctx* c, int block, const float* d_x, int L, float* d_u, uint8_t* d_idx, hipStream_t s) {
+  BwdWs w;
+  int rc;
+  if ((rc = bwd_workspace(c, &w))) return rc;
+  if ((rc = act_pad(d_x, L, w.xpad, s))) return rc;
+  return conv5x5_maxout_winners(c, block, w.xpad, L, d_u, d_idx, s);
+}
+
+// d_idx: the winners the forward saved (conv5x5_maxout_fwd_winners), or null: the forward is run again here
+int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_du, const uint8_t* d_idx, int L, float* d_dx,
+                       float* d_dw, float* d_db, hipStream_t s) {
+  const BlockW& B = c->W.blk[block - 1];
+  const int LL = L * L, P = act_pitch(L), tiles = act_tiles(L);
+  BwdWs w;
+  int rc;
+  if ((rc = bwd_workspace(c, &w))) return rc;
+  if (c->bwd_w_block != block) {                          // the flipped weight pack of this block
+    hipLaunchKernelGGL(bwd_pack_dgrad_weights_kernel, dim3(cdiv(DG_MSPLIT * DG_NCHUNK * DG_WSLAB, 256)), dim3(256), 0, s,
+                       B.wpack, w.wd);
     DMP_LAUNCH_CHECK();
     c->bwd_w_block = block;
   }
-  float* col = c->bwd_ws;
-  float* z = col + (int64_t)3200 * LL;
-  float* dz = z + (int64_t)512 * LL;
-  hipLaunchKernelGGL(bwd_im2col_kernel, dim3(cdiv(LL, 256), 3200), dim3(256), 0, s, d_x, L, col);
+  // 1. the padded input (wgrad's halo tiles) and, unless the caller kept them, the winners: the forward again, in
+  //    float32 (its maxout output goes to the context's scratch plane c->u)
+  if ((rc = act_pad(d_x, L, w.xpad, s))) return rc;
+  if (!d_idx) {
+    if ((rc = conv5x5_maxout_winners(c, block, w.xpad, L, c->u, w.idx, s))) return rc;
+    d_idx = w.idx;
+  }
+  // 2. bias gradient
+  hipLaunchKernelGGL(bwd_bias_kernel, dim3(DB_CHUNKS, CW), dim3(256), 0, s, d_du, d_idx, LL, reinterpret_cast<double*>(w.norm));
+  hipLaunchKernelGGL(bwd_bias_finish_kernel, dim3(2), dim3(256), 0, s, reinterpret_cast<const double*>(w.norm), d_db);
   DMP_LAUNCH_CHECK();
-  GemmArgs g{};
-  // z = W col
-  g.A = c->bwd_w; g.sam = 3200; g.sak = 1; g.B = col; g.sbk = LL; g.sbn = 1; g.C = z; g.ldc = LL;
-  g.M = 512; g.N = LL; g.K = 3200; g.alpha = 1.f; g.beta = 0.f; g.bias_n = nullptr;
-  if ((rc = gemm_f32(g, s))) return rc;
-  hipLaunchKernelGGL(bwd_maxout_route_kernel, dim3(cdiv(LL, 256), 128), dim3(256), 0, s, z, B.bias, d_du, LL, dz);
+  // 3. input gradient
+  const int nwork = tiles * tiles * DG_MSPLIT;
+  hipLaunchKernelGGL(conv5x5_dgrad_kernel, dim3(round_up(nwork, 8)), dim3(256), 0, s, d_du, d_idx, w.wd, L, tiles, nwork, d_dx);
   DMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bwd_bias_kernel, dim3(512), dim3(256), 0, s, dz, LL, d_db);
+  // 4. weight gradient
+  const int ty = cdiv(L, WG_TY), tx = cdiv(L, WG_TX);
+  hipLaunchKernelGGL(conv5x5_wgrad_kernel, dim3(64 * WG_KSPLIT), dim3(320), 0, s, w.xpad, d_du, d_idx, L, P, tx, ty * tx, w.part);
   DMP_LAUNCH_CHECK();
-  // dW = dz col^T
-  g.A = dz; g.sam = LL; g.sak = 1; g.B = col; g.sbk = 1; g.sbn = LL; g.C = d_dw; g.ldc = 3200;
-  g.M = 512; g.N = 3200; g.K = LL;
-  if ((rc = gemm_f32(g, s))) return rc;
-  // dcol = W^T dz (over the patch matrix, which the weight gradient no longer needs)
-  g.A = c->bwd_w; g.sam = 1; g.sak = 3200; g.B = dz; g.sbk = LL; g.sbn = 1; g.C = col; g.ldc = LL;
-  g.M = 3200; g.N = LL; g.K = 512;
-  if ((rc = gemm_f32(g, s))) return rc;
-  hipLaunchKernelGGL(bwd_col2im_kernel, dim3(cdiv(LL, 256), 128), dim3(256), 0, s, col, L, d_dx);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(512 * 25 * CW / 256), dim3(256), 0, s, w.part, d_dw);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// The 1x1 head (network.py:207: Conv2d(128 -> 2, k 1)), backward: with G = d(head output) [2][L][L] and x its input,
+//   dx[c][p] = sum_h W[h][c] G[h][p];   dW[h][c] = sum_p G[h][p] x[c][p];   db[h] = sum_p G[h][p]
+// dparams: [dW 2 x 128][db 2]
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ hw, int LL,
+                                                          float* __restrict__ dx) {
+  const int c = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= LL) return;
+  dx[(int64_t)c * LL + p] = fmaf(hw[CW + c], g[LL + p], hw[c] * g[p]);
+}
+// grid: 130 (c < 128: the two weight gradients of channel c; 128, 129: the bias gradients)   block: 256
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ g, const float* __restrict__ x, int LL,
+                                                          float* __restrict__ dparams) {
+  __shared__ double red[4][2];
+  const int c = blockIdx.x;
+  double a0 = 0.0, a1 = 0.0;
+  for (int p = threadIdx.x; p < LL; p += 256) {
+    const double xv = c < CW ? (double)x[(int64_t)c * LL + p] : 1.0;
+    a0 += (double)g[p] * xv;
+    a1 += (double)g[LL + p] * xv;
+  }
+  a0 = wave_sum_f64(a0);
+  a1 = wave_sum_f64(a1);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a0; red[threadIdx.x >> 6][1] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s0 = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0], s1 = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    if (c < CW) { dparams[c] = (float)s0; dparams[CW + c] = (float)s1; }
+    else if (c == CW) { dparams[2 * CW] = (float)s0; dparams[2 * CW + 1] = (float)s1; }
+  }
+}
+
+int head_conv_bwd(dmp_ctx* c, const float* d_x, const float* d_g, int L, float* d_dx, float* d_dparams, hipStream_t s) {
+  const int LL = L * L;
+  hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(cdiv(LL, 256), CW), dim3(256), 0, s, d_g, c->W.head_w, LL, d_dx);
+  DMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(CW + 1), dim3(256), 0, s, d_g, d_x, LL, d_dparams);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
@@ -340,14 +650,15 @@ int norm_scse_residual_bwd(dmp_ctx* c, int block, const float* d_u, const float*
   const BlockW& B = c->W.blk[block - 1];
   const int LL = L * L, nch = cdiv(LL, TB_CHUNK);
   // workspace: gate planes 2 LL floats | coef 512 | kco 1024 | partial sums 128 nch 8 doubles
-  const int64_t fl = 2 * (int64_t)LL + 512 + 1024, need = fl + 2 * (int64_t)CW * nch * TB_NSUM + 16;
+  const int64_t fl = 2 * (int64_t)LL + 512 + 1024;
   int rc;
-  if ((rc = bwd_workspace(c, need))) return rc;
-  float* sg = c->bwd_ws;
+  BwdWs w;
+  if ((rc = bwd_workspace(c, &w))) return rc;
+  float* sg = w.norm;
   float* da = sg + LL;
   float* coef = da + LL;
   float* kco = coef + 512;
-  double* part = reinterpret_cast<double*>(c->bwd_ws + ((fl + 3) & ~(int64_t)3));
+  double* part = reinterpret_cast<double*>(w.norm + ((fl + 3) & ~(int64_t)3));
   hipLaunchKernelGGL(tb_stats_kernel, dim3(nch, CW), dim3(256), 0, s, d_u, LL, part);
   DMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(tb_coef_kernel, dim3(1), dim3(CW), 0, s, part, nch, (double)LL, B.gamma, B.beta, coef);

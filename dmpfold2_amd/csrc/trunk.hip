@@ -442,12 +442,17 @@ constexpr int NCHUNK = CW / CONV_CC;      // 64
 constexpr int W_STAGE = NTAP * CONV_CC * MCH;          // 6400 floats
 constexpr int IN_STAGE = CONV_CC * HALO * IN_PITCH;    // 960 floats
 
+// IDX (the training-side slice, train.hip): also write which channel of each quadruple won the maximum - the FIRST
+// maximal one, as torch.max (network.py:31) - one byte per maxout channel and pixel.  The inference instantiation is
+// <false>: its code is what it was.
+template <bool IDX>
 __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __restrict__ xpad,
                                                                 const float* __restrict__ wpack,
                                                                 const float* __restrict__ bias, int L,
                                                                 int P, int tiles, int nwork,
                                                                 float* __restrict__ u,
-                                                                double* __restrict__ part) {
+                                                                double* __restrict__ part,
+                                                                uint8_t* __restrict__ idx) {
   // one LDS object (a second one makes hipcc drain vmcnt in front of LDS reads of a DMA pipeline)
   __shared__ __attribute__((aligned(16))) float smem[2 * W_STAGE + 2 * IN_STAGE];
   float (*w_lds)[W_STAGE] = reinterpret_cast<float (*)[W_STAGE]>(smem);
@@ -563,12 +568,22 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         float v = acc[mb][q][4 * g4] + bsp[cl];
-        v = fmaxf(v, acc[mb][q][4 * g4 + 1] + bsp[cl + 1]);
-        v = fmaxf(v, acc[mb][q][4 * g4 + 2] + bsp[cl + 2]);
-        v = fmaxf(v, acc[mb][q][4 * g4 + 3] + bsp[cl + 3]);
+        int win = 0;
+        if constexpr (IDX) {
+#pragma unroll
+          for (int e = 1; e < 4; ++e) {
+            const float t = acc[mb][q][4 * g4 + e] + bsp[cl + e];
+            if (t > v) { v = t; win = e; }               // strict: the first maximal channel wins
+          }
+        } else {
+          v = fmaxf(v, acc[mb][q][4 * g4 + 1] + bsp[cl + 1]);
+          v = fmaxf(v, acc[mb][q][4 * g4 + 2] + bsp[cl + 2]);
+          v = fmaxf(v, acc[mb][q][4 * g4 + 3] + bsp[cl + 3]);
+        }
         const int nb = 2 * wave + q;
         const int y = ty0 + (nb >> 1) * 4 + (li >> 3), x = tx0 + (nb & 1) * 8 + (li & 7);
         if (y < L && x < L) {
+          if constexpr (IDX) idx[(int64_t)gch * LL + (int64_t)y * L + x] = (uint8_t)win;
           u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
           s1 += v;
           s2 += v * v;
@@ -678,10 +693,22 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
     DMP_LAUNCH_CHECK();
     return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
   }
-  hipLaunchKernelGGL(conv5x5_maxout_kernel, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
-                     P, tiles, nwork, d_u, c->part);
+  hipLaunchKernelGGL(conv5x5_maxout_kernel<false>, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
+                     P, tiles, nwork, d_u, c->part, (uint8_t*)nullptr);
   DMP_LAUNCH_CHECK();
   return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
+}
+
+// the block's convolution + maxout in float32 with the winner of every quadruple (train.hip: the backward routes the
+// gradient of a maxout channel to that one convolution channel)
+int conv5x5_maxout_winners(dmp_ctx* c, int block, const float* d_xpad, int L, float* d_u, uint8_t* d_idx, hipStream_t s) {
+  const BlockW& B = c->W.blk[block - 1];
+  const int tiles = act_tiles(L), P = act_pitch(L);
+  const int nwork = tiles * tiles * CONV_SPLIT;
+  hipLaunchKernelGGL(conv5x5_maxout_kernel<true>, dim3(round_up(nwork, 8)), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
+                     P, tiles, nwork, d_u, c->part, d_idx);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -697,6 +724,9 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
 // (108 registers; the kernel took 135 us there against 38 alone) and is three waves of this one.  A wave = 16 pixels
 // x 4 channel quarters; sums over the channels are formed as (q0 + q1) + (q2 + q3), each quarter an fmaf chain in
 // channel order - the same in every lane of a pixel.
+#ifndef NORM_PRIO
+#define NORM_PRIO 0
+#endif
 template <int SPLIT, int HEAD>
 __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     const float* __restrict__ u, const float* __restrict__ ab, const float* __restrict__ cse,
@@ -704,6 +734,9 @@ __global__ __launch_bounds__(256) void norm_scse_residual_kernel(
     float* __restrict__ xout, uint16_t* __restrict__ xs, int* __restrict__ fault, float xscale,
     const float* __restrict__ hw, float hb0, float hb1, float* __restrict__ head0, float* __restrict__ head1) {
   __shared__ float sh_a[CW], sh_b[CW], sh_g[CW], sh_w[CW], sh_h[HEAD ? 2 * CW : 1];
+#if NORM_PRIO
+  __builtin_amdgcn_s_setprio(NORM_PRIO);                 // ahead of the convolution waves it shares its CUs with (see NORM_PRIO)
+#endif
   if (threadIdx.x < CW) {
     sh_a[threadIdx.x] = ab[threadIdx.x * 2];
     sh_b[threadIdx.x] = ab[threadIdx.x * 2 + 1];

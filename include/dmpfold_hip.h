@@ -34,7 +34,7 @@ extern "C" {
  *    holds every launch's interval; the three lane functions became dmp_ctx_share_lane.  Options vgru_legacy and gj_lds are gone;
  *    act_scaling and vgru_persistent are new; fault bit DMP_FAULT_VGRU_HANDOFF is new.
  * 2: dmp_sync_faults clears what it reports, dmp_ctx_get_option and dmp_dca_features added. */
-#define DMP_ABI_VERSION 3
+#define DMP_ABI_VERSION 4
 #define DMP_MAX_SEQS 3000 /* predict.py:130-132: deeper MSAs are truncated */
 
 typedef struct dmp_ctx dmp_ctx;
@@ -217,11 +217,27 @@ int dmp_block_norm_scse_residual(dmp_ctx* ctx, int block, const float* d_u,
  * max (network.py:25-31 with kernel 5), the piece of autograd train.py:318-344 runs through ResNet_Block
  * (network.py:85-103).  d_x: the block's input (128 x L x L), d_du: gradient w.r.t. the maxout output (128 x L x L).
  * Outputs: d_dx (128 x L x L) gradient w.r.t. the input, d_dw (512 x 128 x 5 x 5) and d_db (512) gradients of
- * layer1.lin.weight / .bias (overwritten, not accumulated).  Float32 matrix-core products on an explicit patch
- * matrix; ties of the max go to the first maximal channel, as torch.max.  Allocates its workspace ((3200 + 1024) L^2
- * floats) on first use. */
-int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, const float* d_du, int L, float* d_dx,
-                                 float* d_dw, float* d_db, void* stream);
+ * layer1.lin.weight / .bias (overwritten, not accumulated).  Implicit GEMMs on the float32 matrix cores (round 5: no
+ * patch matrix): the forward is run again in float32 for the winner of every quadruple (ties go to the first maximal
+ * channel, as torch.max), the routed gradient travels as d_du + one winner byte per maxout channel and pixel and is
+ * expanded only in LDS; dgrad = the forward's tile structure with flipped taps, wgrad = a pixel-K GEMM over 8 x 16
+ * pixel tiles reduced in fixed order (deterministic).  EVALUATION MODE ONLY: the dropouts of network.py:96-97 are
+ * identities here; a training-mode block (Dropout / Dropout2d masks ahead of layer1) is not representable.
+ * Workspace: one allocation per context at the first call of either backward entry point, sized for the context's
+ * max_L (2.6 activation tensors: padded input, winners, flipped weight pack, wgrad partial sums) - L may change between
+ * calls without reallocation.  Uses the context's maxout scratch plane (not to be interleaved with a prediction in
+ * flight on the same context). */
+int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, const float* d_du, const uint8_t* d_idx, int L,
+                                 float* d_dx, float* d_dw, float* d_db, void* stream);
+/* The forward a training step runs for that block: convolution + maxout in float32, d_u (128 x L x L), and what autograd
+ * saves for the backward of torch.max (network.py:31) - d_idx (128 x L x L bytes): which channel of each quadruple won,
+ * 0..3, the FIRST maximal one.  Handed to dmp_block_conv5x5_maxout_bwd as d_idx it saves the backward its own forward
+ * (a third of its matrix-core work); with d_idx = NULL the backward runs the forward again.  (Two implementations of the
+ * convolution can resolve a near-tie - two channels within float32 rounding of each other - differently, about one
+ * decision in a million; both are valid subgradients.  The parity tests substitute the reference's winners at the
+ * near-ties their fixtures list.) */
+int dmp_block_conv5x5_maxout_winners(dmp_ctx* ctx, int block, const float* d_x, int L, float* d_u, uint8_t* d_idx,
+                                     void* stream);
 /* ... and of its second half - InstanceNorm (network.py:32), scSE (network.py:36-83) and the residual add
  * (network.py:99-101).  d_u: the maxout output the forward normalised (128 x L x L; its statistics are recomputed),
  * d_dout: gradient w.r.t. the block's output.  Outputs: d_du (128 x L x L) = gradient w.r.t. the maxout output (the
@@ -231,6 +247,11 @@ int dmp_block_conv5x5_maxout_bwd(dmp_ctx* ctx, int block, const float* d_x, cons
  * first half plus d_dout (the caller's add).  Evaluation-mode block (the dropouts of network.py:96-97 are identities). */
 int dmp_block_norm_scse_residual_bwd(dmp_ctx* ctx, int block, const float* d_u, const float* d_dout, int L,
                                      float* d_du, float* d_dparams, void* stream);
+/* ... and of the 1x1 head convolution (network.py:207, Conv2d(128 -> 2)): d_x its input (128 x L x L), d_g the gradient
+ * w.r.t. its two output planes (2 x L x L).  Outputs: d_dx (128 x L x L) and d_dparams (258 floats: weight 2 x 128,
+ * bias 2).  With the two entry points above a caller chains the sixteen blocks and the head of net.resnet
+ * (tests/test_gpu_train.py); the stem's backward (955 input channels) is not built. */
+int dmp_head_conv_bwd(dmp_ctx* ctx, const float* d_x, const float* d_g, int L, float* d_dx, float* d_dparams, void* stream);
 /* Head 1x1 conv (network.py:207) + network.py:237-246: d_conf (L) = row means of channel 1,
  * d_M (L x L) = Gram matrix 0.5*(dm_0j^2 + dm_i0^2 - dm_ij^2) of dm = |sym(channel 0)|. */
 int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M,

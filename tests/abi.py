@@ -106,17 +106,31 @@ class Stages:
         self.call("dmp_block_norm_scse_residual", block, u, st, x, L, out)
         return out
 
-    def conv_bwd(self, block, x, du):
+    def conv_bwd(self, block, x, du, idx=None):
         L = x.shape[-1]
         dx, dw, db = self.f32(128, L, L), self.f32(512, 128, 5, 5), self.f32(512)
-        self.call("dmp_block_conv5x5_maxout_bwd", block, x, du, L, dx, dw, db)
+        self.call("dmp_block_conv5x5_maxout_bwd", block, x, du, idx, L, dx, dw, db)
         return dx, dw, db
+
+    def conv_winners(self, block, x):
+        """the float32 forward of a training step: maxout output + the winner of every quadruple (uint8)"""
+        L = x.shape[-1]
+        u = self.f32(128, L, L)
+        idx = torch.empty((128, L, L), dtype=torch.uint8, device=self.dev)
+        self.call("dmp_block_conv5x5_maxout_winners", block, x, L, u, idx)
+        return u, idx
 
     def norm_bwd(self, block, u, dout):
         L = u.shape[-1]
         du, dparams = self.f32(128, L, L), self.f32(2433)
         self.call("dmp_block_norm_scse_residual_bwd", block, u, dout, L, du, dparams)
         return du, dparams
+
+    def head_bwd(self, x, g):
+        L = x.shape[-1]
+        dx, dparams = self.f32(128, L, L), self.f32(258)
+        self.call("dmp_head_conv_bwd", x, g, L, dx, dparams)
+        return dx, dparams
 
     def head_gram(self, x):
         L = x.shape[-1]

@@ -573,6 +573,111 @@ def main():
                       % (float(x.grad.abs().max()), float(u.grad.abs().max()),
                          float(blk.layer1.norm.weight.grad.abs().max()), float(blk.scSE.cSE.fc[0].weight.grad.abs().max())))
 
+    # Round 5: the same at the sizes training runs at - L = 128 and the reference's 350 crop
+    # (train.py:26-27) - and through the sixteen blocks + the head of net.resnet in one backward pass.  The tensors are
+    # too large to store: the inputs are regenerated from their Philox keys in the test, of the outputs a fixed sample
+    # of entries + sum + sum of squares is kept (pack_sample), the small parameter gradients in full.
+    NEAR_TIE = 1e-4       # absolute margin between a quadruple's two largest channels below which the decision is listed
+
+    def near_ties(z):
+        """z: the convolution output (1, 512, L, L) -> (flat index into [128][L][L], the reference's winner) of every
+        maxout decision whose two largest channels are closer than NEAR_TIE: another implementation of the same float32
+        convolution (sums in another order: 1e-6 relative) may resolve those the other way."""
+        q = z.detach()[0].reshape(128, 4, -1)
+        top2 = q.topk(2, dim=1)
+        gap = (top2.values[:, 0] - top2.values[:, 1]).reshape(-1)
+        at = torch.nonzero(gap < NEAR_TIE).reshape(-1)
+        win = q.argmax(dim=1).reshape(-1)                 # the first maximal channel
+        return at.numpy().astype(np.int64), win[at].numpy().astype(np.uint8)
+
+    def philox_plane(key, shape, scale):
+        rng = np.random.Generator(np.random.Philox(key=key))
+        return ((2.0 * rng.random(shape)) - 1.0).astype(np.float32) * np.float32(scale)
+
+    for name, blk_i, Lb, key in (("bwd_block7_full_L128", 7, 128, 0xB7128), ("bwd_block3_full_L350", 3, 350, 0xB3350)):
+        if not want(name):
+            continue
+        torch.set_num_threads(8)
+        net = RN.GRUResNet(512, 128)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net.eval()
+        blk = net.resnet[blk_i]
+        x = torch.from_numpy(philox_plane(key, (1, 128, Lb, Lb), 3.0)).requires_grad_(True)
+        G = torch.from_numpy(philox_plane(key + 1, (1, 128, Lb, Lb), 1.0))
+        grabbed = {}
+
+        def pre3(_m, inp):
+            inp[0].retain_grad()
+            grabbed["u"] = inp[0]
+        h = blk.layer1.norm.register_forward_pre_hook(pre3)
+        h2 = blk.layer1.lin.register_forward_hook(lambda _m, _i, o: grabbed.__setitem__("z", o))
+        for q in blk.parameters():
+            q.grad = None
+        out = blk(x)
+        h.remove()
+        h2.remove()
+        out.backward(G)
+        u = grabbed["u"]
+        tie_at, tie_win = near_ties(grabbed["z"])
+        bw = {"block": np.int64(blk_i), "L": np.int64(Lb), "x_key": np.int64(key), "x_scale": np.float32(3.0),
+              "dout_key": np.int64(key + 1),
+              "db": blk.layer1.lin.bias.grad.numpy(),
+              "dgamma": blk.layer1.norm.weight.grad.numpy(), "dbeta": blk.layer1.norm.bias.grad.numpy(),
+              "dfc0": blk.scSE.cSE.fc[0].weight.grad.numpy(), "dfc2": blk.scSE.cSE.fc[2].weight.grad.numpy(),
+              "dsse_w": blk.scSE.sSE.conv.weight.grad.numpy().reshape(-1), "dsse_b": blk.scSE.sSE.conv.bias.grad.numpy(),
+              "tie.at": tie_at, "tie.win": tie_win, "tie.margin": np.float32(NEAR_TIE),
+              "weights_sha256": np.frombuffer(wsum.encode(), dtype=np.uint8)}
+        pack_sample(bw, "u", u[0])
+        pack_sample(bw, "du", u.grad[0])
+        pack_sample(bw, "dx", x.grad[0])
+        pack_sample(bw, "dw", blk.layer1.lin.weight.grad)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **bw)
+        report.append("%-24s reference autograd through ResNet_Block %d, eval mode (x 128x%dx%d): |dx| max %.3e, |du| max %.3e, |dw| max %.3e"
+                      % (name, blk_i, Lb, Lb, float(x.grad.abs().max()), float(u.grad.abs().max()),
+                         float(blk.layer1.lin.weight.grad.abs().max())))
+
+    if want("bwd_resnet_L96"):
+        Lb = 96
+        torch.set_num_threads(8)
+        net = RN.GRUResNet(512, 128)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net.eval()
+        for q in net.parameters():
+            q.grad = None
+        x0 = torch.from_numpy(philox_plane(0x9E5, (1, 128, Lb, Lb), 2.0)).requires_grad_(True)      # the stem's output
+        G2 = torch.from_numpy(philox_plane(0x9E6, (1, 2, Lb, Lb), 1.0))
+        h = x0
+        zs = {}
+        hooks = [net.resnet[k].layer1.lin.register_forward_hook(lambda _m, _i, o, k=k: zs.__setitem__(k, o)) for k in range(1, 17)]
+        for k in range(1, 17):
+            h = net.resnet[k](h)
+        for hk in hooks:
+            hk.remove()
+        x16 = h
+        x16.retain_grad()
+        out = net.resnet[17](x16)
+        (out * G2).sum().backward()
+        bw = {"L": np.int64(Lb), "x_key": np.int64(0x9E5), "x_scale": np.float32(2.0), "g_key": np.int64(0x9E6),
+              "tie.margin": np.float32(NEAR_TIE),
+              "head_dw": net.resnet[17].weight.grad.numpy().reshape(2, 128), "head_db": net.resnet[17].bias.grad.numpy(),
+              "weights_sha256": np.frombuffer(wsum.encode(), dtype=np.uint8)}
+        pack_sample(bw, "x16", x16[0])
+        pack_sample(bw, "dx16", x16.grad[0])
+        pack_sample(bw, "dx0", x0.grad[0])
+        for k in range(1, 17):
+            blk = net.resnet[k]
+            bw[f"b{k}.db"] = blk.layer1.lin.bias.grad.numpy()
+            bw[f"b{k}.dgamma"] = blk.layer1.norm.weight.grad.numpy()
+            bw[f"b{k}.dbeta"] = blk.layer1.norm.bias.grad.numpy()
+            bw[f"b{k}.dsse_w"] = blk.scSE.sSE.conv.weight.grad.numpy().reshape(-1)
+            bw[f"b{k}.dfc2"] = blk.scSE.cSE.fc[2].weight.grad.numpy()
+            bw[f"b{k}.tie.at"], bw[f"b{k}.tie.win"] = near_ties(zs[k])
+            if k in (1, 8, 16):
+                pack_sample(bw, f"b{k}.dw", blk.layer1.lin.weight.grad)
+        np.savez_compressed(os.path.join(HERE, "bwd_resnet_L96.npz"), **bw)
+        report.append("bwd_resnet_L96           reference autograd through resnet[1..17] (16 blocks + head), eval mode (x 128x96x96): |dx0| max %.3e, |dx16| max %.3e"
+                      % (float(x0.grad.abs().max()), float(x16.grad.abs().max())))
+
     # known-answer vectors for the minimiser and the backbone builder on a real CA trace
     if want("kat_refine_backbone"):
         t = torch.from_numpy(ca)

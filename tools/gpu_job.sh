@@ -1,7 +1,9 @@
 #!/bin/bash
+# scratch GPU job of a session: gpurun -- 'bash tools/gpu_job.sh'.  Every step under its own timeout; outputs under gpurun_out/job/.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/job; mkdir -p $OUT
-timeout 300 python tools/debug_vgru_f32.py 40 > $OUT/dbg.txt 2>&1; grep -c "max|d|" $OUT/dbg.txt; grep "out vs h1" $OUT/dbg.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "vertical or gru_vertical" -s > $OUT/vgru_tests.log 2>&1; tail -5 $OUT/vgru_tests.log
-VGRU_F32=1 timeout 600 python tools/time_vgru_persist.py 8 300 2000 > $OUT/vgru_f32_time.txt 2>&1; tail -8 $OUT/vgru_f32_time.txt
-timeout 600 python tools/time_vgru_persist.py 8 300 2000 > $OUT/vgru_f16_time.txt 2>&1; tail -8 $OUT/vgru_f16_time.txt
+timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py -q -x -s -k "backward or train" > $OUT/train_tests.log 2>&1; tail -15 $OUT/train_tests.log
+timeout 600 python tools/time_bwd.py 300 350 > $OUT/bwd_time.txt 2>&1; cat $OUT/bwd_time.txt
+cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/bwdprof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bwdprof -o bwd -- python $GRAFT_REPO_ROOT/tools/time_bwd.py 300 > /dev/null 2>&1
+f=$(find /tmp/bwdprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $GRAFT_REPO_ROOT/$OUT/bwd_kernel_stats.csv && head -12 "$f"
