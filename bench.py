@@ -266,6 +266,7 @@ def main(argv=None):
     ap.add_argument("--cpu-baseline", choices=("full", "sample", "none"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-f32 convolution leg")
+    ap.add_argument("--no-files-leg", action="store_true", help="skip the alignment files -> PDB files measurement (N = 1)")
     ap.add_argument("--legs", choices=("both", "f16x3", "f32"), default="both",
                     help="profiling: run only one arithmetic leg (f32 alone skips the verification and latency extras, "
                          "so that a kernel-stats table of the run holds that leg's launches only)")
@@ -666,7 +667,7 @@ def main(argv=None):
                          "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA_TFLOPS / 3.0),
                          "traffic": traffic,
                          "traffic_source": "profiles/conv5x5_pmc.json (rocprofv3 --pmc passes of single "
-                                           "launches, tools/profile_r04.sh; a separate profiler run)",
+                                           "launches, tools/profile_r05.sh; a separate profiler run)",
                          "traffic_taken_from_this_kernel_source": traffic_current,
                          "launches_timed": conv_cnt,
                          "avg_launch_ms": conv_ms, "launches_in_flight": in_flight,
@@ -722,6 +723,36 @@ def main(argv=None):
                         "float32 vertical GRU); "
                         "achieved = algorithmic FLOP per launch / chip time per launch (union of the HIP-event "
                         "intervals / launches), as for `roofline`"}
+        # ---- SURVEY 8d's unit of work is one aln_to_coords call: the whole chain alignment FILES -> PDB FILES through the
+        #      batch front end (read + encode + H2D + prediction + D2H + PDB text + write overlapped with the GPU by
+        #      dmpfold2_amd.batch), same configuration, on a pipeline of its own that takes over the timed pipeline's
+        #      streams.  Reported beside `value` (whose inputs are resident in HBM), never instead of it.
+        if world == 1 and not args.no_files_leg and not only_f32:
+            import shutil
+            import tempfile
+            from dmpfold2_amd import batch
+            pipe.close()
+            tmpd = tempfile.mkdtemp(prefix="dmp_bench_files_")
+            try:
+                nfiles = 3 * B
+                paths = []
+                for i in range(nfiles):
+                    paths.append(os.path.join(tmpd, "t%03d.aln" % i))
+                    synth.write_aln(paths[-1], synth.synth_msa(L_NS, N_NS, seed=700000 + i))
+                tw = time.perf_counter()
+                nb, secs, outs_f = batch.run_batch([(a, None) for a in paths], os.path.join(tmpd, "out"), ITERS, MINSTEPS,
+                                                   state_dict={k: torch.from_numpy(np.array(v)) for k, v in sd.items()},
+                                                   streams=S, device=str(device))
+                wall = time.perf_counter() - tw
+                line["files_to_pdb"] = {
+                    "structures_per_s": nb / wall, "targets": nb, "seconds": wall,
+                    "pdb_files_written": sum(1 for o in outs_f if os.path.getsize(o) > 0),
+                    "note": "alignment files -> PDB files through dmpfold2_amd.batch.run_batch (one call: pipeline set-up - "
+                            "contexts, one packed copy of the weights - reading, encoding, H2D, prediction, D2H, PDB text "
+                            "and writing all inside the clock; host work overlapped with the GPU); `value` has its inputs "
+                            "resident in HBM and stops at tensors on the device"}
+            finally:
+                shutil.rmtree(tmpd, ignore_errors=True)
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             line["cpu_baseline"] = cpu_baseline(mode)

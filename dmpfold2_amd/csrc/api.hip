@@ -540,6 +540,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "cluster_local") { ctx->cluster_local = value ? 1 : 0; return DMP_OK; }
   if (k == "refine_single") { ctx->refine_single = value ? 1 : 0; return DMP_OK; }
   if (k == "gj_pairs") { ctx->gj_pairs = value != 0; return DMP_OK; }
+  if (k == "gj_diag_blocked") { ctx->gj_diag_blocked = value != 0; return DMP_OK; }
   if (k == "gj_lookahead") { DMP_ARG(value >= 0 && value <= 2, "gj_lookahead must be 0, 1 or 2"); ctx->gj_lookahead = value; return DMP_OK; }
   if (k == "gj_diag_groups") { DMP_ARG(value == 2 || value == 4 || value == 8, "gj_diag_groups must be 2, 4 or 8"); ctx->gj_diag_groups = value; return DMP_OK; }
   if (k == "act_scaling") { ctx->act_scaling = value ? 1 : 0; return DMP_OK; }
@@ -594,6 +595,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "gj_diag_groups") { *h_value = ctx->gj_diag_groups; return DMP_OK; }
   if (k == "gj_lookahead") { *h_value = ctx->gj_lookahead; return DMP_OK; }
   if (k == "gj_pairs") { *h_value = ctx->gj_pairs; return DMP_OK; }
+  if (k == "gj_diag_blocked") { *h_value = ctx->gj_diag_blocked; return DMP_OK; }
   set_error("unknown option %s", name);
   return DMP_ERR_ARG;
 }

@@ -169,6 +169,142 @@ __global__ __launch_bounds__(128 * NH) void gj_diag_kernel(const float* __restri
 }
 
 typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
+typedef float gj_f32x4 __attribute__((ext_vector_type(4)));
+
+// Round 5: the same sweep, BLOCKED (option "gj_diag_blocked", the default).  The kernel above is a chain of 128 pivots,
+// each a round trip barrier -> LDS -> division -> update through eight waves (0.41 us per pivot alone, 2.5 us beside
+// two convolutions).  Sweeping a SET K of pivots at once is the block form of the same operator:
+//     P = inv(M_KK);   M_KK <- -P;   M_RK <- M_RK P  (= W);   M_RR <- M_RR - W M_KR
+// so the block is swept in 8 sub-blocks of 16: (1) the 16 x 16 pivot block by 16 scalar sweeps inside ONE wave (four
+// elements per lane; the pivot row goes through 16 words of LDS that only this wave touches - no workgroup barrier
+// inside the chain), (2) W = T P for the 128 rows on v_mfma_f32_16x16x4_f32 (one 16-row tile per wave), (3) the rank-16
+// update of the 128 x 128 block on v_mfma_f32_32x32x2_f32 (two 32 x 32 tiles per wave), (4) the pivot columns / rows
+// become W / W^T.  The matrix lives in LDS (pitch 129).  Identity padding of a partial last block is swept like real
+// pivots (d = 1: the row stays e_k), so there is no special case.  Different order of operations from the scalar chain:
+// the inverse agrees with it to float32 rounding, not bit for bit (tests: against the oracle's inverse at 1e-5).
+constexpr int GD_MP = GJ_NB + 1;                              // 129: pitch of the block in LDS
+constexpr int GD_WP = 17;                                    // pitch of W [128][16] and of the pivot block's inverse [16][16]
+constexpr int GJ_DIAGB_LDS = (GJ_NB * GD_MP + GJ_NB * GD_WP + 16 * GD_WP + 16) * 4;       // 77 904 bytes
+__global__ __launch_bounds__(512) void gj_diag_blocked_kernel(const float* __restrict__ A, int D, int k0, int bs,
+                                                              float* __restrict__ P) {
+  extern __shared__ __attribute__((aligned(16))) float gd_smem[];
+  float* M = gd_smem;                                          // [128][129]
+  float* Wl = M + GJ_NB * GD_MP;                               // [128][17]
+  float* Pb = Wl + GJ_NB * GD_WP;                              // [16][17]
+  float* rowk = Pb + 16 * GD_WP;                               // [16] (16-byte aligned: every size above is a multiple of 4 words)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    // all 32 loads of a thread in flight at once (as a loop the compiler issued them one by one, each behind a
+    // vmcnt(0): 32 trips to memory = more than the whole sweep)
+    float reg[GJ_NB * GJ_NB / 512];
+#pragma unroll
+    for (int it = 0; it < GJ_NB * GJ_NB / 512; ++it) {
+      const int e = tid + 512 * it, i = e >> 7, j = e & 127;
+      const bool in = i < bs && j < bs;
+      const float v = A[(int64_t)(k0 + (in ? i : 0)) * D + k0 + (in ? j : 0)];
+      reg[it] = in ? v : (i == j ? 1.f : 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < GJ_NB * GJ_NB / 512; ++it) {
+      const int e = tid + 512 * it;
+      M[(e >> 7) * GD_MP + (e & 127)] = reg[it];
+    }
+  }
+  __syncthreads();
+  const int kk = lane >> 5, li = lane & 31;
+  for (int b = 0; b < GJ_NB / 16; ++b) {
+    const int kb = 16 * b;
+    if (wave == 0) {
+      // (1) the pivot block by 16 scalar sweeps (the operator of gj_diag_kernel): lane (c, rg) holds rows 4 rg .. 4 rg + 3 of
+      // column c; row k is published through `rowk`, which only this wave reads and writes (LDS operations of one wave
+      // complete in order; the wavefront-scope fences keep the compiler from moving them across each other)
+      const int c = lane & 15, rg = lane >> 4;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = M[(kb + 4 * rg + i) * GD_MP + kb + c];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (rg == (k >> 2)) rowk[c] = v[k & 3];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float rc = rowk[c], d = rowk[k];
+        const gj_f32x4 rr = *reinterpret_cast<const gj_f32x4*>(rowk + 4 * rg);      // a_ik = a_ki by symmetry
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float invd = __builtin_amdgcn_rcpf(d);                // 1 ulp, + one Newton step: the IEEE division is ten
+        invd = fmaf(fmaf(-d, invd, 1.0f), invd, invd);        // dependent instructions on the critical path of every pivot
+        const bool ck = c == k;
+        const float bj = rc * invd;
+        const float mul = ck ? -invd : bj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaf(-rr[i], mul, ck ? 0.f : v[i]);
+        if (rg == (k >> 2)) v[k & 3] = ck ? -invd : bj;       // the pivot row itself
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        M[(kb + 4 * rg + i) * GD_MP + kb + c] = v[i];          // M_KK <- -P
+        Pb[(4 * rg + i) * GD_WP + c] = -v[i];
+      }
+    }
+    __syncthreads();
+    {
+      // (2) W = T P, T = the pivot columns (rows inside K give values nobody uses); wave w: rows 16 w .. 16 w + 15
+      const int c = lane & 15, kq = lane >> 4;
+      gj_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(M[(16 * wave + c) * GD_MP + kb + 4 * s4 + kq], Pb[(4 * s4 + kq) * GD_WP + c],
+                                                   acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wl[(16 * wave + 4 * kq + r) * GD_WP + c] = acc[r];
+    }
+    __syncthreads();
+    // (3) M_RR <- M_RR - W T^T, rows and columns outside K; wave w: the 32 x 32 tiles 2 w, 2 w + 1 of the 4 x 4
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * wave + tt, i0 = 32 * (t >> 2), j0 = 32 * (t & 3);
+      gj_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[(i0 + li) * GD_WP + 2 * s2 + kk], M[(j0 + li) * GD_MP + kb + 2 * s2 + kk],
+                                                   acc, 0, 0, 0);
+      // (rows / columns inside K keep their values: the subtraction of 0 rewrites what is there - T, which other waves
+      // are still reading, and -P - with the same bits; unconditional stores instead of sixteen branches)
+      const int col = j0 + li;
+      const bool col_ok = (col >> 4) != b;
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = M[(i0 + 8 * (r >> 2) + 4 * kk + (r & 3)) * GD_MP + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 8 * (r >> 2) + 4 * kk + (r & 3);
+        M[row * GD_MP + col] = (col_ok && (row >> 4) != b) ? old[r] - acc[r] : old[r];
+      }
+    }
+    __syncthreads();
+    // (4) the pivot columns and rows
+#pragma unroll
+    for (int it = 0; it < GJ_NB * 16 / 512; ++it) {
+      const int e = tid + 512 * it, r = e >> 4, c = e & 15;
+      if ((r >> 4) != b) {
+        const float w = Wl[r * GD_WP + c];
+        M[r * GD_MP + kb + c] = w;
+        M[(kb + c) * GD_MP + r] = w;
+      }
+    }
+    __syncthreads();
+  }
+  // P = inverse = -swept matrix; padding rows / columns of a partial block are the identity again
+#pragma unroll 8
+  for (int it = 0; it < GJ_NB * GJ_NB / 512; ++it) {
+    const int e = tid + 512 * it, i = e >> 7, j = e & 127;
+    P[e] = (i < bs && j < bs) ? -M[i * GD_MP + j] : (i == j ? 1.f : 0.f);
+  }
+}
 
 // Everything of a block step between the diagonal block's inverse P and the trailing update, for one strip of 64
 // matrix rows / columns per workgroup (round 4: four launches before - the refresh of the stale upper triangle, the
@@ -477,6 +613,7 @@ int gj_kernel_attrs(dmp_ctx* c) {
   static bool done[64] = {};
   if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
   DMP_HIP(hipFuncSetAttribute((const void*)gj_cross_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GJ_CROSS_LDS));
+  DMP_HIP(hipFuncSetAttribute((const void*)gj_diag_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GJ_DIAGB_LDS));
   if (c->device >= 0 && c->device < 64) done[c->device] = true;
   return DMP_OK;
 }
@@ -528,7 +665,8 @@ int spd_inverse_steps(dmp_ctx* c, float* A, int D, int blk_lo, int blk_hi, hipSt
   auto RTb = [&](int k) { return reinterpret_cast<float4*>(c->gj_rt + (k & 1) * pan); };
   auto prepare = [&](int k, hipStream_t st) -> int {    // P, panels and row write-back of step k
     const int k0 = k * GJ_NB, bs = std::min(GJ_NB, D - k0);
-    if (c->gj_diag_groups == 2) hipLaunchKernelGGL(gj_diag_kernel<2>, dim3(1), dim3(256), 0, st, A, D, k0, bs, Pb(k));
+    if (c->gj_diag_blocked) hipLaunchKernelGGL(gj_diag_blocked_kernel, dim3(1), dim3(512), GJ_DIAGB_LDS, st, A, D, k0, bs, Pb(k));
+    else if (c->gj_diag_groups == 2) hipLaunchKernelGGL(gj_diag_kernel<2>, dim3(1), dim3(256), 0, st, A, D, k0, bs, Pb(k));
     else if (c->gj_diag_groups == 8) hipLaunchKernelGGL(gj_diag_kernel<8>, dim3(1), dim3(1024), 0, st, A, D, k0, bs, Pb(k));
     else hipLaunchKernelGGL(gj_diag_kernel<4>, dim3(1), dim3(512), 0, st, A, D, k0, bs, Pb(k));
     DMP_LAUNCH_CHECK();

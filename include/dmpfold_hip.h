@@ -109,6 +109,10 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * agent-scope stores, the protocol that does not depend on placement.  Same bits, 1.84 against 2.8 us per GRU step.
  * "gj_diag_groups" = 2 / 4 / 8: threads (x 128) of the one-workgroup diagonal sweep of the inverse; same bits; 4 is the
  * default (8.9 against 10.0 ms per inverse at D = 6300 with 2, the form of rounds 1-3).
+ * "gj_diag_blocked" (default 1, round 5): the 128 x 128 diagonal block of a block step is swept in 8 sub-blocks of 16
+ * pivots (the pivot block inside one wave, W = T P and the rank-16 update on the f32 matrix cores) instead of as a chain
+ * of 128 barrier-synchronised pivots; 0 = that chain (the arithmetic of rounds 1-4; "gj_diag_groups" applies to it).  The
+ * two agree to float32 rounding, not bit for bit.
  * "gj_pairs" (default 1): the inverse takes its 128-column block steps in pairs - one pass of the trailing update over
  * the matrix tiles per two steps (119 against 173 ms at D = 21 000, 20.4 against 26.0 at D = 10 500, equal at D = 6300);
  * 0 = one pass per step.  Same bits.

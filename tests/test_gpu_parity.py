@@ -150,6 +150,33 @@ def test_spd_inverse_pairs_and_lookahead_are_bitwise_the_serial_order(st_engine)
         st.eng.set_option("gj_pairs", 1)
 
 
+def test_spd_inverse_blocked_diagonal_sweep_vs_the_pivot_chain(st_engine):
+    """Round 5 (option gj_diag_blocked, the default): the 128 x 128 diagonal block swept in 8 sub-blocks of 16 pivots
+    (pivot block inside one wave, W = T P and the rank-16 update on the f32 matrix cores) against the chain of 128
+    barrier-synchronised pivots of rounds 1-4: the same operator in another order - the inverses agree to float32
+    rounding - for one block, a ragged last block, the front end's 21 L sizes; both satisfy A inv(A) = I."""
+    st = st_engine
+    rng = np.random.default_rng(11)
+    try:
+        for D in (16, 100, 128, 129, 21 * 30, 21 * 61, 1536):
+            X = rng.standard_normal((D, 2 * D)).astype(np.float32)
+            A = X @ X.T / (2 * D) + 0.5 * np.eye(D, dtype=np.float32)
+            out = {}
+            for blocked in (1, 0):
+                st.eng.set_option("gj_diag_blocked", blocked)
+                assert st.eng.get_option("gj_diag_blocked") == blocked
+                out[blocked] = st.spd_inverse(st.to(A)).cpu().numpy()
+            st.eng.sync_check()
+            ref = np.linalg.inv(A.astype(np.float64))
+            scale = np.abs(ref).max()
+            assert np.abs(out[1] - out[0]).max() <= 1e-5 * scale, D
+            # ... and the blocked form is no further from the float64 inverse than the chain (x 2)
+            assert np.abs(out[1] - ref).max() <= max(2.0 * np.abs(out[0] - ref).max(), 1e-6 * scale), D
+            assert np.abs(out[1].astype(np.float64) @ A - np.eye(D)).max() < 5e-5
+    finally:
+        st.eng.set_option("gj_diag_blocked", 1)
+
+
 def test_spd_inverse_identity_property(st):
     rng = np.random.default_rng(3)
     for D in (21 * 9, 21 * 13 + 0, 300):

@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""Turn the rocprofv3 outputs of tools/profile_r04.sh (gpurun_out/prof_bench, prof_bench_f32, pmc) into the small
+"""Turn the rocprofv3 outputs of tools/profile_r05.sh (gpurun_out/prof_bench, prof_bench_f32, pmc) into the small
 tracked files under profiles/:
 
-    python tools/summarize_profiles.py r04
+    python tools/summarize_profiles.py r05
 
   profiles/<tag>_bench_kernel_stats_f16x3.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1 --legs f16x3`
-  profiles/<tag>_bench_kernel_stats_f32.csv     the same of `--legs f32` (the exact-f32 MFMA convolution)
+  profiles/<tag>_bench_kernel_stats_f32.csv     the same of `--legs f32` (option precision = 1: float32 convolutions AND float32
+                                                vertical GRU; the script fails if an f16 / bf16 matrix-core kernel appears in it)
   profiles/<tag>_conv5x5_pmc.txt / _f32_pmc.txt PMC counters of conv5x5_f16x3_kernel / conv5x5_maxout_kernel (separate --pmc passes)
   profiles/conv5x5_pmc.json, conv5x5_f32_pmc.json   HBM traffic per conv launch, read by bench.py (roofline.traffic, roofline_f32.traffic)
 
@@ -22,7 +23,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -34,6 +35,15 @@ for sub, leg in (("prof_bench", "f16x3"), ("prof_bench_f32", "f32")):
         for line in open(os.path.join(G, sub, "bench_under_rocprof.log")):
             if line.startswith("{"):
                 open(os.path.join(P, f"{tag}_bench_under_rocprof_{leg}.json"), "w").write(line)
+
+
+# the float32 leg runs the reference's arithmetic end to end: none of the split-product kernels may appear in its table
+f32_stats = os.path.join(P, f"{tag}_bench_kernel_stats_f32.csv")
+if os.path.exists(f32_stats):
+    bad = [r["Name"] for r in csv.DictReader(open(f32_stats))
+           if any(k in r["Name"] for k in ("f16x3", "bf16x6", "vgru_persist_kernel(", "vgru2_step_kernel", "act_split_kernel"))]
+    print("float32 leg: f16 / bf16 matrix-core kernels in its kernel table:", bad or "none")
+    assert not bad, bad
 
 
 def counters(name):
@@ -73,7 +83,7 @@ for sfx, kernel, src, out_txt, out_json, expect in (
     # algorithmic bytes per launch: input activations (f16x3: two f16 pieces = 4 B per value; f32: 4 B) + weights + output
     algo = 4.0 * (128 * L * L + 512 * 128 * 25 + 128 * L * L)
     with open(os.path.join(P, out_txt), "w") as fh:
-        fh.write(f"# {kernel}, L=300, 16 launches of one trunk pass; rocprofv3 --pmc passes (tools/profile_r04.sh)\n")
+        fh.write(f"# {kernel}, L=300, 16 launches of one trunk pass; rocprofv3 --pmc passes (tools/profile_r05.sh)\n")
         fh.write("\n".join(lines) + "\n")
         if gui and busy:
             # GRBM_GUI_ACTIVE sums the 8 XCDs; MFMA busy cycles sum over the 1024 SIMDs
