@@ -180,7 +180,7 @@ struct dmp_ctx {
   unsigned long long* tri_gx = nullptr;    // [2][4][min(max_L, 640)] hand-off granules of the tridiagonalisation cluster + [2] placement header
   int refine_single = 0;                   // option: 1 = single-workgroup minimiser
   int gj_diag_groups = 4;                  // option: row groups of the diagonal sweep (2 = 256 threads as in rounds 1-3, 4 = 512 threads)
-  int gj_diag_blocked = 1;                 // option: the diagonal block swept in 8 sub-blocks of 16 pivots (round 5); 0 = the chain of 128 pivots
+  int gj_diag_blocked = 0;                 // option: 1 = the diagonal block swept in 8 sub-blocks of 16 pivots (round 5); 0 (default) = the chain of 128 pivots
   float* vout = nullptr;    // [L][512]
   float* seq_g = nullptr;   // [L][1536] input projections, both directions
   float* seq_a = nullptr;   // [L][512]

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(128 * NH) void gj_diag_kernel(const float* __restri
 typedef float gj_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gj_f32x4 __attribute__((ext_vector_type(4)));
 
-// Round 5: the same sweep, BLOCKED (option "gj_diag_blocked", the default).  The kernel above is a chain of 128 pivots,
+// Round 5: the same sweep, BLOCKED (option "gj_diag_blocked" = 1; the chain above stays the default, see the header).  The kernel above is a chain of 128 pivots,
 // each a round trip barrier -> LDS -> division -> update through eight waves (0.41 us per pivot alone, 2.5 us beside
 // two convolutions).  Sweeping a SET K of pivots at once is the block form of the same operator:
 //     P = inv(M_KK);   M_KK <- -P;   M_RK <- M_RK P  (= W);   M_RR <- M_RR - W M_KR
@@ -182,6 +182,9 @@ typedef float gj_f32x4 __attribute__((ext_vector_type(4)));
 // become W / W^T.  The matrix lives in LDS (pitch 129).  Identity padding of a partial last block is swept like real
 // pivots (d = 1: the row stays e_k), so there is no special case.  Different order of operations from the scalar chain:
 // the inverse agrees with it to float32 rounding, not bit for bit (tests: against the oracle's inverse at 1e-5).
+#ifndef GD_FAST_RCP
+#define GD_FAST_RCP 0
+#endif
 constexpr int GD_MP = GJ_NB + 1;                              // 129: pitch of the block in LDS
 constexpr int GD_WP = 17;                                    // pitch of W [128][16] and of the pivot block's inverse [16][16]
 constexpr int GJ_DIAGB_LDS = (GJ_NB * GD_MP + GJ_NB * GD_WP + 16 * GD_WP + 16) * 4;       // 77 904 bytes
@@ -233,8 +236,12 @@ __global__ __launch_bounds__(512) void gj_diag_blocked_kernel(const float* __res
         const gj_f32x4 rr = *reinterpret_cast<const gj_f32x4*>(rowk + 4 * rg);      // a_ik = a_ki by symmetry
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float invd = __builtin_amdgcn_rcpf(d);                // 1 ulp, + one Newton step: the IEEE division is ten
-        invd = fmaf(fmaf(-d, invd, 1.0f), invd, invd);        // dependent instructions on the critical path of every pivot
+#if GD_FAST_RCP
+        float invd = __builtin_amdgcn_rcpf(d);                // 1 ulp, + one Newton step (the IEEE division is ten dependent
+        invd = fmaf(fmaf(-d, invd, 1.0f), invd, invd);        // instructions on the critical path of every pivot: 2 us per sweep)
+#else
+        const float invd = 1.0f / d;
+#endif
         const bool ck = c == k;
         const float bj = rc * invd;
         const float mul = ck ? -invd : bj;

@@ -27,7 +27,11 @@
 extern "C" {
 #endif
 
-/* 3 (round 4): 45 functions instead of 60.  Removed: the experimental scheduler entry points that were measured
+/* 4 (round 5): 47 functions.  New: dmp_block_conv5x5_maxout_winners (the training slice's forward: maxout output + the
+ *    winners autograd saves) and dmp_head_conv_bwd; dmp_block_conv5x5_maxout_bwd takes the saved winners (d_idx, NULL = run
+ *    the forward again: the ABI-3 behaviour).  New options: precision (0 split-f16 / 1 the reference's float32 end to end),
+ *    vgru_f32, gj_diag_blocked.
+ * 3 (round 4): 45 functions instead of 60.  Removed: the experimental scheduler entry points that were measured
  *    slower (detached group chain, chain on its own stream, features ahead: six functions), the convenience wrappers
  *    predict_begin / predict_pass / predict_end_refine - dmp_predict and the unit calls cover them -, clear_faults and
  *    sync_check - dmp_sync_faults reports and clears -, profile_conv_ms and time_conv5x5 - dmp_profile_conv_intervals
@@ -109,10 +113,14 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * agent-scope stores, the protocol that does not depend on placement.  Same bits, 1.84 against 2.8 us per GRU step.
  * "gj_diag_groups" = 2 / 4 / 8: threads (x 128) of the one-workgroup diagonal sweep of the inverse; same bits; 4 is the
  * default (8.9 against 10.0 ms per inverse at D = 6300 with 2, the form of rounds 1-3).
- * "gj_diag_blocked" (default 1, round 5): the 128 x 128 diagonal block of a block step is swept in 8 sub-blocks of 16
+ * "gj_diag_blocked" (round 5, default 0): 1 = the 128 x 128 diagonal block of a block step is swept in 8 sub-blocks of 16
  * pivots (the pivot block inside one wave, W = T P and the rank-16 update on the f32 matrix cores) instead of as a chain
- * of 128 barrier-synchronised pivots; 0 = that chain (the arithmetic of rounds 1-4; "gj_diag_groups" applies to it).  The
- * two agree to float32 rounding, not bit for bit.
+ * of 128 barrier-synchronised pivots (0: the arithmetic of rounds 1-4; "gj_diag_groups" applies to it).  The blocked form
+ * is faster (6.6 against 7.65 ms per inverse at D = 6300, 18.4 against 20.2 at D = 10 500) and closer to the float64
+ * inverse (4.5e-7 against 8.7e-7 of max |inv| at D = 630); the two agree to 1.1e-6, not bit for bit - and on three of the
+ * reference's recycling fixtures (L = 200, ten passes; the x 4 weight set) that difference, amplified by eleven trunk
+ * passes, moves a confidence by 1.4 .. 2.0e-4 from the reference's where the chain's stays below 1e-4, so the chain
+ * remains the default of the prediction path.
  * "gj_pairs" (default 1): the inverse takes its 128-column block steps in pairs - one pass of the trailing update over
  * the matrix tiles per two steps (119 against 173 ms at D = 21 000, 20.4 against 26.0 at D = 10 500, equal at D = 6300);
  * 0 = one pass per step.  Same bits.

@@ -198,6 +198,19 @@ def test_no_hazardous_packed_f32_instruction_in_any_kernel():
     assert not lint.hazardous("\tv_pk_mul_f32 v[4:5], v[10:11], v[2:3] op_sel_hi:[1,0]")
     assert not lint.hazardous("\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1] op_sel_hi:[1,1,0]")
     assert not lint.hazardous("\tv_pk_mov_b32 v[2:3], v[6:7], v[6:7] op_sel:[1,0]")
+    # second rule (round 5): a VALU write of an operand of an INLINE-ASSEMBLY MFMA fewer than two wait states ahead of it
+    # (the compiler does not see the MFMA as a reader: found on the GPU in the first build of vgru_f32.hip)
+    asm = lambda body: "kern:\n" + body                  # noqa: E731
+    mfma = "\t;;#ASMSTART\n\tv_mfma_f32_16x16x4_f32 v[98:101], a16, v62, v[98:101]\n\t;;#ASMEND\n"
+    assert lint.scan_asm_mfma_hazards(asm("\tv_mov_b64_e32 v[98:99], s[28:29]\n" + mfma))            # the measured failure
+    assert lint.scan_asm_mfma_hazards(asm("\tv_mov_b64_e32 v[98:99], s[28:29]\n\tv_mov_b32_e32 v7, v8\n" + mfma))   # one slot
+    assert lint.scan_asm_mfma_hazards(asm("\tv_mov_b32_e32 v62, v8\n" + mfma))                          # srcB
+    assert not lint.scan_asm_mfma_hazards(asm("\tv_mov_b64_e32 v[98:99], s[28:29]\n\ts_nop 1\n" + mfma))   # two wait states
+    assert not lint.scan_asm_mfma_hazards(asm("\tv_mov_b64_e32 v[98:99], s[28:29]\n\t;;#ASMSTART\n\ts_nop 1\n"
+                                              "\tv_mfma_f32_16x16x4_f32 v[98:101], a16, v62, v[98:101]\n\t;;#ASMEND\n"))
+    assert not lint.scan_asm_mfma_hazards(asm("\tv_mov_b64_e32 v[90:91], s[28:29]\n" + mfma))           # another register
+    assert not lint.scan_asm_mfma_hazards(asm("\tv_mov_b64_e32 v[98:99], s[28:29]\n"                    # a builtin MFMA: the
+                                              "\tv_mfma_f32_16x16x4_f32 v[98:101], a16, v62, v[98:101]\n"))  # compiler's own business
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     assert lint.main() == 0

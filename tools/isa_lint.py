@@ -16,6 +16,14 @@ op_sel:[1,1], v_pk_mov_b32.
 This script compiles every translation unit of the library to gfx950 assembly with the library's flags
 and fails (exit 1) if any kernel contains a packed-f32 instruction with op_sel[1] = 1 (a superset of the
 measured condition).  It is run by tests/test_host_cpu.py and by __graft_entry__.build().
+
+Second rule (round 5).  MFMAs written as INLINE ASSEMBLY (the vertical GRU's weight-stationary kernels read their A
+operand straight from AGPRs, which the builtins cannot express) are invisible to the compiler's hazard recogniser.
+Found on the GPU: the compiler sank the zero-initialisation of an accumulator (v_mov_b64) to directly in front of
+its first assembly MFMA, and that MFMA accumulated onto the stale register pair (vgru_f32.hip, first build: columns
+16..31, rows 4g and 4g+1 wrong by 2e-2).  The kernels now pin their accumulators behind a statement with wait states;
+this lint checks the result: no VALU instruction may write a VGPR that an assembly MFMA reads (srcA, srcB or srcC)
+fewer than two wait states ahead of it.
 """
 import os
 import re
@@ -53,6 +61,66 @@ def scan_asm(text):
     return found
 
 
+REG = re.compile(r"\bv(?:\[(\d+):(\d+)\]|(\d+)\b)")
+INS = re.compile(r"^\s*([a-z_][a-z0-9_]*)\s*(.*)$")
+NOT_VGPR_WRITERS = ("v_cmp", "v_cmpx", "v_readlane", "v_readfirstlane", "v_mfma", "v_smfmac", "v_accvgpr_read", "v_nop")
+
+
+def vregs(text):
+    out = set()
+    for lo, hi, one in REG.findall(text):
+        if one:
+            out.add(int(one))
+        else:
+            out.update(range(int(lo), int(hi) + 1))
+    return out
+
+
+def scan_asm_mfma_hazards(text, need=2):
+    """-> list of (symbol, VALU instruction, MFMA) where a VALU write of an operand of an inline-assembly MFMA is fewer than
+    `need` wait states ahead of it"""
+    found, sym, in_asm = [], "?", False
+    hist = []                                            # (instruction text, VGPRs written by a VALU or None, wait states it provides)
+    for raw in text.split("\n"):
+        line = raw.split(";")[0] if not raw.strip().startswith(";;#") else raw
+        m = LABEL.match(line)
+        if m and not line.startswith(".L"):
+            sym, hist = m.group(1), []
+        st = raw.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if st.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        mi = INS.match(line)
+        if not mi or line.strip().startswith(".") or line.strip().endswith(":"):
+            continue
+        op, rest = mi.group(1), mi.group(2)
+        if op == "s_nop":
+            hist.append((line.strip(), None, int(rest.strip() or 0) + 1))
+            continue
+        if in_asm and op.startswith("v_mfma"):
+            ops = [o.strip() for o in rest.split(",")]
+            reads = set()
+            for o in ops[1:4]:
+                reads |= vregs(o)
+            waited = 0
+            for txt, writes, ws in reversed(hist[-6:]):
+                if waited >= need:
+                    break
+                if writes is not None and writes & reads:
+                    found.append((sym, txt, line.strip()))
+                    break
+                waited += ws
+        writes = None
+        if op.startswith("v_") and not op.startswith(NOT_VGPR_WRITERS):
+            writes = vregs(rest.split(",")[0])
+        hist.append((line.strip(), writes, 1))
+        del hist[:-8]
+    return found
+
+
 def device_asm(src, flags):
     from dmpfold2_amd import build as B
     cmd = [B._hipcc()] + [f for f in flags if f not in ("-fPIC", "-c")] + ["-S", "--cuda-device-only", src, "-o", "-"]
@@ -70,16 +138,21 @@ def main():
         path = os.path.join(B.CSRC, src)
         # exactly the flags of the shipped objects, tuning extras included (build.py)
         extra = os.environ.get("DMP_EXTRA_HIPCC_FLAGS", "").split()
-        return src, scan_asm(device_asm(path, B.FLAGS + extra + B.per_file_flags(src)))
+        text = device_asm(path, B.FLAGS + extra + B.per_file_flags(src))
+        return src, scan_asm(text), scan_asm_mfma_hazards(text)
 
-    bad = 0
+    bad = bad2 = 0
     with ThreadPoolExecutor(max_workers=4) as ex:
-        for src, found in ex.map(one, B.SOURCES):
+        for src, found, found2 in ex.map(one, B.SOURCES):
             for sym, ins in found:
                 print("%s: %s: %s" % (src, sym, ins))
+            for sym, valu, mfma in found2:
+                print("%s: %s: VALU write too close to an assembly MFMA that reads it: %s  ->  %s" % (src, sym, valu, mfma))
             bad += len(found)
+            bad2 += len(found2)
     print("isa_lint: %d hazardous packed instruction(s)" % bad)
-    return 1 if bad else 0
+    print("isa_lint: %d VALU write(s) within two wait states of an inline-assembly MFMA that reads them" % bad2)
+    return 1 if (bad or bad2) else 0
 
 
 if __name__ == "__main__":

@@ -4,9 +4,6 @@
 # timings of the stages that changed this round, the bench itself; summaries are copied to profiles/ by
 # tools/summarize_profiles.py r05.  Every step under its own timeout.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r05prof; mkdir -p $O; cd $R
-# the arithmetic of the default path changed this round (blocked diagonal sweep of the inverse): new digest first
-DMP_WRITE_DIGEST=1 timeout 600 python bench.py --steps 1 --warmup 1 --legs f16x3 --no-cpu-baseline --no-files-leg > $O/digest_run.json 2> $O/digest_run.err
-cp profiles/bench_digest.json $O/bench_digest.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_bench $R/gpurun_out/prof_bench_f32 $R/gpurun_out/pmc /tmp/single_prof
 mkdir -p $R/gpurun_out/prof_bench $R/gpurun_out/prof_bench_f32 $R/gpurun_out/pmc
