@@ -159,6 +159,18 @@ def raise_for_faults(bits):
 # ---------------------------------------------------------------------------
 # engine: one dmp_ctx per GPU
 # ---------------------------------------------------------------------------
+def _env_precision():
+    """DMPFOLD_PRECISION=1 selects the reference's float32 arithmetic end to end (option "precision": float32 matrix-core
+    convolutions and vertical GRU, about a third of the default's speed) for the drop-in entry points - aln_to_coords, the
+    CLI, the batch front end - which have no argument for it; 0 / unset = the default split-f16 products."""
+    v = os.environ.get("DMPFOLD_PRECISION", "").strip()
+    if v == "":
+        return None
+    if v not in ("0", "1"):
+        raise ValueError(f"DMPFOLD_PRECISION must be 0 or 1, got {v!r}")
+    return int(v)
+
+
 class Engine:
     """Owns one `dmp_ctx` (device buffers + packed weights) on one GPU."""
 
@@ -174,6 +186,9 @@ class Engine:
                                                C.byref(self._ctx)))
         self.weights_tag = None
         self.last_fallback = False     # the last predict_*_checked call fell back to conv_mode 2
+        prec = _env_precision()
+        if prec is not None:
+            self.set_option("precision", prec)
 
     def close(self):
         if self._ctx:

@@ -627,6 +627,40 @@ def test_two_part_default_weights_route(synth_sd, tmp_path, monkeypatch, weights
     P._ENGINES.clear()
 
 
+def test_env_selects_the_references_float32_arithmetic_for_the_drop_in_api(monkeypatch, weights_file, synth_sd):
+    """DMPFOLD_PRECISION=1: aln_to_coords / the CLI have no argument for the arithmetic, so the environment selects option
+    "precision" = 1 (float32 matrix-core convolutions and vertical GRU) for the engines they create; the result is the bits
+    of an engine set to precision 1 by hand, and differs from the default's."""
+    from dmpfold2_amd import predict as P
+    aln = os.path.join(os.path.dirname(__file__), "golden", "PF10963.aln")
+    P._ENGINES.clear()
+    c0, f0 = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=weights_file)
+    P._ENGINES.clear()
+    monkeypatch.setenv("DMPFOLD_PRECISION", "1")
+    try:
+        c1, f1 = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=weights_file)
+        eng = P._ENGINES[0]
+        assert eng.get_option("precision") == 1 and eng.get_option("vgru_f32") == 1 and eng.get_option("conv_mode") == 1
+    finally:
+        monkeypatch.delenv("DMPFOLD_PRECISION")
+        P._ENGINES.clear()
+    alnmat = P.encode_aln(P.read_aln(aln))
+    e = P.Engine("cuda:0", alnmat.shape[1], alnmat.shape[0])
+    try:
+        e.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+        assert e.get_option("precision") == 0
+        e.set_option("precision", 1)
+        c2, f2 = e.predict_checked(alnmat, None, 1, 0)
+    finally:
+        e.close()
+    assert torch.equal(c1, c2) and torch.equal(f1, f2)
+    assert not torch.equal(c0, c1)
+    assert float((c0[:, 1] - c1[:, 1]).pow(2).sum(-1).mean().sqrt()) < 1e-3       # ... by rounding only
+    monkeypatch.setenv("DMPFOLD_PRECISION", "2")
+    with pytest.raises(ValueError, match="DMPFOLD_PRECISION"):
+        P.Engine("cuda:0", 64, 8)
+
+
 # ------------------------------------------------------------------ BASELINE config[3], sharded
 def _parse_pdb(text):
     ca, conf = [], None

@@ -588,14 +588,16 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
 
 
 @pytest.mark.parametrize("persistent", [1, 0])
-@pytest.mark.parametrize("group,riders", [(1, 4), (2, 4), (4, 4), (4, 0), (2, 6), (3, 2), (4, 7)])
-def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(synth_sd, monkeypatch, group, riders, persistent):
+@pytest.mark.parametrize("group,riders,precision", [(1, 4, 0), (2, 4, 0), (4, 4, 0), (4, 0, 0), (2, 6, 0), (3, 2, 0), (4, 7, 0),
+                                                    (4, 4, 1), (2, 6, 1)])
+def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(synth_sd, monkeypatch, group, riders, persistent, precision):
     """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE chain (the group
     leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so groups of every
     size up to `group` form.  riders: a group's chain also serves up to that many of the NEXT targets in the queue
     (dmp_predict_group_riders; members + riders <= 8), handed over when those targets start
     (dmp_predict_set_vgru_result).  Every result equals the single engine's, bit for bit - in the persistent
-    weight-stationary form of the chain (one launch) and in the launch-per-row form."""
+    weight-stationary form of the chain (one launch) and in the launch-per-row form; precision = 1 (round 5): the same
+    with the float32 vertical GRU (vgru_f32.hip) and the float32 convolutions."""
     from dmpfold2_amd import synth
     from dmpfold2_amd.predict import Engine, Pipeline, encode_aln
     monkeypatch.setenv("DMP_VGRU_GROUP", str(group))
@@ -606,10 +608,13 @@ def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(synth_sd, monkeypatch
     single = Engine(dev, 128, 512)
     single.set_weights(synth_sd)
     single.set_option("vgru_persistent", persistent)
+    single.set_option("precision", precision)
     single.set_option("tridiag_cluster", 0)                 # as the scheduler's engines (LIKE_PIPELINE)
     pipe = Pipeline(dev, 128, 512, synth_sd, streams=4)
     for e in pipe.engines:
         e.set_option("vgru_persistent", persistent)
+        e.set_option("precision", precision)
+    assert pipe.engines[0].get_option("vgru_f32") == precision
     assert pipe.engines[0].get_option("vgru_persistent") == persistent        # a 256-CU device has the persistent form
     assert pipe._group_max == group and pipe._riders_max == riders
     rode = []

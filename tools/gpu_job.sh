@@ -3,4 +3,5 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/job; mkdir -p $OUT
 timeout 2400 python -m pytest tests -q -m gpu > $OUT/all.log 2>&1; tail -5 $OUT/all.log
-bash tools/profile_r05.sh > $OUT/profile_r05.log 2>&1; tail -12 $OUT/profile_r05.log | cut -c 1-300
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 700 $OUT/bench.json
