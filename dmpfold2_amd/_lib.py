@@ -41,6 +41,8 @@ SIGNATURES = {
     "dmp_block_conv5x5_maxout_winners": (_i, [_vp, _i, _fp, _i, _fp, _vp, _vp]),
     "dmp_block_norm_scse_residual_bwd": (_i, [_vp, _i, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_head_conv_bwd": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
+    "dmp_stem_maxout_winners": (_i, [_vp, _fp, _fp, _i, _fp, _vp, _vp]),
+    "dmp_stem_bwd": (_i, [_vp, _fp, _vp, _fp, _fp, _fp, _i, _fp, _fp, _fp, _vp]),
     "dmp_head_gram": (_i, [_vp, _fp, _i, _fp, _fp, _vp]),
     "dmp_trunk_pass": (_i, [_vp, _fp, _fp, _i, _fp, _fp, _vp]),
     "dmp_eigh_top8": (_i, [_vp, _fp, _i, _fp, _vp]),

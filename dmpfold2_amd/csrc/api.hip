@@ -878,6 +878,21 @@ int dmp_block_norm_scse_residual_bwd(dmp_ctx* ctx, int block, const float* d_u, 
   return norm_scse_residual_bwd(ctx, block, d_u, d_dout, L, d_du, d_dparams, STREAM);
 }
 
+int dmp_stem_maxout_winners(dmp_ctx* ctx, const float* d_z0, const float* d_dmap, int L, float* d_u, uint8_t* d_idx, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_z0 && d_dmap && d_u && d_idx, "null argument");
+  return stem_maxout_fwd_winners(ctx, d_z0, d_dmap, L, d_u, d_idx, STREAM);
+}
+
+int dmp_stem_bwd(dmp_ctx* ctx, const float* d_u, const uint8_t* d_idx, const float* d_dy, const float* d_mat1d,
+                 const float* d_dmap, int L, float* d_dw, float* d_dparams, float* d_dmat1d, void* stream) {
+  CHECK_CAP(L, 1);
+  CHECK_W();
+  DMP_ARG(d_u && d_idx && d_dy && d_mat1d && d_dmap && d_dw && d_dparams && d_dmat1d, "null argument");
+  return stem_bwd(ctx, d_u, d_idx, d_dy, d_mat1d, d_dmap, L, d_dw, d_dparams, d_dmat1d, STREAM);
+}
+
 int dmp_head_conv_bwd(dmp_ctx* ctx, const float* d_x, const float* d_g, int L, float* d_dx, float* d_dparams, void* stream) {
   CHECK_CAP(L, 1);
   CHECK_W();

@@ -331,6 +331,9 @@ int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_d
 int norm_scse_residual_bwd(dmp_ctx* c, int block, const float* d_u, const float* d_dout, int L, float* d_du,
                            float* d_dparams, hipStream_t s);
 int head_conv_bwd(dmp_ctx* c, const float* d_x, const float* d_g, int L, float* d_dx, float* d_dparams, hipStream_t s);
+int stem_maxout_fwd_winners(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L, float* d_u, uint8_t* d_idx, hipStream_t s);
+int stem_bwd(dmp_ctx* c, const float* d_u, const uint8_t* d_idx, const float* d_dy, const float* d_mat1d, const float* d_dmap,
+             int L, float* d_dw, float* d_dparams, float* d_dmat1d, hipStream_t s);
 int head_gram_padded(dmp_ctx* c, const float* d_xpad, int L, float* d_conf, float* d_M,
                      hipStream_t s);
 int act_pad(const float* d_dense, int L, float* d_xpad, hipStream_t s);

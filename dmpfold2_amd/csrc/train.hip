@@ -55,6 +55,8 @@ constexpr int WG_KSPLIT = 12;                     // 64 x 12 = 768 workgroups = 
 constexpr int WG_TY = 8, WG_TX = 16, WG_HY = WG_TY + 4, WG_HX = WG_TX + 4;
 constexpr int WG_LP = 33;                         // LDS pitch of the wgrad tiles: [position][32 channels | 1 pad]
 constexpr int DB_CHUNKS = 16;                     // pixel chunks of the bias gradient's first stage
+constexpr int ST_OCH = 32;                        // stem backward: stem channels per panel of the outer-product weight gradient
+constexpr int ST_CCH = 64;                        // ... and sequence channels per panel of the mat1d gradient
 
 struct BwdWs { float* norm; float* xpad; float* wd; float* part; uint8_t* idx; };
 
@@ -69,7 +71,9 @@ static int bwd_workspace(dmp_ctx* c, BwdWs* w) {
   const int64_t n_norm = (norm_ws_floats(c->max_L) + 3) & ~(int64_t)3, n_xpad = (int64_t)CW * P * P;
   const int64_t n_wd = (int64_t)DG_MSPLIT * DG_NCHUNK * DG_WSLAB, n_part = (int64_t)WG_KSPLIT * 512 * 3200;
   const int64_t n_idx = ((int64_t)CW * L * L + 3) / 4;
-  const int64_t need = n_norm + n_xpad + n_wd + n_part + n_idx;
+  // the stem's backward (below) uses the space behind the norm region differently: DZ (384 L^2) + one GEMM panel
+  const int64_t n_stem = (int64_t)STEM_OUT * L * L + std::max<int64_t>((int64_t)ST_OCH * L * WIDTH, (int64_t)ST_CCH * L * L);
+  const int64_t need = n_norm + std::max(n_xpad + n_wd + n_part + n_idx, n_stem);
   if (!c->bwd_ws) {
     DMP_HIP(hipMalloc((void**)&c->bwd_ws, sizeof(float) * (size_t)need));
     c->bwd_ws_floats = need;
@@ -675,5 +679,184 @@ int norm_scse_residual_bwd(dmp_ctx* c, int block, const float* d_u, const float*
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// The stem, resnet[0] = Maxout2d(955 -> 128, pool 3, kernel 1) + InstanceNorm (network.py:194, 12-34), forwards with
+// the winners and backwards.  Its 955-channel input is never materialised, on the prediction path or here:
+//   channels 0..511    mat1d[c][i] mat1d[c][j]           (network.py:226-227; mat1d = the sequence trunk's output)
+//   channels 512..953  the covariance planes             (the context's c->planes, written by dmp_stem_static)
+//   channel  954       the distance / seed channel
+// With dz = the gradient at the 1x1 convolution's output (the routed d(u), 384 x L^2, dense: it is only 3 x d(u)):
+//   dW[o][c < 512]    = m_c^T DZ_o m_c          -> panels T = DZ_o M^T on the matrix cores (gemm_f32), then a row dot
+//   dW[o][512 + q]    = sum_p dz[o][p] planes[q][p]                  -> one GEMM (384 x 442 x L^2)
+//   dW[o][954], db[o] = sum_p dz[o][p] dmap[p], sum_p dz[o][p]
+//   d mat1d[c][i]     = sum_j (H_c[i][j] + H_c[j][i]) mat1d[c][j],  H = W[:, :512]^T DZ  -> panels of 64 channels (gemm_f32)
+//   d(u) from d(y): the InstanceNorm's backward, d gamma, d beta.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_maxout_winners_kernel(const float* __restrict__ z0, const float* __restrict__ wd,
+                                                                  const float* __restrict__ dmap, int64_t LL,
+                                                                  float* __restrict__ u, uint8_t* __restrict__ idx) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (p >= LL) return;
+  const float d = dmap[p];
+  float v = z0[(int64_t)(3 * g) * LL + p] + wd[3 * g] * d;
+  int win = 0;
+#pragma unroll
+  for (int q = 1; q < 3; ++q) {
+    const float t = z0[(int64_t)(3 * g + q) * LL + p] + wd[3 * g + q] * d;
+    if (t > v) { v = t; win = q; }                        // strict: the first maximal channel, as torch.max
+  }
+  u[(int64_t)g * LL + p] = v;
+  idx[(int64_t)g * LL + p] = (uint8_t)win;
+}
+
+int stem_maxout_fwd_winners(dmp_ctx* c, const float* d_z0, const float* d_dmap, int L, float* d_u, uint8_t* d_idx,
+                            hipStream_t s) {
+  const int64_t LL = (int64_t)L * L;
+  hipLaunchKernelGGL(stem_maxout_winners_kernel, dim3((unsigned)cdiv64(LL, 256), CW), dim3(256), 0, s, d_z0, c->W.stem_wd,
+                     d_dmap, LL, d_u, d_idx);
+  DMP_LAUNCH_CHECK();
+  return DMP_OK;
+}
+
+// per channel and pixel chunk: sum dy, sum dy uh          grid: (chunks, 128)   block: 256
+__global__ __launch_bounds__(256) void stem_in_sums_kernel(const float* __restrict__ u, const float* __restrict__ dy,
+                                                           const float* __restrict__ coef, int LL, double* __restrict__ part) {
+  const int c = blockIdx.y, nch = gridDim.x;
+  const float mean = coef[c * 4 + 2], rstd = coef[c * 4 + 3];
+  const int p1 = min(LL, (int)(blockIdx.x + 1) * 4096);
+  double v[2] = {0.0, 0.0};
+  for (int p = blockIdx.x * 4096 + threadIdx.x; p < p1; p += 256) {
+    const double d = (double)dy[(int64_t)c * LL + p];
+    v[0] += d;
+    v[1] += d * (double)((u[(int64_t)c * LL + p] - mean) * rstd);
+  }
+  __shared__ double red[4][2];
+  v[0] = wave_sum_f64(v[0]);
+  v[1] = wave_sum_f64(v[1]);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = v[0]; red[threadIdx.x >> 6][1] = v[1]; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    part[((int64_t)c * nch + blockIdx.x) * 2 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+// kco[c] = {gamma rstd, S1 / P, S2 / P, mean, rstd}; dparams[384 + c] = d gamma, [512 + c] = d beta      grid: 1, block: 128
+__global__ __launch_bounds__(128) void stem_in_finish_kernel(const double* __restrict__ part, int nch, double count,
+                                                             const float* __restrict__ coef, float* __restrict__ kco,
+                                                             float* __restrict__ dparams) {
+  const int c = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = 0; t < nch; ++t) { s1 += part[((int64_t)c * nch + t) * 2]; s2 += part[((int64_t)c * nch + t) * 2 + 1]; }
+  dparams[STEM_OUT + c] = (float)s2;
+  dparams[STEM_OUT + CW + c] = (float)s1;
+  kco[c * 8 + 0] = coef[c * 4 + 0];
+  kco[c * 8 + 1] = (float)(s1 / count);
+  kco[c * 8 + 2] = (float)(s2 / count);
+  kco[c * 8 + 3] = coef[c * 4 + 2];
+  kco[c * 8 + 4] = coef[c * 4 + 3];
+}
+// d(u) of the InstanceNorm and, routed by the winners, the dense dz (the two losers of a triple get 0)
+// grid: (ceil(LL / 256), 128)   block: 256
+__global__ __launch_bounds__(256) void stem_route_kernel(const float* __restrict__ u, const float* __restrict__ dy,
+                                                         const uint8_t* __restrict__ idx, const float* __restrict__ kco,
+                                                         int LL, float* __restrict__ dz) {
+  const int g = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= LL) return;
+  const float uh = (u[(int64_t)g * LL + p] - kco[g * 8 + 3]) * kco[g * 8 + 4];
+  const float du = kco[g * 8] * ((dy[(int64_t)g * LL + p] - kco[g * 8 + 1]) - uh * kco[g * 8 + 2]);
+  const int w = idx[(int64_t)g * LL + p];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) dz[(int64_t)(3 * g + q) * LL + p] = w == q ? du : 0.f;
+}
+// db[o] = sum_p dz[o][p], dW[o][954] = sum_p dz[o][p] dmap[p]        grid: 384   block: 256
+__global__ __launch_bounds__(256) void stem_bias_dist_kernel(const float* __restrict__ dz, const float* __restrict__ dmap, int LL,
+                                                             float* __restrict__ dparams, float* __restrict__ dw) {
+  __shared__ double red[4][2];
+  const int o = blockIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int p = threadIdx.x; p < LL; p += 256) {
+    const double v = (double)dz[(int64_t)o * LL + p];
+    a += v;
+    b += v * (double)dmap[p];
+  }
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dparams[o] = (float)(((red[0][0] + red[1][0]) + red[2][0]) + red[3][0]);
+    dw[(int64_t)o * STEM_IN + (STEM_IN - 1)] = (float)(((red[0][1] + red[1][1]) + red[2][1]) + red[3][1]);
+  }
+}
+// dW[o0 + o][c] = sum_i mat1d[c][i] T[(o L + i)][c]        grid: (2, ST_OCH)   block: 256 (thread = sequence channel c)
+__global__ __launch_bounds__(256) void stem_outer_dw_kernel(const float* __restrict__ T, const float* __restrict__ mat1d, int L,
+                                                            int o0, float* __restrict__ dw) {
+  const int c = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+  double acc = 0.0;
+  for (int i = 0; i < L; ++i) acc += (double)mat1d[(int64_t)c * L + i] * (double)T[((int64_t)o * L + i) * WIDTH + c];
+  dw[(int64_t)(o0 + o) * STEM_IN + c] = (float)acc;
+}
+// d mat1d[c0 + cl][i] = sum_j (H[cl][i L + j] + H[cl][j L + i]) mat1d[c0 + cl][j]      grid: (L, ST_CCH)   block: 64
+__global__ __launch_bounds__(64) void stem_dmat1d_kernel(const float* __restrict__ H, const float* __restrict__ mat1d, int L,
+                                                         int c0, float* __restrict__ dmat1d) {
+  const int i = blockIdx.x, cl = blockIdx.y;
+  const int64_t LL = (int64_t)L * L;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < L; j += 64)
+    acc += ((double)H[cl * LL + (int64_t)i * L + j] + (double)H[cl * LL + (int64_t)j * L + i]) * (double)mat1d[(int64_t)(c0 + cl) * L + j];
+  acc = wave_sum_f64(acc);
+  if (threadIdx.x == 0) dmat1d[(int64_t)(c0 + cl) * L + i] = (float)acc;
+}
+
+// d_dw: 384 x 955 (resnet.0.lin.weight.grad); d_dparams: [lin.bias.grad 384][norm.weight.grad 128][norm.bias.grad 128];
+// d_dmat1d: 512 x L.  dmp_stem_static must have run for this target on this context (the covariance planes).
+int stem_bwd(dmp_ctx* c, const float* d_u, const uint8_t* d_idx, const float* d_dy, const float* d_mat1d,
+             const float* d_dmap, int L, float* d_dw, float* d_dparams, float* d_dmat1d, hipStream_t s) {
+  const Weights& W = c->W;
+  const int LL = L * L, nch = cdiv(LL, 4096);
+  BwdWs w;
+  int rc;
+  if ((rc = bwd_workspace(c, &w))) return rc;
+  c->bwd_w_block = 0;                                     // the space behind the norm region is about to be overwritten
+  float* coef = w.norm;                                   // [128][4]
+  float* kco = coef + 512;                                // [128][8]
+  double* part = reinterpret_cast<double*>(w.norm + 2048);
+  float* dz = w.xpad;                                     // [384][LL]
+  float* panel = dz + (int64_t)STEM_OUT * LL;
+  // InstanceNorm: statistics of u (as the forward's), the two sums of its backward, d(u) -> routed dz
+  hipLaunchKernelGGL(tb_stats_kernel, dim3(nch, CW), dim3(256), 0, s, d_u, LL, part);
+  hipLaunchKernelGGL(tb_coef_kernel, dim3(1), dim3(CW), 0, s, part, nch, (double)LL, W.stem_gamma, W.stem_beta, coef);
+  hipLaunchKernelGGL(stem_in_sums_kernel, dim3(nch, CW), dim3(256), 0, s, d_u, d_dy, coef, LL, part);
+  hipLaunchKernelGGL(stem_in_finish_kernel, dim3(1), dim3(CW), 0, s, part, nch, (double)LL, coef, kco, d_dparams);
+  hipLaunchKernelGGL(stem_route_kernel, dim3(cdiv(LL, 256), CW), dim3(256), 0, s, d_u, d_dy, d_idx, kco, LL, dz);
+  hipLaunchKernelGGL(stem_bias_dist_kernel, dim3(STEM_OUT), dim3(256), 0, s, dz, d_dmap, LL, d_dparams, d_dw);
+  DMP_LAUNCH_CHECK();
+  GemmArgs g{};
+  g.alpha = 1.f; g.beta = 0.f; g.bias_n = nullptr; g.lower_tiles = false;
+  // covariance channels 512 .. 953: dW[:, 512 + q] = DZ planes^T
+  g.A = dz; g.sam = LL; g.sak = 1; g.B = c->planes; g.sbk = 1; g.sbn = LL; g.C = d_dw + WIDTH; g.ldc = STEM_IN;
+  g.M = STEM_OUT; g.N = NS * NS + 1; g.K = LL;
+  if ((rc = gemm_f32(g, s))) return rc;
+  // outer-product channels: panels of ST_OCH stem channels, T[(o, i)][c] = sum_j dz[o][i][j] mat1d[c][j]
+  for (int o0 = 0; o0 < STEM_OUT; o0 += ST_OCH) {
+    g.A = dz + (int64_t)o0 * LL; g.sam = L; g.sak = 1; g.B = d_mat1d; g.sbk = 1; g.sbn = L; g.C = panel; g.ldc = WIDTH;
+    g.M = ST_OCH * L; g.N = WIDTH; g.K = L;
+    if ((rc = gemm_f32(g, s))) return rc;
+    hipLaunchKernelGGL(stem_outer_dw_kernel, dim3(WIDTH / 256, ST_OCH), dim3(256), 0, s, panel, d_mat1d, L, o0, d_dw);
+    DMP_LAUNCH_CHECK();
+  }
+  // d mat1d: panels of ST_CCH sequence channels, H[cl][p] = sum_o W[o][c0 + cl] dz[o][p]
+  for (int c0 = 0; c0 < WIDTH; c0 += ST_CCH) {
+    g.A = W.stemT + (int64_t)c0 * STEM_OUT; g.sam = STEM_OUT; g.sak = 1; g.B = dz; g.sbk = LL; g.sbn = 1; g.C = panel; g.ldc = LL;
+    g.M = ST_CCH; g.N = LL; g.K = STEM_OUT;
+    if ((rc = gemm_f32(g, s))) return rc;
+    hipLaunchKernelGGL(stem_dmat1d_kernel, dim3(L, ST_CCH), dim3(64), 0, s, panel, d_mat1d, L, c0, d_dmat1d);
+    DMP_LAUNCH_CHECK();
+  }
+  return DMP_OK;
+}
+
 
 }  // namespace dmp

@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-/* 4 (round 5): 47 functions.  New: dmp_block_conv5x5_maxout_winners (the training slice's forward: maxout output + the
- *    winners autograd saves) and dmp_head_conv_bwd; dmp_block_conv5x5_maxout_bwd takes the saved winners (d_idx, NULL = run
+/* 4 (round 5): 49 functions.  New: dmp_block_conv5x5_maxout_winners (the training slice's forward: maxout output + the
+ *    winners autograd saves), dmp_head_conv_bwd, dmp_stem_maxout_winners and dmp_stem_bwd; dmp_block_conv5x5_maxout_bwd takes the saved winners (d_idx, NULL = run
  *    the forward again: the ABI-3 behaviour).  New options: precision (0 split-f16 / 1 the reference's float32 end to end),
  *    vgru_f32, gj_diag_blocked.
  * 3 (round 4): 45 functions instead of 60.  Removed: the experimental scheduler entry points that were measured
@@ -262,8 +262,20 @@ int dmp_block_norm_scse_residual_bwd(dmp_ctx* ctx, int block, const float* d_u, 
 /* ... and of the 1x1 head convolution (network.py:207, Conv2d(128 -> 2)): d_x its input (128 x L x L), d_g the gradient
  * w.r.t. its two output planes (2 x L x L).  Outputs: d_dx (128 x L x L) and d_dparams (258 floats: weight 2 x 128,
  * bias 2).  With the two entry points above a caller chains the sixteen blocks and the head of net.resnet
- * (tests/test_gpu_train.py); the stem's backward (955 input channels) is not built. */
+ * (tests/test_gpu_train.py). */
 int dmp_head_conv_bwd(dmp_ctx* ctx, const float* d_x, const float* d_g, int L, float* d_dx, float* d_dparams, void* stream);
+/* ... and of the stem, resnet[0] = Maxout2d(955 -> 128, pool 3, kernel 1) + InstanceNorm (network.py:194, 12-34).  Its
+ * 955-channel input is never materialised: channels 0..511 are the outer product of d_mat1d (512 x L, network.py:226-227),
+ * 512..953 the covariance planes the context holds after dmp_stem_static for this target, 954 the distance channel.
+ * dmp_stem_maxout_winners: from d_z0 (dmp_stem_static) and d_dmap the maxout output d_u (128 x L x L, before the
+ * InstanceNorm) and the winner of every triple, d_idx (128 x L x L bytes, 0..2).  dmp_stem_bwd: d_dy = gradient w.r.t. the
+ * stem's output; outputs d_dw (384 x 955 = resnet.0.lin.weight.grad), d_dparams (640 floats: lin.bias.grad 384,
+ * norm.weight.grad 128, norm.bias.grad 128) and d_dmat1d (512 x L: what flows on into the sequence trunk).  With these and
+ * the block / head entry points above a caller runs autograd's backward through the whole of net.resnet
+ * (tests/test_gpu_train.py). */
+int dmp_stem_maxout_winners(dmp_ctx* ctx, const float* d_z0, const float* d_dmap, int L, float* d_u, uint8_t* d_idx, void* stream);
+int dmp_stem_bwd(dmp_ctx* ctx, const float* d_u, const uint8_t* d_idx, const float* d_dy, const float* d_mat1d,
+                 const float* d_dmap, int L, float* d_dw, float* d_dparams, float* d_dmat1d, void* stream);
 /* Head 1x1 conv (network.py:207) + network.py:237-246: d_conf (L) = row means of channel 1,
  * d_M (L x L) = Gram matrix 0.5*(dm_0j^2 + dm_i0^2 - dm_ij^2) of dm = |sym(channel 0)|. */
 int dmp_head_gram(dmp_ctx* ctx, const float* d_x, int L, float* d_conf, float* d_M,

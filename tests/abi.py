@@ -126,6 +126,19 @@ class Stages:
         self.call("dmp_block_norm_scse_residual_bwd", block, u, dout, L, du, dparams)
         return du, dparams
 
+    def stem_winners(self, z0, dmap):
+        L = dmap.shape[0]
+        u = self.f32(128, L, L)
+        idx = torch.empty((128, L, L), dtype=torch.uint8, device=self.dev)
+        self.call("dmp_stem_maxout_winners", z0, dmap, L, u, idx)
+        return u, idx
+
+    def stem_bwd(self, u, idx, dy, mat1d, dmap):
+        L = dmap.shape[0]
+        dw, dparams, dmat1d = self.f32(384, 955), self.f32(640), self.f32(512, L)
+        self.call("dmp_stem_bwd", u, idx, dy, mat1d, dmap, L, dw, dparams, dmat1d)
+        return dw, dparams, dmat1d
+
     def head_bwd(self, x, g):
         L = x.shape[-1]
         dx, dparams = self.f32(128, L, L), self.f32(258)

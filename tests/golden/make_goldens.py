@@ -579,11 +579,11 @@ def main():
     # of entries + sum + sum of squares is kept (pack_sample), the small parameter gradients in full.
     NEAR_TIE = 1e-4       # absolute margin between a quadruple's two largest channels below which the decision is listed
 
-    def near_ties(z):
-        """z: the convolution output (1, 512, L, L) -> (flat index into [128][L][L], the reference's winner) of every
+    def near_ties(z, pool=4):
+        """z: the convolution output (1, 128 pool, L, L) -> (flat index into [128][L][L], the reference's winner) of every
         maxout decision whose two largest channels are closer than NEAR_TIE: another implementation of the same float32
         convolution (sums in another order: 1e-6 relative) may resolve those the other way."""
-        q = z.detach()[0].reshape(128, 4, -1)
+        q = z.detach()[0].reshape(128, pool, -1)
         top2 = q.topk(2, dim=1)
         gap = (top2.values[:, 0] - top2.values[:, 1]).reshape(-1)
         at = torch.nonzero(gap < NEAR_TIE).reshape(-1)
@@ -677,6 +677,98 @@ def main():
         np.savez_compressed(os.path.join(HERE, "bwd_resnet_L96.npz"), **bw)
         report.append("bwd_resnet_L96           reference autograd through resnet[1..17] (16 blocks + head), eval mode (x 128x96x96): |dx0| max %.3e, |dx16| max %.3e"
                       % (float(x0.grad.abs().max()), float(x16.grad.abs().max())))
+
+    # ... and the stem, resnet[0] = Maxout2d(955 -> 128, pool 3, kernel 1) (network.py:194, 12-34), on an input built as
+    # GRUResNet.forward builds it (network.py:226-229): outer product of mat1d (a leaf here: its gradient is what flows
+    # on into the sequence trunk), the 442 covariance channels, the distance channel.
+    if want("bwd_stem_L96"):
+        Lb = 96
+        torch.set_num_threads(8)
+        net = RN.GRUResNet(512, 128)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net.eval()
+        stem = net.resnet[0]
+        for q in stem.parameters():
+            q.grad = None
+        mat1d = torch.from_numpy(philox_plane(0x57E0, (1, 512, Lb), 1.0)).requires_grad_(True)
+        f2d = torch.from_numpy(philox_plane(0x57E1, (1, 442, Lb, Lb), 0.5))
+        dmap = torch.from_numpy(np.abs(philox_plane(0x57E2, (1, 1, Lb, Lb), 10.0)))
+        G = torch.from_numpy(philox_plane(0x57E3, (1, 128, Lb, Lb), 1.0))
+        x = mat1d.unsqueeze(2) * mat1d.unsqueeze(3)
+        inp = torch.cat((x, f2d, dmap), dim=1)
+        grabbed = {}
+
+        def pre4(_m, i_):
+            i_[0].retain_grad()
+            grabbed["u"] = i_[0]
+        h1 = stem.norm.register_forward_pre_hook(pre4)
+        h2 = stem.lin.register_forward_hook(lambda _m, _i, o: grabbed.__setitem__("z", o))
+        y = stem(inp)
+        h1.remove()
+        h2.remove()
+        y.backward(G)
+        u = grabbed["u"]
+        tie_at, tie_win = near_ties(grabbed["z"], pool=3)
+        dw = stem.lin.weight.grad.reshape(384, 955)
+        bw = {"L": np.int64(Lb), "mat1d_key": np.int64(0x57E0), "f2d_key": np.int64(0x57E1), "f2d_scale": np.float32(0.5),
+              "dmap_key": np.int64(0x57E2), "dmap_scale": np.float32(10.0), "g_key": np.int64(0x57E3),
+              "db": stem.lin.bias.grad.numpy(), "dgamma": stem.norm.weight.grad.numpy(), "dbeta": stem.norm.bias.grad.numpy(),
+              "dw_dist": dw[:, 954].numpy().copy(), "dw_contacts": dw[:, 953].numpy().copy(),
+              "tie.at": tie_at, "tie.win": tie_win, "tie.margin": np.float32(NEAR_TIE),
+              "weights_sha256": np.frombuffer(wsum.encode(), dtype=np.uint8)}
+        pack_sample(bw, "u", u[0])
+        pack_sample(bw, "y", y[0])
+        pack_sample(bw, "du", u.grad[0])
+        pack_sample(bw, "dw", dw)
+        pack_sample(bw, "dw_outer", dw[:, :512].contiguous())
+        pack_sample(bw, "dmat1d", mat1d.grad[0])
+        np.savez_compressed(os.path.join(HERE, "bwd_stem_L96.npz"), **bw)
+        report.append("bwd_stem_L96             reference autograd through resnet[0] (stem: 955 -> 384 -> max 3 -> norm; x 955x96x96 from mat1d, f2d, dmap): |dw| max %.3e, |dmat1d| max %.3e, |du| max %.3e"
+                      % (float(dw.abs().max()), float(mat1d.grad.abs().max()), float(u.grad.abs().max())))
+
+    # ... and ONE backward pass through the WHOLE of net.resnet - stem, sixteen blocks, head (network.py:194-207) - from the
+    # two head planes back to mat1d.
+    if want("bwd_resnet_whole_L96"):
+        Lb = 96
+        torch.set_num_threads(8)
+        net = RN.GRUResNet(512, 128)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        net.eval()
+        for q in net.parameters():
+            q.grad = None
+        mat1d = torch.from_numpy(philox_plane(0xA110, (1, 512, Lb), 1.0)).requires_grad_(True)
+        f2d = torch.from_numpy(philox_plane(0xA111, (1, 442, Lb, Lb), 0.5))
+        dmap = torch.from_numpy(np.abs(philox_plane(0xA112, (1, 1, Lb, Lb), 10.0)))
+        G2 = torch.from_numpy(philox_plane(0xA113, (1, 2, Lb, Lb), 1.0))
+        inp = torch.cat((mat1d.unsqueeze(2) * mat1d.unsqueeze(3), f2d, dmap), dim=1)
+        zs = {}
+        hooks = [net.resnet[0].lin.register_forward_hook(lambda _m, _i, o: zs.__setitem__(0, o))]
+        hooks += [net.resnet[k].layer1.lin.register_forward_hook(lambda _m, _i, o, k=k: zs.__setitem__(k, o)) for k in range(1, 17)]
+        out = net.resnet(inp)
+        for hk in hooks:
+            hk.remove()
+        (out * G2).sum().backward()
+        stem = net.resnet[0]
+        sdw = stem.lin.weight.grad.reshape(384, 955)
+        bw = {"L": np.int64(Lb), "mat1d_key": np.int64(0xA110), "f2d_key": np.int64(0xA111), "f2d_scale": np.float32(0.5),
+              "dmap_key": np.int64(0xA112), "dmap_scale": np.float32(10.0), "g_key": np.int64(0xA113),
+              "tie.margin": np.float32(NEAR_TIE),
+              "head_dw": net.resnet[17].weight.grad.numpy().reshape(2, 128), "head_db": net.resnet[17].bias.grad.numpy(),
+              "stem.db": stem.lin.bias.grad.numpy(), "stem.dgamma": stem.norm.weight.grad.numpy(),
+              "stem.dbeta": stem.norm.bias.grad.numpy(),
+              "weights_sha256": np.frombuffer(wsum.encode(), dtype=np.uint8)}
+        bw["b0.tie.at"], bw["b0.tie.win"] = near_ties(zs[0], pool=3)
+        pack_sample(bw, "out", out[0])
+        pack_sample(bw, "stem.dw", sdw)
+        pack_sample(bw, "dmat1d", mat1d.grad[0])
+        for k in range(1, 17):
+            blk = net.resnet[k]
+            bw[f"b{k}.db"] = blk.layer1.lin.bias.grad.numpy()
+            bw[f"b{k}.dgamma"] = blk.layer1.norm.weight.grad.numpy()
+            bw[f"b{k}.tie.at"], bw[f"b{k}.tie.win"] = near_ties(zs[k])
+        np.savez_compressed(os.path.join(HERE, "bwd_resnet_whole_L96.npz"), **bw)
+        report.append("bwd_resnet_whole_L96     reference autograd through ALL of net.resnet (stem + 16 blocks + head), eval mode, from mat1d / f2d / dmap: |dmat1d| max %.3e, |stem dw| max %.3e"
+                      % (float(mat1d.grad.abs().max()), float(sdw.abs().max())))
 
     # known-answer vectors for the minimiser and the backbone builder on a real CA trace
     if want("kat_refine_backbone"):

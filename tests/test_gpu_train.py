@@ -155,3 +155,107 @@ def test_resnet_backward_through_sixteen_blocks_and_head_vs_reference_autograd(s
               "deviation per stage: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     finally:
         st.eng.close()
+
+
+def test_stem_backward_vs_reference_autograd(synth_sd):
+    """resnet[0] = Maxout2d(955 -> 128, pool 3, kernel 1) + InstanceNorm (network.py:194, 12-34) on an input built as
+    GRUResNet.forward builds it (network.py:226-229: outer product of mat1d, the 442 covariance channels, the distance
+    channel), backwards: lin.weight.grad for all 955 channels - outer-product, covariance, contact and distance columns -
+    lin.bias.grad, the norm's gradients, and the gradient that flows on into the sequence trunk (d mat1d).  The 955-channel
+    input is never materialised on the device: the static stem's Z0 forwards, panels of matrix-core GEMMs backwards."""
+    from abi import Stages
+    g = load_golden("bwd_stem_L96")
+    L = int(g["L"])
+    st = Stages(synth_sd, max_L=L, max_N=8)
+    try:
+        mat1d = st.to(philox_plane(g["mat1d_key"], (512, L), 1.0))
+        f2d = philox_plane(g["f2d_key"], (442, L, L), float(g["f2d_scale"]))
+        dmap = st.to(np.abs(philox_plane(g["dmap_key"], (L, L), float(g["dmap_scale"]))))
+        dy = st.to(philox_plane(g["g_key"], (128, L, L), 1.0))
+        # the covariance channels as the inverse they are read from: inv[21 i + a][21 j + b] = f2d[21 a + b][i][j]
+        inv = st.to(np.ascontiguousarray(f2d[:441].reshape(21, 21, L, L).transpose(2, 0, 3, 1)).reshape(21 * L, 21 * L))
+        contacts = st.to(f2d[441])
+        z0 = st.stem_static(mat1d, inv, contacts)
+        u, idx = st.stem_winners(z0, dmap)
+        rel = {"u": close_sample(u, g, "u", 1e-5)}
+        y = st.stem_update(z0, dmap)
+        rel["y"] = close_sample(y, g, "y", 1e-4)
+        differ = substitute_near_ties(idx, g["tie.at"], g["tie.win"])
+        dw, dp, dm = st.stem_bwd(u, idx, dy, mat1d, dmap)
+        st.eng.sync_check()
+        rel["dw"] = close_sample(dw, g, "dw")
+        rel["dw_outer"] = close_sample(dw[:, :512].contiguous(), g, "dw_outer")
+        rel["dw_dist"] = close_full(dw[:, 954], g["dw_dist"], what="dw_dist")
+        rel["dw_contacts"] = close_full(dw[:, 953], g["dw_contacts"], what="dw_contacts")
+        rel["dmat1d"] = close_sample(dm, g, "dmat1d")
+        dp = dp.cpu().numpy()
+        rel["db"] = close_full(dp[:384], g["db"], what="db")
+        rel["dgamma"] = close_full(dp[384:512], g["dgamma"], what="dgamma")
+        rel["dbeta"] = close_full(dp[512:640], g["dbeta"], what="dbeta")
+        print(f"bwd_stem_L96: {len(g['tie.at'])} near-ties listed, {differ} resolved differently by the HIP forward; relative "
+              "deviations " + ", ".join(f"{k} {v:.1e}" for k, v in rel.items()))
+        # the block entry points still work after the stem used the shared workspace (the flipped weight pack is rebuilt)
+        x = st.to(philox_plane(7, (128, L, L), 1.0))
+        du = st.to(philox_plane(8, (128, L, L), 1.0))
+        a = st.conv_bwd(3, x, du, None)
+        st.stem_bwd(u, idx, dy, mat1d, dmap)
+        b = st.conv_bwd(3, x, du, None)
+        st.eng.sync_check()
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+    finally:
+        st.eng.close()
+
+
+def test_whole_resnet_backward_stem_blocks_head_vs_reference_autograd(synth_sd):
+    """ONE backward pass of the reference's autograd through ALL of net.resnet (network.py:194-207: the stem, the sixteen
+    residual blocks, the 1x1 head) from the gradient at the two head planes back to mat1d, composed here from the entry
+    points of the training slice: forwards in float32 with the winners saved per maxout (the reference's near-ties
+    substituted, see the module docstring), backwards head -> blocks 16 .. 1 -> stem."""
+    from abi import Stages
+    g = load_golden("bwd_resnet_whole_L96")
+    L = int(g["L"])
+    st = Stages(synth_sd, max_L=L, max_N=8)
+    try:
+        st.eng.set_option("precision", 1)
+        mat1d = st.to(philox_plane(g["mat1d_key"], (512, L), 1.0))
+        f2d = philox_plane(g["f2d_key"], (442, L, L), float(g["f2d_scale"]))
+        dmap = st.to(np.abs(philox_plane(g["dmap_key"], (L, L), float(g["dmap_scale"]))))
+        g2 = st.to(philox_plane(g["g_key"], (2, L, L), 1.0))
+        inv = st.to(np.ascontiguousarray(f2d[:441].reshape(21, 21, L, L).transpose(2, 0, 3, 1)).reshape(21 * L, 21 * L))
+        z0 = st.stem_static(mat1d, inv, st.to(f2d[441]))
+        u0, idx0 = st.stem_winners(z0, dmap)
+        flips = substitute_near_ties(idx0, g["b0.tie.at"], g["b0.tie.win"])
+        x = st.stem_update(z0, dmap)
+        xs, us, idxs = {}, {}, {}
+        for k in range(1, 17):
+            u, stats = st.conv(k, x)
+            _, idx = st.conv_winners(k, x)
+            flips += substitute_near_ties(idx, g[f"b{k}.tie.at"], g[f"b{k}.tie.win"])
+            xs[k], us[k], idxs[k] = x, u, idx
+            x = st.norm(k, u, stats, x)
+        # the head's two planes (its forward is part of dmp_head_gram on the prediction path: here by hand, float64)
+        W = {k: torch.from_numpy(np.array(v)).to(st.dev) for k, v in synth_sd.items() if k.startswith("resnet.17.")}
+        out = (torch.einsum("hc,cij->hij", W["resnet.17.weight"].reshape(2, 128).double(), x.double())
+               + W["resnet.17.bias"].double()[:, None, None]).float()
+        worst = {"out": close_sample(out, g, "out")}
+        d, hp = st.head_bwd(x, g2)
+        hp = hp.cpu().numpy()
+        worst["head"] = max(close_full(hp[:256].reshape(2, 128), g["head_dw"], what="head_dw"),
+                            close_full(hp[256:258], g["head_db"], what="head_db"))
+        for k in range(16, 0, -1):
+            du, dp = st.norm_bwd(k, us[k], d)
+            dx, dw, db = st.conv_bwd(k, xs[k], du, idxs[k])
+            d = dx + d
+            worst[f"b{k}"] = max(close_full(db, g[f"b{k}.db"], what=f"b{k}.db"),
+                                 close_full(dp[0:128], g[f"b{k}.dgamma"], what=f"b{k}.dgamma"))
+        sdw, sdp, dm = st.stem_bwd(u0, idx0, d, mat1d, dmap)
+        st.eng.sync_check()
+        sdp = sdp.cpu().numpy()
+        worst["stem"] = max(close_sample(sdw, g, "stem.dw"), close_full(sdp[:384], g["stem.db"], what="stem.db"),
+                            close_full(sdp[384:512], g["stem.dgamma"], what="stem.dgamma"),
+                            close_full(sdp[512:640], g["stem.dbeta"], what="stem.dbeta"))
+        worst["dmat1d"] = close_sample(dm, g, "dmat1d")
+        print(f"bwd_resnet_whole_L96: {flips} near-ties resolved differently by the HIP forward; worst relative deviation per "
+              "stage: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+    finally:
+        st.eng.close()
