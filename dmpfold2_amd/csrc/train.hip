@@ -254,14 +254,16 @@ __global__ __launch_bounds__(256, 4) void conv5x5_dgrad_kernel(const float* __re
   }
 }
 
-// grid: 64 x WG_KSPLIT   block: 320 (wave = tap row dy)      part[ks][o 512][tap 25][c 128]
-// Three workgroups per CU (48.6 KB of LDS each): 15 waves on the four SIMDs (4 / 4 / 4 / 3) - with two the five waves of a
-// workgroup left one SIMD with twice the others' MFMAs (first version: 3.46 ms at L = 300, 0.54 of the peak).  The next
+// grid: 64 x WG_KSPLIT   block: 256      part[ks][o 512][tap 25][c 128]
+// Four waves, balanced: wave w owns taps 6 w .. 6 w + 5 (six accumulators over every k) and a quarter of the k steps of
+// the 25th tap (a seventh accumulator; the four quarters are added in wave order once, at the end).  Three workgroups per
+// CU (48.6 KB of LDS each) = 12 waves = exactly three per SIMD.  (First forms: five waves, one tap row each - 3.46 ms at
+// L = 300 with two workgroups per CU, one SIMD carrying twice the others' MFMAs; 3.15 ms with three per CU.)  The next
 // tile's operands are requested before this tile's MFMAs and written to LDS behind them: the x halo tile as 16-byte
 // loads of the padded planes (rows of 20 = 5 x float4, aligned: P and the tile origin are multiples of 4), the dz tile as
 // du + winner byte, expanded at the LDS write.  LDS layout [position][32 channels | 1 pad]: the 32 lanes of an MFMA
 // operand read 32 consecutive words.
-__global__ __launch_bounds__(320, 4) void conv5x5_wgrad_kernel(const float* __restrict__ xpad, const float* __restrict__ du,
+__global__ __launch_bounds__(256, 3) void conv5x5_wgrad_kernel(const float* __restrict__ xpad, const float* __restrict__ du,
                                                                const uint8_t* __restrict__ idx, int L, int P, int tx_tiles,
                                                                int ntiles, float* __restrict__ part) {
   __shared__ float a_lds[WG_TY * WG_TX * WG_LP];          // dz tile  [pixel 128][o 32 | pad]
@@ -269,68 +271,72 @@ __global__ __launch_bounds__(320, 4) void conv5x5_wgrad_kernel(const float* __re
   const int ks = blockIdx.x >> 6, rb = blockIdx.x & 63, ob = rb >> 2, cb = rb & 3;
   const int t_lo = (int)((int64_t)ntiles * ks / WG_KSPLIT), t_hi = (int)((int64_t)ntiles * (ks + 1) / WG_KSPLIT);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int dy = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = lane >> 5, li = lane & 31;
   const int64_t LL = (int64_t)L * L, PP = (int64_t)P * P;
-  // staging slots: six float4 of the halo tile (i = tid + 320 e < 32 x 12 x 5 = 1920 exactly: channel i / 60, row, float4
-  // of the row) and up to four (maxout channel, pixel) items of dz (i < 1024).  The slot arithmetic is redone at every
-  // use - divisions by constants under 320 MFMAs per wave and tile - instead of being kept in 30 registers: with the 80
-  // accumulator registers and the 32 of the prefetch the kernel has to stay within the 128 of four waves per SIMD.
+  int toff[6];                                           // LDS word offset of this wave's taps: (dy 20 + dx) positions
+#pragma unroll
+  for (int d = 0; d < 6; ++d) toff[d] = (((6 * w + d) / 5) * WG_HX + (6 * w + d) % 5) * WG_LP;
+  // staging slots: up to eight float4 of the halo tile (i = tid + 256 e < 32 x 12 x 5 = 1920: channel i / 60, row, float4
+  // of the row) and four (maxout channel, pixel) items of dz (i < 1024).  The slot arithmetic is redone at every use -
+  // divisions by constants under 400 MFMAs per wave and tile - instead of being kept in registers (seven accumulators
+  // = 112 registers, 40 of the prefetch; the budget of three waves per SIMD is 170).
   const float* xb = xpad + (int64_t)cb * 32 * PP;
   const float* dub = du + (int64_t)ob * 8 * LL;
   const uint8_t* idb = idx + (int64_t)ob * 8 * LL;
-  float4 breg[6];
+  float4 breg[8];
   float areg[4];
   int wreg[4];                                           // the winner, or -1 for a pixel outside the image
   auto prefetch = [&](int t) {
     const int ty0 = (t / tx_tiles) * WG_TY, tx0 = (t % tx_tiles) * WG_TX;
     const float* xt = xb + (int64_t)ty0 * P + tx0;
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      int i = tid + e * 320;
+    for (int e = 0; e < 8; ++e) {
+      int i = tid + e * 256;
       asm volatile("" : "+v"(i));                        // (keeps the slot arithmetic inside the loop: see above)
-      const int cl = i / 60, rem = i % 60, row = rem / 5, f4 = rem % 5;
+      const int ic = i < 1920 ? i : 0;
+      const int cl = ic / 60, rem = ic % 60, row = rem / 5, f4 = rem % 5;
       breg[e] = *reinterpret_cast<const float4*>(xt + ((int64_t)cl * PP + (int64_t)row * P + 4 * f4));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      int i = tid + e * 320;
+      int i = tid + e * 256;
       asm volatile("" : "+v"(i));
-      const int g = (i >> 7) & 7, p = i & 127;
+      const int g = i >> 7, p = i & 127;
       const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
       const bool real = y < L && x < L;
       const int64_t off = (int64_t)g * LL + (real ? y * L + x : 0);
       areg[e] = dub[off];
-      const int w = idb[off];
-      wreg[e] = real ? w : -1;
+      const int win = idb[off];
+      wreg[e] = real ? win : -1;
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      int i = tid + e * 320;
+    for (int e = 0; e < 8; ++e) {
+      int i = tid + e * 256;
       asm volatile("" : "+v"(i));
-      const int cl = i / 60, rem = i % 60, row = rem / 5, f4 = rem % 5;
-      float* d = b_lds + (row * WG_HX + 4 * f4) * WG_LP + cl;
-      d[0] = breg[e].x;
-      d[WG_LP] = breg[e].y;
-      d[2 * WG_LP] = breg[e].z;
-      d[3 * WG_LP] = breg[e].w;
+      if (i < 1920) {
+        const int cl = i / 60, rem = i % 60, row = rem / 5, f4 = rem % 5;
+        float* d = b_lds + (row * WG_HX + 4 * f4) * WG_LP + cl;
+        d[0] = breg[e].x;
+        d[WG_LP] = breg[e].y;
+        d[2 * WG_LP] = breg[e].z;
+        d[3 * WG_LP] = breg[e].w;
+      }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      int i = tid + e * 320;
+      int i = tid + e * 256;
       asm volatile("" : "+v"(i));
-      if (i < 8 * WG_TY * WG_TX) {
-        float* d = a_lds + (i & 127) * WG_LP + (i >> 7) * 4;
+      float* d = a_lds + (i & 127) * WG_LP + (i >> 7) * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d[q] = wreg[e] == q ? areg[e] : 0.f;
-      }
+      for (int q = 0; q < 4; ++q) d[q] = wreg[e] == q ? areg[e] : 0.f;
     }
   };
-  tr_f32x16 acc[5];
+  tr_f32x16 acc[7];
 #pragma unroll
-  for (int d = 0; d < 5; ++d)
+  for (int d = 0; d < 7; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   if (t_lo < t_hi) prefetch(t_lo);
@@ -339,22 +345,40 @@ __global__ __launch_bounds__(320, 4) void conv5x5_wgrad_kernel(const float* __re
     commit();
     __syncthreads();
     if (t + 1 < t_hi) prefetch(t + 1);
+#pragma unroll 1
+    for (int seg = 0; seg < 4; ++seg) {
+      const bool mine = seg == w;                        // this wave's quarter of the 25th tap (dy = dx = 4)
 #pragma unroll 4
-    for (int s = 0; s < WG_TY * WG_TX / 2; ++s) {
-      const int p = 2 * s + kk;
-      const float a = a_lds[p * WG_LP + li];
-      const float* bp = b_lds + (((p >> 4) + dy) * WG_HX + (p & 15)) * WG_LP + li;
+      for (int s = 16 * seg; s < 16 * seg + 16; ++s) {
+        const int p = 2 * s + kk;
+        const float a = a_lds[p * WG_LP + li];
+        const float* bp = b_lds + ((p >> 4) * WG_HX + (p & 15)) * WG_LP + li;
 #pragma unroll
-      for (int d = 0; d < 5; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[d * WG_LP], acc[d], 0, 0, 0);
+        for (int d = 0; d < 6; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[toff[d]], acc[d], 0, 0, 0);
+        if (mine) acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[(4 * WG_HX + 4) * WG_LP], acc[6], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
-  for (int d = 0; d < 5; ++d)
+  for (int d = 0; d < 6; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = ob * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
-      part[(((int64_t)ks * 512 + o) * 25 + dy * 5 + d) * CW + cb * 32 + li] = acc[d][r];
+      part[(((int64_t)ks * 512 + o) * 25 + 6 * w + d) * CW + cb * 32 + li] = acc[d][r];
     }
+  // the 25th tap: the four waves' quarters, added in wave order (through the halo tile's LDS)
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) b_lds[(w * 16 + r) * 64 + lane] = acc[6][r];
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * w + rr;
+    const float v = ((b_lds[(0 * 16 + r) * 64 + lane] + b_lds[(1 * 16 + r) * 64 + lane]) + b_lds[(2 * 16 + r) * 64 + lane]) +
+                    b_lds[(3 * 16 + r) * 64 + lane];
+    const int o = ob * 32 + 8 * (r >> 2) + 4 * kk + (r & 3);
+    part[(((int64_t)ks * 512 + o) * 25 + 24) * CW + cb * 32 + li] = v;
+  }
 }
 
 // dW[o][c 25 + tap] = sum_ks part[ks][o][tap][c], ks ascending          grid: 512 x 25 x 128 / 256   block: 256
@@ -408,7 +432,7 @@ int conv5x5_maxout_bwd(dmp_ctx* c, int block, const float* d_x, const float* d_d
   DMP_LAUNCH_CHECK();
   // 4. weight gradient
   const int ty = cdiv(L, WG_TY), tx = cdiv(L, WG_TX);
-  hipLaunchKernelGGL(conv5x5_wgrad_kernel, dim3(64 * WG_KSPLIT), dim3(320), 0, s, w.xpad, d_du, d_idx, L, P, tx, ty * tx, w.part);
+  hipLaunchKernelGGL(conv5x5_wgrad_kernel, dim3(64 * WG_KSPLIT), dim3(256), 0, s, w.xpad, d_du, d_idx, L, P, tx, ty * tx, w.part);
   DMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(512 * 25 * CW / 256), dim3(256), 0, s, w.part, d_dw);
   DMP_LAUNCH_CHECK();
