@@ -1,9 +1,16 @@
 #!/bin/bash
-# scratch GPU job of a session: gpurun -- 'bash tools/gpu_job.sh'.  Every step under its own timeout; outputs under gpurun_out/job/.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-R=$PWD; OUT=$R/gpurun_out/job; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_parity.py -q -x -s -k "backward or train" > $OUT/train_tests.log 2>&1; tail -4 $OUT/train_tests.log | cut -c 1-300
-timeout 600 python tools/time_bwd.py 300 350 > $OUT/bwd_time.txt 2>&1; grep "^L=" $OUT/bwd_time.txt | cut -c 1-330
-cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/bwdprof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bwdprof -o bwd -- python $R/tools/time_bwd.py 300 > /dev/null 2>&1
-f=$(find /tmp/bwdprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/bwd_kernel_stats.csv && head -6 "$f" | cut -c 1-200
+R=$PWD; OUT=gpurun_out/job; mkdir -p $OUT
+for rep in 1 2; do
+  for v in 0 2; do
+    DMP_GJ_DIAG=$v timeout 600 python bench.py --steps 8 --warmup 2 --legs f16x3 --no-cpu-baseline --no-files-leg > $OUT/gj_${v}_$rep.json 2> $OUT/gj_${v}_$rep.err
+    python - <<PY
+import json
+try:
+    j = json.loads(open("$OUT/gj_${v}_$rep.json").read().strip().splitlines()[-1])
+    print("gj_diag=$v rep $rep value %.3f chip_ms %.4f single %.1f ok %s digest_match %s" % (j["value"], j["roofline"]["chip_ms_per_launch"], j["single_target"]["ms"], j["verify"]["ok"], j["verify"].get("digest_match")))
+except Exception as e:
+    print("gj_diag=$v rep $rep FAILED", e); print(open("$OUT/gj_${v}_$rep.err").read()[-600:])
+PY
+  done
+done
