@@ -545,6 +545,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "gj_diag_groups") { DMP_ARG(value == 2 || value == 4 || value == 8, "gj_diag_groups must be 2, 4 or 8"); ctx->gj_diag_groups = value; return DMP_OK; }
   if (k == "act_scaling") { ctx->act_scaling = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_persistent") { ctx->vgru_persist = value ? 1 : 0; return DMP_OK; }
+  if (k == "vgru_debug_drop_wg") { ctx->vgru_debug_drop_wg = value ? 1 : 0; return DMP_OK; }     // tests only
   if (k == "vgru_f32") { DMP_ARG(value >= -1 && value <= 1, "vgru_f32 must be -1 (follow conv_mode), 0 or 1"); ctx->vgru_f32 = value; return DMP_OK; }
   if (k == "precision") {
     // 0: float32-grade split-f16 products in the convolutions and the vertical GRU (the default); 1: the reference's
@@ -571,6 +572,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "act_scaling") { *h_value = ctx->act_scaling; return DMP_OK; }
   if (k == "device_mib") { *h_value = (int)((ctx->bytes + (1 << 20) - 1) >> 20); return DMP_OK; }    // read only
   if (k == "vgru_persistent") { *h_value = ctx->vgru_persist && ctx->vgru_persist_ok; return DMP_OK; }
+  if (k == "vgru_debug_drop_wg") { *h_value = ctx->vgru_debug_drop_wg; return DMP_OK; }
   if (k == "vgru_f32") { *h_value = vgru_runs_f32(ctx); return DMP_OK; }          // what the next prediction will run
   if (k == "precision") {                                                          // 1 / 0, or -1 for a mixed setting
     const int v = vgru_runs_f32(ctx);

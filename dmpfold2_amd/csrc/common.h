@@ -156,6 +156,8 @@ struct dmp_ctx {
   uint8_t* vgru_sync = nullptr;            // VPSync of the persistent chain (vgru.hip): XCD arrival counters, row flags
   int vgru_persist = 1;                    // option "vgru_persistent": the chain as ONE weight-stationary launch (0: one launch per row)
   bool vgru_persist_ok = false;            // the device has the 256 CUs the persistent form is laid out for
+  int vgru_debug_drop_wg = 0;              // TEST option "vgru_debug_drop_wg": launch the persistent chain one workgroup short (its row
+                                           // barrier must time out ONCE, raise DMP_FAULT_VGRU_HANDOFF and leave the row loop)
   int vgru_f32 = -1;                       // option "vgru_f32": 1 = float32 MFMAs + library gates (vgru_f32.hip), 0 = split-f16
                                            // products, -1 (default) = follow the convolution: float32 with conv_mode 1
   int vg_ntiles = 0, vg_maxN = 0;          // group this context leads (vgru.hip): column tiles, deepest member alignment

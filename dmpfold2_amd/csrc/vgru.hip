@@ -863,7 +863,7 @@ int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
       CoResident guard(lead, s, true);
       if (guard.status()) return guard.status();
       DMP_HIP(hipMemsetAsync(sync, 0, sizeof(VPSync), s));
-      hipLaunchKernelGGL(vgru_persist_kernel, dim3(VP_GRID), dim3(256), VP_LDS_BYTES, s, st, (const VGroupRec*)rec, sync,
+      hipLaunchKernelGGL(vgru_persist_kernel, dim3(VP_GRID - (lead->vgru_debug_drop_wg ? 1 : 0)), dim3(256), VP_LDS_BYTES, s, st, (const VGroupRec*)rec, sync,
                          lead->seq_abort, t_lo, t_hi, nt);
       DMP_LAUNCH_CHECK();
       int rc = guard.done();

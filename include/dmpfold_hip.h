@@ -137,6 +137,9 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * XCDs, hidden units over the CUs of an XCD, XCD-local row barriers); 0 = one launch per alignment row (the round-3
  * group step kernel, also the fallback on a device without 256 CUs).  Reads back 0 where the persistent form is not
  * available.  The two forms sum K in different orders: results agree to float32 rounding.
+ * "vgru_debug_drop_wg" = 1 (TESTS ONLY): the persistent chain is launched one workgroup short, so one XCD's row barrier can
+ * never complete - the situation of a second process holding CUs.  The kernel must time out ONCE (a quarter of a second),
+ * raise DMP_FAULT_VGRU_HANDOFF and leave its row loop; the Python layer then repeats with one launch per row.
  * "refine_single" = 1 runs the minimiser (dmp_refine_coords, dmp_predict*) in one workgroup instead
  * of a cluster of 16 that hands the coordinates over every step; same iteration, different
  * partial-sum slices (results agree to float32 rounding). */

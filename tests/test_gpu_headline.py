@@ -661,6 +661,43 @@ def test_env_selects_the_references_float32_arithmetic_for_the_drop_in_api(monke
         P.Engine("cuda:0", 64, 8)
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_missing_workgroup_of_the_persistent_chain_times_out_once_and_falls_back(synth_sd, capsys, precision):
+    """a workgroup of the persistent vertical GRU that is missing for good - another process holds CUs -
+    used to make EVERY row wait the full spin bound again (hours at N = 3000).  With the test option the chain is launched
+    one workgroup short: the row barrier of one XCD times out once, DMP_FAULT_VGRU_HANDOFF is raised, the kernel leaves
+    its row loop, and predict_checked repeats with one launch per row - within seconds, with the right answer, in both
+    arithmetic settings."""
+    import time
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, encode_aln, FAULT_VGRU_HANDOFF
+    msa = encode_aln(synth.synth_msa(96, 400, 77))
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()}
+    eng = Engine("cuda:0", 96, 400)
+    try:
+        eng.set_weights(sd)
+        eng.set_option("precision", precision)
+        eng.set_option("vgru_persistent", 0)
+        want_c, want_f = eng.predict_checked(msa, None, 1, 0)          # the launch-per-row answer
+        eng.set_option("vgru_persistent", 1)
+        eng.set_option("vgru_debug_drop_wg", 1)
+        d_msa = torch.from_numpy(msa).to(eng.device)
+        t0 = time.perf_counter()
+        c, f = eng.predict_device(d_msa, None, 1, 0)
+        bits = eng.sync_faults()
+        dt = time.perf_counter() - t0
+        assert bits & FAULT_VGRU_HANDOFF and bool(torch.isnan(f).all())   # flagged, and never a plausible wrong structure
+        assert dt < 5.0, dt                                               # ONE time-out, not one per row (401 rows here)
+        t0 = time.perf_counter()
+        c, f = eng.predict_device_checked(d_msa, None, 1, 0)            # times out again, then falls back
+        dt = time.perf_counter() - t0
+        assert "one launch per alignment row" in capsys.readouterr().err
+        assert eng.get_option("vgru_persistent") == 0
+        assert torch.equal(c, want_c) and torch.equal(f, want_f) and dt < 10.0, dt
+    finally:
+        eng.close()
+
+
 # ------------------------------------------------------------------ BASELINE config[3], sharded
 def _parse_pdb(text):
     ca, conf = [], None
