@@ -1017,7 +1017,7 @@ static int issue_group_chain(dmp_ctx* c, int j, hipStream_t s) {
   if (!rc && j == chunks - 1) {
     for (int i = 0; !rc && i < n; ++i) {
       dmp_ctx* m = c->vg_members[i];
-      rc = vgru_group_output(c, i, m->last_N, m->last_L, m->vout, s);
+      rc = vgru_group_output(c, i, m->last_N, m->last_L, m->vout, s, m);
     }
     for (int i = 0; !rc && i < nr; ++i)
       rc = vgru_group_output(c, n + i, c->vg_riders[i].N, c->vg_riders[i].L, c->vg_riders[i].out, s);

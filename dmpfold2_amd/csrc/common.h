@@ -314,7 +314,7 @@ void coresident_forget(dmp_ctx* c);   // dmp_ctx_destroy
 int vgru_group_setup(dmp_ctx* lead, dmp_ctx* const* members, const uint8_t* const* msas, const int* Ns,
                      const int* Ls, int n, hipStream_t s);
 int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s);
-int vgru_group_output(dmp_ctx* lead, int member_index, int N, int L, float* d_out, hipStream_t s);
+int vgru_group_output(dmp_ctx* lead, int member_index, int N, int L, float* d_out, hipStream_t s, dmp_ctx* member = nullptr);
 int gru_bidir(dmp_ctx* c, int which, const float* d_in, int T, float* d_out, hipStream_t s);
 // trunk.hip
 int stem_static(dmp_ctx* c, const float* d_mat1d, const float* d_inv, const float* d_contacts,

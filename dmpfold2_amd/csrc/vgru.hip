@@ -886,18 +886,29 @@ int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
   return DMP_OK;
 }
 
-// out[l][j] = state[j/4][col0 + l][j%4] with column pitch Lb
+// out[l][j] = state[j/4][col0 + l][j%4] with column pitch Lb.  A chain whose row barrier timed out (fault word of the
+// LEADER, whose prediction the chain belongs to) hands NaN to every alignment it served: a member's or a rider's
+// prediction must never go on from a half-updated state to a plausible-looking wrong structure (round 5: the members
+// of a group used to get exactly that - only the leader's prediction was invalidated).
 __global__ __launch_bounds__(128) void vgru2_out_kernel(const float* __restrict__ hP, int Lb, int col0,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const int* __restrict__ fault,
+                                                        int* __restrict__ member_fault) {
   const int l = blockIdx.x, j4 = threadIdx.x;
-  const float4 v = *reinterpret_cast<const float4*>(hP + ((int64_t)j4 * Lb + col0 + l) * 4);
+  float4 v = *reinterpret_cast<const float4*>(hP + ((int64_t)j4 * Lb + col0 + l) * 4);
+  if (fault[0] & DMP_FAULT_VGRU_HANDOFF) {
+    const float nan = __builtin_nanf("");
+    v = make_float4(nan, nan, nan, nan);
+    if (member_fault && l == 0 && j4 == 0) atomicOr(member_fault, DMP_FAULT_VGRU_HANDOFF);
+  }
   *reinterpret_cast<float4*>(out + (int64_t)l * WIDTH + 4 * j4) = v;
 }
 
-// member `mi` of the group on `lead`: its result (top-layer state after its last row) as L x 512
-int vgru_group_output(dmp_ctx* lead, int mi, int N, int L, float* d_out, hipStream_t s) {
+// member `mi` of the group on `lead`: its result (top-layer state after its last row) as L x 512; `member` = the context
+// whose prediction consumes it (its fault word takes the chain's time-out), or null for a rider's buffer
+int vgru_group_output(dmp_ctx* lead, int mi, int N, int L, float* d_out, hipStream_t s, dmp_ctx* member) {
   hipLaunchKernelGGL(vgru2_out_kernel, dim3(L), dim3(128), 0, s, lead->hT[1][N & 1], lead->vg_ntiles * VG_TB,
-                     lead->vg_tile0[mi] * VG_TB, d_out);
+                     lead->vg_tile0[mi] * VG_TB, d_out, (const int*)lead->seq_abort,
+                     (member && member != lead) ? member->seq_abort : (int*)nullptr);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }
@@ -911,7 +922,7 @@ int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo,
   }
   if (t_hi > N + 1) t_hi = N + 1;
   if ((rc = vgru_group_steps(c, t_lo, t_hi, s))) return rc;
-  if (t_hi == N + 1) return vgru_group_output(c, 0, N, L, d_out, s);
+  if (t_hi == N + 1) return vgru_group_output(c, 0, N, L, d_out, s, c);
   return DMP_OK;
 }
 

@@ -698,6 +698,45 @@ def test_missing_workgroup_of_the_persistent_chain_times_out_once_and_falls_back
         eng.close()
 
 
+def test_pipeline_whose_chains_time_out_repeats_and_switches_every_engine(synth_sd, capsys):
+    """in a Pipeline the launch-per-row fallback used to be set on the engine that ran the repeat only - the other
+    engines (and a group chain led by one of them) kept faulting, target after target.  Every chain of this pipeline is
+    launched one workgroup short: collect() repeats the faulted targets, switches ALL engines, and every target gets the
+    single engine's launch-per-row bits."""
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, Pipeline, encode_aln
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()}
+    msas = [encode_aln(synth.synth_msa(L, N, 300 + i)) for i, (L, N) in enumerate([(64, 120), (48, 60), (80, 33), (40, 200), (64, 64)])]
+    single = Engine(dev, 80, 200)
+    pipe = Pipeline(dev, 80, 200, sd, streams=2)
+    try:
+        single.set_weights(sd)
+        single.set_option("vgru_persistent", 0)
+        single.set_option("tridiag_cluster", 0)
+        for e in pipe.engines:
+            e.set_option("vgru_debug_drop_wg", 1)
+        tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 2) for m in msas]
+        out = pipe.collect(tickets)
+        assert "one launch per alignment row" in capsys.readouterr().err
+        assert all(e.get_option("vgru_persistent") == 0 for e in pipe.engines)
+        for m, t in zip(msas, tickets):
+            assert not isinstance(out[t], Exception), out[t]
+            c, f = single.predict(m, None, 1, 2)
+            single.sync_check()
+            assert torch.equal(out[t][0], c) and torch.equal(out[t][1], f), m.shape
+        # ... and the next batch runs clean on the switched engines
+        more = [pipe.submit(torch.from_numpy(m).to(dev), 1, 2) for m in msas[:3]]
+        res = pipe.collect(more)
+        for m, t in zip(msas[:3], more):
+            c, f = single.predict(m, None, 1, 2)
+            single.sync_check()
+            assert torch.equal(res[t][0], c) and torch.equal(res[t][1], f)
+    finally:
+        pipe.close()
+        single.close()
+
+
 # ------------------------------------------------------------------ BASELINE config[3], sharded
 def _parse_pdb(text):
     ca, conf = [], None
