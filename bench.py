@@ -13,17 +13,22 @@ collective, only the timing barrier.  `--gpus N` with N > 1 starts the N ranks i
 (torch.distributed.run on 127.0.0.1) unless the process already runs under a launcher
 (RANK / WORLD_SIZE in the environment, as the driver's command line does).
 
-Two arithmetic flavours are measured, each for the full --steps with its own warm-up and its own HIP-event
-intervals around every convolution launch:
-  * `value` / `roofline`: option "precision" 0, the default - convolutions and vertical GRU form float32 products from
-    two f16 pieces per operand (22 significand bits, float32 accumulate) on the f16 matrix cores -
-    tolerance-qualified float32-GRADE arithmetic;
-  * `value_f32` / `roofline_f32`: option "precision" 1 - the reference's own arithmetic type END TO END: the exact-f32 MFMA
-    convolution (conv_mode 1, bitwise an fmaf chain) AND the float32 vertical GRU (v_mfma_f32_16x16x4_f32, library
-    expf / tanhf gates; round 5) - no f16 / bf16 matrix-core kernel runs in this leg; priced against the 157.3 TFLOP/s
-    f32 matrix-core peak.
-Rank 0 prints ONE JSON line with both, a verification of the outputs against the reference's golden vectors for this
-configuration (`verify`), and (N = 1 only) the CPU oracle timed on this host (`cpu_baseline`).
+Three arithmetic settings of the same workload and scheduler are measured, each with its own warm-up and its own
+HIP-event intervals around every convolution launch (recorded on the launching streams):
+  * `value` / `roofline` / `dtype` - THE HEADLINE: option "precision" 2, full-width operands at the 16-bit matrix cores'
+    rate.  Every float32 operand of the convolutions is split EXACTLY into three bf16 pieces (3 x 8 = the 24 significand
+    bits of a float32), the six piece products above 2^-24 are accumulated in float32 (conv5x5_bf16x6_kernel), and the
+    vertical GRU runs on the f32 matrix cores with library gate functions.  Priced against the dense bf16 peak / 6.
+    The full --steps / --warmup;
+  * `value_f32` / `roofline_f32`: option "precision" 1 - the reference's instruction for instruction: the f32 MFMA
+    convolution (bitwise an fmaf chain) and the same float32 vertical GRU; no 16-bit matrix-core kernel runs in this leg;
+    priced against the 157.3 TFLOP/s f32 matrix-core peak (SURVEY 8d);
+  * `value_split_f16` / `roofline_split_f16`: option "precision" 0, the FAST mode - two f16 pieces per operand (22-23
+    significand bits: narrower than float32's 24, so this number is never the metric), 3 f16 MFMA products.
+  The two secondary legs run a quarter of the steps (at least 2, one warm-up step): they are reported beside the
+  headline, not instead of it.
+Rank 0 prints ONE JSON line with all three, a verification of the outputs against the reference's golden vectors for
+this configuration in every setting (`verify`), and (N = 1 only) the CPU oracle timed on this host (`cpu_baseline`).
 """
 import argparse
 import ctypes as C
@@ -45,6 +50,32 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 L_NS, N_NS, ITERS, MINSTEPS = 300, 2000, 10, 100
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (not the 2:1 sparse figure)
+
+# The arithmetic settings (option "precision" of include/dmpfold_hip.h).  `peak` prices the ALGORITHMIC float32 FLOPs of
+# the convolution: the dense 16-bit matrix-core peak over the number of piece products per float32 product.
+LEGS = {
+    "bf16x3": {"precision": 2, "sfx": "", "peak": PEAK_F16_MFMA_TFLOPS / 6.0, "products": 6,
+               "kernel": "conv5x5_bf16x6_kernel (5x5 conv 128->512 + bias + 4-way maxout; every float32 operand as three "
+                         "bf16 pieces = 24 significand bits, six bf16 MFMA products per float32 product, float32 accumulate)",
+               "dtype": "f32 with full-width operands on the bf16 matrix cores (option precision = 2): convolution operands "
+                        "split exactly into 3 bf16 pieces (24 significand bits), the 6 piece products above 2^-24 accumulated "
+                        "in f32 by v_mfma_f32_32x32x16_bf16; vertical GRU on v_mfma_f32_16x16x4_f32 with library expf / tanhf; "
+                        "everything else f32 (f64 statistics and eigensolver)",
+               "pmc": "conv5x5_bf16_pmc.json", "src": "dmpfold2_amd/csrc/conv_bf16.h"},
+    "f32": {"precision": 1, "sfx": "_f32", "peak": PEAK_F32_MFMA_TFLOPS, "products": 1,
+            "kernel": "conv5x5_maxout_kernel (5x5 conv 128->512 + bias + 4-way maxout on the f32 matrix cores)",
+            "dtype": "f32 end to end (option precision = 1): convolutions on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain), "
+                     "vertical GRU on v_mfma_f32_16x16x4_f32 with library expf / tanhf gates; no f16 / bf16 matrix-core "
+                     "kernel runs in this leg",
+            "pmc": "conv5x5_f32_pmc.json", "src": "dmpfold2_amd/csrc/trunk.hip"},
+    "f16x2": {"precision": 0, "sfx": "_split_f16", "peak": PEAK_F16_MFMA_TFLOPS / 3.0, "products": 3,
+              "kernel": "conv5x5_f16x3_kernel (5x5 conv 128->512 + bias + 4-way maxout, float32 products from 3 f16 MFMA "
+                        "products of 2 f16 pieces per operand, float32 accumulate)",
+              "dtype": "f32-GRADE, NOT the metric's arithmetic (option precision = 0, the fast mode): 2 x f16 split products "
+                       "(22-23-bit operands) in the convolutions and the vertical GRU, f32 accumulate",
+              "pmc": "conv5x5_pmc.json", "src": "dmpfold2_amd/csrc/conv_f16.h"},
+}
+HEADLINE = "bf16x3"
 CONV_FLOP_PER_LAUNCH = 2.0 * 128 * 512 * 25 * L_NS * L_NS     # one block's 5x5 conv
 STUB = os.environ.get("DMP_BENCH_STUB") == "1"   # CPU test of the launch / reduction logic (gloo, no GPU work)
 
@@ -253,6 +284,37 @@ def stub_main(args, rank, world):
     return 0
 
 
+def all_threads_probe(cores16):
+    """The host's EVERY hardware thread beside the `cores16` the baseline uses ("the node's own host cores"
+    reads as all of them): the same bounded probe with both thread counts - the vertical GRU on 64 of the 2000 rows and
+    one residual block - extrapolated to a structure.  PyTorch-CPU collapses on the 256-thread hosts when given every
+    thread, which is why the full run uses 16."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dmpfold_oracle as O
+    from dmpfold2_amd import synth
+    W = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_scale=5.0).items()}
+    alnmat = O.encode_aln(synth.synth_msa(L_NS, N_NS, 0))
+    out = {}
+    every = os.cpu_count() or 1
+    for n in sorted({cores16, every}):
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            x = W["embed.weight"][torch.from_numpy(alnmat[:64].astype(np.int64))]
+            t0 = time.time()
+            O._gru(W, "vgru", x, 22, 512, 2, False, False)
+            t_v = (time.time() - t0) * N_NS / 64.0
+            xb = torch.randn(1, 128, L_NS, L_NS)
+            t0 = time.time()
+            O.block_finish(W, 1, O.block_conv(W, 1, xb), xb)
+            t_b = (time.time() - t0) * 16 * (ITERS + 1)
+        out[str(n)] = {"threads": n, "est_seconds_per_structure": t_v + t_b, "vgru_s": t_v, "pair_trunk_s": t_b}
+    torch.set_num_threads(cores16)
+    return {"probe": "vertical GRU on 64 of 2000 rows (x 31.25) + one residual block (x 176), per thread count",
+            "by_threads": out, "all_threads": every}
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -265,13 +327,14 @@ def main(argv=None):
                     help="targets per step and GPU (default 2 x streams)")
     ap.add_argument("--cpu-baseline", choices=("full", "sample", "none"), default="full")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
-    ap.add_argument("--no-exact-f32", action="store_true", help="skip the exact-f32 convolution leg")
+    ap.add_argument("--no-exact-f32", "--headline-only", dest="headline_only", action="store_true",
+                    help="skip the two secondary arithmetic legs (precision 1 and 0)")
     ap.add_argument("--no-files-leg", action="store_true", help="skip the alignment files -> PDB files measurement (N = 1)")
-    ap.add_argument("--legs", choices=("both", "f16x3", "f32"), default="both",
-                    help="profiling: run only one arithmetic leg (f32 alone skips the verification and latency extras, "
+    ap.add_argument("--legs", choices=("all",) + tuple(LEGS), default="all",
+                    help="profiling: run ONE arithmetic leg only, with the full --steps (no verification or latency extras, "
                          "so that a kernel-stats table of the run holds that leg's launches only)")
     ap.add_argument("--vgru-per-row", action="store_true",
-                    help="A/B: the vertical GRU as one launch per alignment row (round 3) instead of the persistent launch")
+                    help="A/B: the vertical GRU as one launch per alignment row instead of the persistent launch")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -308,7 +371,7 @@ def main(argv=None):
     red_device = torch.device("cpu") if share_gpu else device          # where the reduced scalars live
 
     from dmpfold2_amd import synth, _lib, shard
-    from dmpfold2_amd.predict import Pipeline, encode_aln
+    from dmpfold2_amd.predict import Pipeline, Engine, encode_aln
     lib = _lib.load()
     if world > 1 and not share_gpu:
         shard.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
@@ -319,9 +382,9 @@ def main(argv=None):
     # two PROCESSES on one GPU (the share-GPU test mode): the persistent vertical GRU needs every CU of the device for
     # itself, and the per-device launch order that keeps a process's own co-resident kernels apart does not reach
     # across processes - one launch per row there
-    if args.vgru_per_row or share_gpu:
-        for e in pipe.engines:
-            e.set_option("vgru_persistent", 0)
+    per_row = args.vgru_per_row or share_gpu
+    if per_row:
+        pipe.set_option("vgru_persistent", 0)
 
     # B synthetic targets per step and rank, all resident in HBM before the clock starts
     B = args.batch if args.batch > 0 else 2 * S
@@ -337,33 +400,31 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    host_cpu = {}                                        # conv_mode -> host CPU-seconds per structure of the timed region
-
-    def timed_leg(conv_mode):
-        """W warm-up steps, then exactly K timed steps of the scheduler in the given convolution arithmetic, bracketed
-        by barrier + synchronize; HIP events around every convolution launch of the timed region (recorded on the
-        launching streams).  -> (elapsed s, warm-up outputs, timed outputs, launches, mean launch ms, union ms)"""
+    def timed_leg(name, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` timed steps of the scheduler in the leg's arithmetic, bracketed by
+        barrier + synchronize; HIP events around every convolution launch of the timed region (recorded on the launching
+        streams).  The steps are pipelined: step k+1 is queued as soon as every target of step k has started on an engine;
+        the clock stops when all batches have completed."""
+        prec = LEGS[name]["precision"]
+        pipe.set_option("precision", prec)
         for e in pipe.engines:
-            e.set_option("precision", conv_mode)          # 0: split f16; 1: float32 convolutions AND float32 vertical GRU
-            assert e.get_option("precision") == conv_mode and e.get_option("vgru_f32") == conv_mode
-        warm = pipe.run(targets[:args.warmup * B], ITERS, MINSTEPS)
+            assert e.get_option("precision") == prec and e.get_option("vgru_f32") == (1 if prec else 0)
+        warm = pipe.run(targets[:warmup * B], ITERS, MINSTEPS)
         sync_all()
-        cap = 16 * (ITERS + 1) * (args.steps * B // S + 2)
+        cap = 16 * (ITERS + 1) * (steps * B // S + 2)
         for e in pipe.engines:
             _lib.check(lib.dmp_profile_enable(e.ctx, 1, cap))
         cpu0 = time.process_time()                       # CPU time of this process, all threads
         t0 = time.perf_counter()
-        # the steps are pipelined: step k+1 is queued as soon as every target of step k has started on an
-        # engine; the clock stops when all K batches have completed (sync_all)
         tickets = []
-        for k in range(args.steps):
-            lo = (args.warmup + k) * B
+        for k in range(steps):
+            lo = (warmup + k) * B
             tickets += [pipe.submit(m, ITERS, MINSTEPS) for m in targets[lo:lo + B]]
             pipe.pump()
         pipe.drain()
         sync_all()
         el = time.perf_counter() - t0
-        host_cpu[conv_mode] = (time.process_time() - cpu0) / max(1, len(tickets))
+        host_cpu = (time.process_time() - cpu0) / max(1, len(tickets))
         timed = [pipe.result(t) for t in tickets]
         # the lane keeps two launches in flight: besides the per-launch duration, measure the time during
         # which at least one launch runs (union of the HIP-event intervals of all engines)
@@ -374,59 +435,124 @@ def main(argv=None):
             iv += [(a[i], b[i]) for i in range(n.value)]
         for e in pipe.engines:                           # (the record of engines[0] is the time origin of all of them)
             _lib.check(lib.dmp_profile_enable(e.ctx, 0, 0))
-        union = interval_union(iv)
-        tot, cnt = sum(b_ - a_ for a_, b_ in iv), len(iv)
         pipe.sync_check()
-        for e in pipe.engines:
-            e.set_option("precision", 0)
-        return el, warm, timed, cnt, tot, union
+        finite = all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in warm + timed)
+        return {"elapsed": el, "steps": steps, "warmup": warmup, "timed": timed, "finite": finite, "host_cpu": host_cpu,
+                "cnt": len(iv), "tot": sum(b_ - a_ for a_, b_ in iv), "union": interval_union(iv)}
 
-    only_f32 = args.legs == "f32"
-    if args.legs == "f16x3":
-        args.no_exact_f32 = True
-    if only_f32:
-        # profiling run of the exact-f32 leg alone: its numbers go into the f32 keys, nothing else is measured
-        exact, warm1, timed1, cnt1, tot1, union1 = timed_leg(1)
+    def roofline_of(name, r):
+        """chip-level rate of the leg's convolution kernel: the launches' algorithmic FLOPs over the time at least one of
+        them runs.  With one launch at a time this is FLOP per launch / average launch duration; with the lane's two
+        launches in flight each launch lasts about twice its share of the chip (avg_launch_ms is the raw per-launch
+        duration the rocprofv3 kernel trace shows)."""
+        leg = LEGS[name]
+        eff = r["union"] / r["cnt"] if r["cnt"] else 0.0
+        ach = CONV_FLOP_PER_LAUNCH / (eff * 1e-3) / 1e12 if eff > 0 else 0.0
+        traffic, current = None, None
+        pmc = os.path.join(ROOT, "profiles", leg["pmc"])
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                traffic = pj.get("hbm_bytes_per_launch")
+                # the PMC passes are a separate profiler run (counters cannot be collected inside the timed region):
+                # the file carries the hash of the kernel source it was taken from
+                if pj.get("kernel_source_sha256"):
+                    src = os.path.join(ROOT, pj.get("kernel_source", leg["src"]))
+                    current = hashlib.sha256(open(src, "rb").read()).hexdigest() == pj["kernel_source_sha256"]
+            except Exception:
+                traffic = None
+        out = {"kernel": leg["kernel"], "bound": "mfma", "achieved": ach, "peak": leg["peak"], "unit": "TFLOP/s",
+               "frac": ach / leg["peak"], "traffic": traffic,
+               "traffic_source": "profiles/%s (rocprofv3 --pmc passes of single launches; a separate profiler run)" % leg["pmc"],
+               "traffic_taken_from_this_kernel_source": current,
+               "launches_timed": r["cnt"], "avg_launch_ms": r["tot"] / r["cnt"] if r["cnt"] else 0.0,
+               "launches_in_flight": r["tot"] / r["union"] if r["union"] > 0 else 0.0, "chip_ms_per_launch": eff,
+               "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH,
+               "peak_is": "dense 16-bit matrix-core peak %.0f / %d piece products per float32 product" % (PEAK_F16_MFMA_TFLOPS, leg["products"])
+                          if leg["products"] > 1 else "the f32 matrix-core peak"}
+        if leg["products"] > 1:
+            out["executed_16bit_mfma_tflops"] = leg["products"] * ach
+            # what the matrix cores sustain under the power cap on random operands (measured, not a spec figure):
+            # reported beside the spec-peak fraction, never instead of it
+            cpath = os.path.join(ROOT, "profiles", "mfma_power_ceiling.json")
+            if os.path.exists(cpath):
+                try:
+                    cj = json.load(open(cpath))
+                    key = "random_bf16_operands_tflops" if name == "bf16x3" else "random_f16_operands_tflops"
+                    if cj.get(key):
+                        out["power_capped_ceiling"] = {
+                            "mfma_random_operands_tflops": cj[key], "executed_frac_of_it": leg["products"] * ach / cj[key],
+                            "source": "profiles/mfma_power_ceiling.json (tools/ubench_mfma_power.hip: register-resident "
+                                      "operands, no memory traffic; zeros reach the 2.5 PFLOP/s spec peak, random data is "
+                                      "held lower by the 1.3 kW power cap)"}
+                except Exception:
+                    pass
+        return out
+
+    # ---- a single leg alone (profiling): its numbers under the leg's own keys, nothing else is measured
+    if args.legs != "all":
+        r = timed_leg(args.legs, args.steps, args.warmup)
+        if distributed:
+            t = torch.tensor([r["elapsed"]], dtype=torch.float64, device=red_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r["elapsed"] = float(t[0].item())
         if rank == 0:
-            eff1 = union1 / cnt1 if cnt1 else 0.0
-            print(json.dumps({"metric": "structures/s at L=300, N_seq=2000, 10 iters+100 min", "legs": "f32",
-                              "value_f32": world * args.steps * B / exact, "ms_per_step_f32": exact / args.steps * 1e3,
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "roofline_f32": {"achieved": CONV_FLOP_PER_LAUNCH / (eff1 * 1e-3) / 1e12 if eff1 else 0.0,
-                                               "peak": PEAK_F32_MFMA_TFLOPS, "chip_ms_per_launch": eff1,
-                                               "avg_launch_ms": tot1 / cnt1 if cnt1 else 0.0, "launches_timed": cnt1}}), flush=True)
+            sfx = LEGS[args.legs]["sfx"]
+            print(json.dumps({"metric": "structures/s at L=300, N_seq=2000, 10 iters+100 min", "legs": args.legs,
+                              "value" + sfx: world * args.steps * B / r["elapsed"],
+                              "ms_per_step" + sfx: r["elapsed"] / args.steps * 1e3,
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "finite_outputs": r["finite"],
+                              "roofline" + sfx: roofline_of(args.legs, r)}), flush=True)
         if distributed:
             dist.destroy_process_group()
         return 0
-    elapsed, outs, timed_outs, conv_cnt, conv_tot, conv_union = timed_leg(0)
-    outs += timed_outs
-    conv_ms = conv_tot / conv_cnt if conv_cnt else 0.0
-    pipe.sync_check()
-    ok = all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in outs)
+
+    # ---- the headline leg, then the two secondary ones at a quarter of the steps
+    res = {HEADLINE: timed_leg(HEADLINE, args.steps, args.warmup)}
+    ok = res[HEADLINE]["finite"]
+    k2, w2 = max(2, args.steps // 4), min(1, args.warmup)
+    if not args.headline_only:
+        for name in LEGS:
+            if name != HEADLINE:
+                res[name] = timed_leg(name, min(k2, args.steps), w2)
+                ok = ok and res[name]["finite"]
+    timed_outs = res[HEADLINE]["timed"]
 
     # ---- verification of the outputs (untimed) ---------------------------------------------------
     verify = {"finite_outputs": ok}
-    e0 = pipe.engines[0]
-    first = args.warmup * B                                   # first target of the timed region
-    if timed_outs:
-        # (1) the scheduler's result of that target == the same target alone on one engine, bit for bit
-        c1, f1 = e0.predict_device(targets[first], None, ITERS, MINSTEPS)
-        e0.sync_check()
-        verify["timed_target_bitwise_equals_single_engine"] = bool(
-            torch.equal(c1, timed_outs[0][0]) and torch.equal(f1, timed_outs[0][1]))
-        ok = ok and verify["timed_target_bitwise_equals_single_engine"]
-        # (2) digest of bench target 0 (seed 0, the full 10 + 100 prediction, alone on one engine - the same
-        #     bits the scheduler delivers, by (1)) against the stored one (profiles/bench_digest.json, written
-        #     by DMP_WRITE_DIGEST=1); the results are bit-reproducible, so a change means the arithmetic changed.
-        #     The key does not depend on --steps / --warmup.
-        if rank == 0:
-            c0, f0 = e0.predict_device(targets[0], None, ITERS, MINSTEPS)
-            e0.sync_check()
+    first = args.warmup * B                                   # first target of the headline leg's timed region
+    es = Engine(device, L_NS, N_NS)                           # an engine of its own, with the pipeline's packed weights
+    es.share_weights(pipe.engines[0])
+    if per_row:
+        es.set_option("vgru_persistent", 0)
+    single, t0_out = {}, {}
+    try:
+        for name, r in res.items():
+            prec, sfx = LEGS[name]["precision"], LEGS[name]["sfx"]
+            es.set_option("precision", prec)
+            # (1) the scheduler's result of the leg's first timed target == the same target alone on one engine, bit for
+            #     bit.  The bits are compared with the scheduler's kernels selected (its engines tridiagonalise with one
+            #     launch per Householder step; the cluster launch of a lone engine is the same algorithm with its float64
+            #     sums associated differently - the same bits on almost every matrix, not on all)
+            es.set_option("tridiag_cluster", 0)
+            lo = (r["warmup"]) * B
+            c1, f1 = es.predict_device(targets[lo], None, ITERS, MINSTEPS)
+            es.sync_check()
+            same = bool(torch.equal(c1, r["timed"][0][0]) and torch.equal(f1, r["timed"][0][1]))
+            verify["timed_target_bitwise_equals_single_engine" + sfx] = same
+            ok = ok and same
+            if rank != 0:
+                continue
+            # (2) digest of bench target 0 (seed 0, the full 10 + 100 prediction, alone on one engine - the same bits the
+            #     scheduler delivers, by (1)) against the stored one (profiles/bench_digest.json, written by
+            #     DMP_WRITE_DIGEST=1); the results are bit-reproducible, so a change means the arithmetic changed.
+            c0, f0 = es.predict_device(targets[0], None, ITERS, MINSTEPS)
+            es.sync_check()
+            t0_out[name] = (c0.clone(), f0.clone())
             digest = hashlib.sha256(c0.cpu().numpy().tobytes() + f0.cpu().numpy().tobytes()).hexdigest()
-            verify["digest"] = digest
             dpath = os.path.join(ROOT, "profiles", "bench_digest.json")
-            key = f"L{L_NS}_N{N_NS}_n{ITERS}_m{MINSTEPS}_seed0"
-            if not e0.get_option("vgru_persistent"):         # the launch-per-row chain sums K in another order: its own bits
+            key = f"L{L_NS}_N{N_NS}_n{ITERS}_m{MINSTEPS}_seed0" + ("" if prec == 0 else f"_precision{prec}")
+            if not es.get_option("vgru_persistent"):         # the launch-per-row chain sums K in another order: its own bits
                 key += "_vgru_per_row"
             stored = {}
             if os.path.exists(dpath):
@@ -435,59 +561,87 @@ def main(argv=None):
                 except Exception:
                     stored = {}
             if os.environ.get("DMP_WRITE_DIGEST") == "1":
-                stored = {key: digest}
+                stored[key] = digest
                 json.dump(stored, open(dpath, "w"), indent=1, sort_keys=True)
-            verify["digest_expected"] = stored.get(key)
-            verify["digest_match"] = (stored.get(key) == digest) if key in stored else None
-            if verify["digest_match"] is False:          # the arithmetic changed: not a valid headline run
+            match = (stored.get(key) == digest) if key in stored else None
+            verify["digest" + sfx] = {"sha256": digest, "expected": stored.get(key), "match": match}
+            if match is False:                               # the arithmetic changed: not a valid run
                 ok = False
-    if rank == 0:
-        # (3) bench target 0 (seed 0) at iterations=1, minsteps=0 against the vector captured from the
-        #     reference itself at this size (tests/golden/synth_L300_N2000_n1_m0.npz; data only)
-        gpath = os.path.join(ROOT, "tests", "golden", "synth_L300_N2000_n1_m0.npz")
-        if os.path.exists(gpath):
-            g = np.load(gpath)
-            t0msa = targets[0]                          # synth_msa(300, 2000, seed 0) on rank 0
-            sha = hashlib.sha256(t0msa.cpu().numpy().tobytes()).hexdigest()
-            gc, gf = e0.predict_device(t0msa, None, 1, 0)
-            e0.sync_check()
-            d = gc.cpu().numpy()[:, 1].astype(np.float64) - g["coords"][:, 1].astype(np.float64)
-            rmsd = float(np.sqrt((d ** 2).sum(-1).mean()))
-            dconf = float(np.abs(gf.cpu().numpy() - g["confs"]).max())
-            same_input = sha == bytes(g["alnmat_sha256"]).decode()
-            verify["reference_golden_L300_N2000_n1_m0"] = {
-                "ca_rmsd_A": rmsd, "max_dconf": dconf, "same_input": same_input,
-                "ok": bool(same_input and rmsd <= 1e-3 and dconf < 1e-4)}
-            ok = ok and verify["reference_golden_L300_N2000_n1_m0"]["ok"]
-        # (4) THE METRIC'S CONFIGURATION ITSELF against the reference: bench target 0 at iterations=10,
-        #     minsteps=100 on the weight set on which the reference is stable there (coord_fc fitted to a
-        #     protein-like trace, MDS feedback attenuated: tests/golden/fitns_L300_N2000_n10_m100.npz holds the
-        #     reference's output, its thread-count floor and the fitted matrix; data only).  Own engine: the
-        #     pipeline's weights stay untouched.
-        gpath = os.path.join(ROOT, "tests", "golden", "fitns_L300_N2000_n10_m100.npz")
-        if os.path.exists(gpath):
-            from dmpfold2_amd.predict import Engine
-            g = np.load(gpath)
-            sdh = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]))
-            eh = Engine(device, L_NS, N_NS)
-            if share_gpu or args.vgru_per_row:
-                eh.set_option("vgru_persistent", 0)        # (two processes on this GPU: see above)
-            try:
-                eh.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sdh.items()})
-                gc, gf = eh.predict_device(targets[0], None, ITERS, MINSTEPS)
-                eh.sync_check()
+            # (3) bench target 0 (seed 0) at iterations=1, minsteps=0 against the vector captured from the reference
+            #     itself at this size (tests/golden/synth_L300_N2000_n1_m0.npz; data only)
+            gpath = os.path.join(ROOT, "tests", "golden", "synth_L300_N2000_n1_m0.npz")
+            if os.path.exists(gpath):
+                g = np.load(gpath)
+                sha = hashlib.sha256(targets[0].cpu().numpy().tobytes()).hexdigest()
+                gc, gf = es.predict_device(targets[0], None, 1, 0)
+                es.sync_check()
                 d = gc.cpu().numpy()[:, 1].astype(np.float64) - g["coords"][:, 1].astype(np.float64)
                 rmsd = float(np.sqrt((d ** 2).sum(-1).mean()))
                 dconf = float(np.abs(gf.cpu().numpy() - g["confs"]).max())
-                floor = float(g["noise_ca_rmsd"])
-                same = (hashlib.sha256(targets[0].cpu().numpy().tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+                same_input = sha == bytes(g["alnmat_sha256"]).decode()
+                verify["reference_golden_L300_N2000_n1_m0" + sfx] = {
+                    "ca_rmsd_A": rmsd, "max_dconf": dconf, "same_input": same_input,
+                    "ok": bool(same_input and rmsd <= 1e-3 and dconf < 1e-4)}
+                ok = ok and verify["reference_golden_L300_N2000_n1_m0" + sfx]["ok"]
+            # ---- latency of ONE prediction of the same configuration (the reference's use case: one CLI call; the
+            #      scheduler above is the throughput mode), with the lone engine's cluster tridiagonalisation.
+            es.set_option("tridiag_cluster", 1)
+            ts = []
+            for _ in range(4):
+                torch.cuda.synchronize(device)
+                t = time.perf_counter()
+                es.predict_device(targets[lo], None, ITERS, MINSTEPS)
+                es.sync_check()
+                ts.append((time.perf_counter() - t) * 1e3)
+            single[name] = {"ms": min(ts[1:]), "runs_ms": ts}
+    finally:
+        es.close()
+    if rank == 0:
+        # (4) THE METRIC'S CONFIGURATION ITSELF against the reference, in every arithmetic setting: 10 + 100 on the weight
+        #     sets on which the reference is stable there (coord_fc fitted to a protein-like trace, MDS feedback
+        #     attenuated): tests/golden/fitns_*.npz and (round 6: other alignment, weight and trace seeds) fitns2_*.npz hold
+        #     the reference's output, its thread-count floor and the fitted matrix; data only.  Own engine: the
+        #     pipeline's weights stay untouched.
+        for gname in ("fitns_L300_N2000_n10_m100", "fitns2_L300_N2000_n10_m100"):
+            gpath = os.path.join(ROOT, "tests", "golden", gname + ".npz")
+            if not os.path.exists(gpath):
+                continue
+            g = np.load(gpath)
+            wseed = int(g["weights_seed"]) if "weights_seed" in g else 0
+            mseed = int(g["msa_seed"])
+            sdh = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]), seed=wseed)
+            msa_h = targets[0] if mseed == 0 else torch.from_numpy(encode_aln(synth.synth_msa(L_NS, N_NS, mseed))).to(device)
+            eh = Engine(device, L_NS, N_NS)
+            if per_row:
+                eh.set_option("vgru_persistent", 0)        # (two processes on this GPU: see above)
+            try:
+                eh.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sdh.items()})
+                same = (hashlib.sha256(msa_h.cpu().numpy().tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
                         and synth.weights_checksum(sdh) == bytes(g["weights_sha256"]).decode())
-                verify["reference_golden_L300_N2000_n10_m100"] = {
-                    "ca_rmsd_A": rmsd, "max_dconf": dconf, "reference_thread_noise_A": floor, "same_input": bool(same),
-                    "ok": bool(same and rmsd <= max(1e-3, 3.0 * floor) and dconf < 1e-4)}
-                ok = ok and verify["reference_golden_L300_N2000_n10_m100"]["ok"]
+                floor = float(g["noise_ca_rmsd"])
+                for name in res:
+                    eh.set_option("precision", LEGS[name]["precision"])
+                    gc, gf = eh.predict_device(msa_h, None, ITERS, MINSTEPS)
+                    eh.sync_check()
+                    d = gc.cpu().numpy()[:, 1].astype(np.float64) - g["coords"][:, 1].astype(np.float64)
+                    rmsd = float(np.sqrt((d ** 2).sum(-1).mean()))
+                    dconf = float(np.abs(gf.cpu().numpy() - g["confs"]).max())
+                    v = {"ca_rmsd_A": rmsd, "max_dconf": dconf, "reference_thread_noise_A": floor, "same_input": bool(same),
+                         "ok": bool(same and rmsd <= max(1e-3, 3.0 * floor) and dconf < 1e-4)}
+                    verify["reference_golden_" + gname[:gname.index("_")] + "_L300_N2000_n10_m100" + LEGS[name]["sfx"]] = v
+                    ok = ok and v["ok"]
             finally:
                 eh.close()
+        for name in t0_out:
+            if name == HEADLINE:
+                continue
+            a, b = t0_out[HEADLINE], t0_out[name]
+            d = (a[0][:, 1].double() - b[0][:, 1].double())
+            verify["headline_vs%s_bench_target_0" % LEGS[name]["sfx"]] = {
+                "ca_rmsd_A": float((d ** 2).sum(-1).mean().sqrt()),
+                "max_dconf": float((a[1] - b[1]).abs().max()),
+                "note": "two arithmetic settings on the same target (10 + 100 on random weights: the minimiser on a "
+                        "collapsed trace amplifies rounding differences, as the reference's own runs do; informational)"}
 
     # ---- host side of one aln_to_coords call (SURVEY 8d's unit of work; outside the timed region, whose
     #      inputs are resident in HBM): alignment file -> rows -> residue codes -> device, and the PDB text
@@ -516,136 +670,35 @@ def main(argv=None):
                 "note": "host work of one target (file -> codes in HBM, result -> PDB text), single thread, "
                         "outside the timed region; the batch front end overlaps it with the GPU"}
 
-    # ---- latency of ONE prediction of the same configuration on an engine of its own (the reference's use case: one
-    #      CLI call; the scheduler above is the throughput mode).  Reported beside `value`, never part of it.
-    single = None
-    if rank == 0 and timed_outs:
-        from dmpfold2_amd.predict import Engine
-        es = Engine(device, L_NS, N_NS)
-        if share_gpu or args.vgru_per_row:
-            es.set_option("vgru_persistent", 0)        # (two processes on this GPU: see above)
-        try:
-            es.share_weights(pipe.engines[0])
-            ts = []
-            for _ in range(4):
-                torch.cuda.synchronize(device)
-                t = time.perf_counter()
-                cs, fs = es.predict_device(targets[first], None, ITERS, MINSTEPS)
-                es.sync_check()
-                ts.append((time.perf_counter() - t) * 1e3)
-            # the bits are compared with the scheduler's kernels selected (its engines tridiagonalise with one launch per
-            # Householder step; the cluster launch of a lone engine is the same algorithm with its float64 sums
-            # associated differently - the same bits on almost every matrix, not on all: round 4 found a target whose
-            # minimised trace tells them apart)
-            es.set_option("tridiag_cluster", 0)
-            cb, fb = es.predict_device(targets[first], None, ITERS, MINSTEPS)
-            es.sync_check()
-            single = {"ms": min(ts[1:]), "runs_ms": ts,
-                      "bitwise_equals_the_scheduler": bool(torch.equal(cb, timed_outs[0][0]) and torch.equal(fb, timed_outs[0][1])),
-                      "cluster_tridiagonalisation_same_bits": bool(torch.equal(cs, cb) and torch.equal(fs, fb)),
-                      "note": "one target alone on one engine of its own (single stream; the first run builds the launch "
-                              "graphs; timed with the cluster tridiagonalisation, compared bit for bit with the scheduler's "
-                              "first timed result with the scheduler's per-step tridiagonalisation)"}
-            ok = ok and single["bitwise_equals_the_scheduler"]
-        finally:
-            es.close()
-
-    # ---- the same workload, same K steps and W warm-up steps, with the exact-f32 MFMA convolution (conv_mode 1): the
-    #      reference's own arithmetic type, measured exactly like the headline leg
-    exact = None
-    f32_leg = None
-    if not args.no_exact_f32:
-        exact, warm1, timed1, cnt1, tot1, union1 = timed_leg(1)
-        ok = ok and all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in warm1 + timed1)
-        f32_leg = (cnt1, tot1, union1)
-        if timed1 and timed_outs:
-            d = (timed1[0][0][:, 1].double() - timed_outs[0][0][:, 1].double())
-            verify["f32_vs_f16x3_first_timed_target"] = {
-                "ca_rmsd_A": float((d ** 2).sum(-1).mean().sqrt()),
-                "max_dconf": float((timed1[0][1] - timed_outs[0][1]).abs().max()),
-                "note": "the two arithmetic flavours on the same target (10 + 100 on random weights: the minimiser on a "
-                        "collapsed trace amplifies rounding differences; informational)"}
-
-        # the float32 leg's own check against the reference: bench target 0 at iterations=1, minsteps=0 in precision 1
-        gpath = os.path.join(ROOT, "tests", "golden", "synth_L300_N2000_n1_m0.npz")
-        if rank == 0 and os.path.exists(gpath):
-            g = np.load(gpath)
-            e0.set_option("precision", 1)
-            try:
-                gc, gf = e0.predict_device(targets[0], None, 1, 0)
-                e0.sync_check()
-            finally:
-                e0.set_option("precision", 0)
-            d = gc.cpu().numpy()[:, 1].astype(np.float64) - g["coords"][:, 1].astype(np.float64)
-            rmsd = float(np.sqrt((d ** 2).sum(-1).mean()))
-            dconf = float(np.abs(gf.cpu().numpy() - g["confs"]).max())
-            verify["reference_golden_L300_N2000_n1_m0_precision1"] = {
-                "ca_rmsd_A": rmsd, "max_dconf": dconf, "ok": bool(rmsd <= 1e-3 and dconf < 1e-4)}
-            ok = ok and verify["reference_golden_L300_N2000_n1_m0_precision1"]["ok"]
-
     if distributed:
-        vals = [elapsed, exact if exact is not None else 0.0]
-        t = torch.tensor(vals, dtype=torch.float64, device=red_device)
+        names = list(res)
+        t = torch.tensor([res[n]["elapsed"] for n in names], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, el1 = float(t[0].item()), float(t[1].item())
-        exact = el1 if exact is not None else None
+        for i, n in enumerate(names):
+            res[n]["elapsed"] = float(t[i].item())
         flag = torch.tensor([1.0 if ok else 0.0], device=red_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() > 0.5)
 
     if rank == 0:
-        # chip-level rate of the kernel: the launches' algorithmic FLOPs over the time at least one of them
-        # runs.  With one launch at a time this is FLOP per launch / average launch duration; with the
-        # lane's two launches in flight each launch lasts about twice its share of the chip
-        # (avg_launch_ms is the raw per-launch duration the rocprofv3 kernel trace shows).
-        eff_ms = conv_union / conv_cnt if conv_cnt else 0.0
-        in_flight = conv_tot / conv_union if conv_union > 0 else 0.0
-        achieved = CONV_FLOP_PER_LAUNCH / (eff_ms * 1e-3) / 1e12 if eff_ms > 0 else 0.0
-        traffic, traffic_current = None, None
-        pmc = os.path.join(ROOT, "profiles", "conv5x5_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                traffic = pj.get("hbm_bytes_per_launch")
-                # the PMC passes are a separate profiler run (counters cannot be collected inside the timed region):
-                # the file carries the hash of the kernel source it was taken from
-                if pj.get("kernel_source_sha256"):
-                    src = os.path.join(ROOT, pj.get("kernel_source", "dmpfold2_amd/csrc/conv_f16.h"))
-                    traffic_current = hashlib.sha256(open(src, "rb").read()).hexdigest() == pj["kernel_source_sha256"]
-            except Exception:
-                traffic = None
         verify["ok"] = ok
-        # what the matrix cores sustain under the power cap on random operands (measured, not a spec figure):
-        # reported beside the spec-peak fraction, never instead of it
-        capped = None
-        cpath = os.path.join(ROOT, "profiles", "mfma_power_ceiling.json")
-        if os.path.exists(cpath):
-            try:
-                cj = json.load(open(cpath))
-                capped = {"mfma_f16_random_operands_tflops": cj["random_f16_operands_tflops"],
-                          "executed_f16_frac_of_it": 3.0 * achieved / cj["random_f16_operands_tflops"],
-                          "source": "profiles/mfma_power_ceiling.json (tools/ubench_mfma_power.hip: register-"
-                                    "resident operands, no memory traffic; zeros reach the 2.5 PFLOP/s spec peak, "
-                                    "random f16 data 1.6 at the 1.3 kW power cap)"}
-            except Exception:
-                capped = None
+        r = res[HEADLINE]
         line = {
             "metric": "structures/s at L=300, N_seq=2000, 10 iters+100 min",
-            "value": world * args.steps * B / elapsed,
+            "value": world * r["steps"] * B / r["elapsed"],
             "unit": "structures/s",
             "n_gpus": world,
             "ranks": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            # `value` / `roofline`: float32-GRADE products from two f16 pieces per operand (22 significand bits) on the f16
-            # matrix cores, float32 accumulate - NOT the f32 instruction; `value_f32` / `roofline_f32` (below) are the
-            # same workload in exact f32 MFMA arithmetic, the reference's own type
-            "dtype": "f32-grade: 2xf16 split products (22-bit operands) in the convolutions and the vertical GRU, f32 "
-                     "accumulate; the reference's f32 arithmetic end to end = value_f32",
+            # `value` / `roofline`: the reference's float32 arithmetic with FULL-WIDTH operands (24 significand bits as three
+            # bf16 pieces, the six products above 2^-24, float32 accumulate); `value_f32` is the same workload on the f32
+            # MFMA instruction; `value_split_f16` the fast 22-bit mode, never the metric
+            "dtype": LEGS[HEADLINE]["dtype"],
             "data": "synthetic",
             "finite_outputs": ok,
             "verify": verify,
@@ -657,82 +710,45 @@ def main(argv=None):
                        "weights": "synthetic seed 0 (reference state_dict shapes)",
                        "parallelism": f"replicas x{world}, no collective on the data path; "
                                       f"{S} HIP streams per GPU"},
-            # The convolution forms each float32 product from 2-way f16 splits of its operands: 3 f16
-            # MFMA products per float32 product, so the matrix-core ceiling for the ALGORITHMIC
-            # (float32) FLOPs is the dense f16 peak / 3.  The exact-f32 MFMA path (conv_mode 1) is bounded by
-            # PEAK_F32_MFMA_TFLOPS: `value_f32` / `roofline_f32`.
-            "roofline": {"kernel": "conv5x5_f16x3_kernel (5x5 conv 128->512 + bias + 4-way maxout, "
-                                   "float32 products from 3 f16 MFMA products, float32 accumulate)",
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
-                         "unit": "TFLOP/s", "frac": achieved / (PEAK_F16_MFMA_TFLOPS / 3.0),
-                         "traffic": traffic,
-                         "traffic_source": "profiles/conv5x5_pmc.json (rocprofv3 --pmc passes of single "
-                                           "launches, tools/profile_r05.sh; a separate profiler run)",
-                         "traffic_taken_from_this_kernel_source": traffic_current,
-                         "launches_timed": conv_cnt,
-                         "avg_launch_ms": conv_ms, "launches_in_flight": in_flight,
-                         "chip_ms_per_launch": eff_ms,
-                         "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH,
-                         "executed_f16_tflops": 3.0 * achieved,
-                         "power_capped_ceiling": capped,
-                         "peak_f16_mfma_tflops": PEAK_F16_MFMA_TFLOPS,
-                         "peak_f32_mfma_tflops": PEAK_F32_MFMA_TFLOPS},
+            "roofline": roofline_of(HEADLINE, r),
         }
+        line["roofline"]["whole_job_conv_tflops"] = line["value"] / world * 16 * (ITERS + 1) * CONV_FLOP_PER_LAUNCH / 1e12
         # what the scheduler costs the host: CPU time of the whole process (scheduler thread, runtime helper threads)
-        # over the timed region per structure; the scheduler sleeps on blocking-sync events when nothing can be issued
-        line["host_cpu_s_per_structure"] = host_cpu.get(0)
-        if 1 in host_cpu:
-            line["host_cpu_s_per_structure_f32"] = host_cpu.get(1)
+        # over the timed region per structure
+        line["host_cpu_s_per_structure"] = r["host_cpu"]
         if host is not None:
             line["host_ms_per_target"] = host
-        if single is not None:
-            line["single_target"] = single
-        if exact is not None:
-            cnt1, tot1, union1 = f32_leg
-            eff1 = union1 / cnt1 if cnt1 else 0.0
-            ach1 = CONV_FLOP_PER_LAUNCH / (eff1 * 1e-3) / 1e12 if eff1 > 0 else 0.0
-            traffic1, traffic1_current = None, None
-            pmc1 = os.path.join(ROOT, "profiles", "conv5x5_f32_pmc.json")
-            if os.path.exists(pmc1):
-                try:
-                    pj = json.load(open(pmc1))
-                    traffic1 = pj.get("hbm_bytes_per_launch")
-                    if pj.get("kernel_source_sha256"):
-                        src = os.path.join(ROOT, pj.get("kernel_source", "dmpfold2_amd/csrc/trunk.hip"))
-                        traffic1_current = hashlib.sha256(open(src, "rb").read()).hexdigest() == pj["kernel_source_sha256"]
-                except Exception:
-                    traffic1 = None
-            v = world * args.steps * B / exact
-            line["value_f32"] = v
-            line["ms_per_step_f32"] = exact / args.steps * 1e3
-            line["dtype_f32"] = ("f32 end to end (option precision = 1): convolutions on v_mfma_f32_32x32x2_f32 (bitwise an "
-                                 "fmaf chain), vertical GRU on v_mfma_f32_16x16x4_f32 with library expf / tanhf gates; no "
-                                 "f16 / bf16 matrix-core kernel runs in this leg")
-            line["roofline_f32"] = {
-                "kernel": "conv5x5_maxout_kernel (5x5 conv 128->512 + bias + 4-way maxout on the f32 matrix cores)",
-                "bound": "mfma", "achieved": ach1, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach1 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic1,
-                "traffic_source": "profiles/conv5x5_f32_pmc.json (rocprofv3 --pmc passes of single launches; a separate "
-                                  "profiler run)",
-                "traffic_taken_from_this_kernel_source": traffic1_current,
-                "launches_timed": cnt1, "avg_launch_ms": tot1 / cnt1 if cnt1 else 0.0,
-                "launches_in_flight": tot1 / union1 if union1 > 0 else 0.0, "chip_ms_per_launch": eff1,
-                "algorithmic_flop_per_launch": CONV_FLOP_PER_LAUNCH,
-                "whole_job_conv_tflops": v / world * 16 * (ITERS + 1) * CONV_FLOP_PER_LAUNCH / 1e12,
-                "note": "same workload, scheduler, --steps and --warmup as `value`, option precision = 1 (conv_mode 1 + "
-                        "float32 vertical GRU); "
-                        "achieved = algorithmic FLOP per launch / chip time per launch (union of the HIP-event "
-                        "intervals / launches), as for `roofline`"}
+        if single:
+            line["single_target"] = dict(single[HEADLINE], note="one target alone on one engine of its own (single stream, the "
+                                         "headline arithmetic; the first run builds the launch graphs)")
+            for name in single:
+                if name != HEADLINE:
+                    line["single_target" + LEGS[name]["sfx"]] = single[name]
+        for name, r2 in res.items():
+            if name == HEADLINE:
+                continue
+            sfx = LEGS[name]["sfx"]
+            v = world * r2["steps"] * B / r2["elapsed"]
+            line["value" + sfx] = v
+            line["ms_per_step" + sfx] = r2["elapsed"] / r2["steps"] * 1e3
+            line["steps" + sfx], line["warmup" + sfx] = r2["steps"], r2["warmup"]
+            line["dtype" + sfx] = LEGS[name]["dtype"]
+            line["roofline" + sfx] = roofline_of(name, r2)
+            line["roofline" + sfx]["whole_job_conv_tflops"] = v / world * 16 * (ITERS + 1) * CONV_FLOP_PER_LAUNCH / 1e12
+            line["host_cpu_s_per_structure" + sfx] = r2["host_cpu"]
         # ---- SURVEY 8d's unit of work is one aln_to_coords call: the whole chain alignment FILES -> PDB FILES through the
         #      batch front end (read + encode + H2D + prediction + D2H + PDB text + write overlapped with the GPU by
-        #      dmpfold2_amd.batch), same configuration, on a pipeline of its own that takes over the timed pipeline's
-        #      streams.  Reported beside `value` (whose inputs are resident in HBM), never instead of it.
-        if world == 1 and not args.no_files_leg and not only_f32:
+        #      dmpfold2_amd.batch), same configuration and arithmetic as the headline, on a pipeline of its own that takes
+        #      over the timed pipeline's streams.  Reported beside `value` (whose inputs are resident in HBM), never
+        #      instead of it.
+        if world == 1 and not args.no_files_leg:
             import shutil
             import tempfile
             from dmpfold2_amd import batch
             pipe.close()
             tmpd = tempfile.mkdtemp(prefix="dmp_bench_files_")
+            keep = os.environ.get("DMPFOLD_PRECISION")
+            os.environ["DMPFOLD_PRECISION"] = str(LEGS[HEADLINE]["precision"])
             try:
                 nfiles = 3 * B
                 paths = []
@@ -747,15 +763,23 @@ def main(argv=None):
                 line["files_to_pdb"] = {
                     "structures_per_s": nb / wall, "targets": nb, "seconds": wall,
                     "pdb_files_written": sum(1 for o in outs_f if os.path.getsize(o) > 0),
-                    "note": "alignment files -> PDB files through dmpfold2_amd.batch.run_batch (one call: pipeline set-up - "
-                            "contexts, one packed copy of the weights - reading, encoding, H2D, prediction, D2H, PDB text "
-                            "and writing all inside the clock; host work overlapped with the GPU); `value` has its inputs "
-                            "resident in HBM and stops at tensors on the device"}
+                    "note": "alignment files -> PDB files through dmpfold2_amd.batch.run_batch in the headline arithmetic (one "
+                            "call: pipeline set-up - contexts, one packed copy of the weights - reading, encoding, H2D, "
+                            "prediction, D2H, PDB text and writing all inside the clock; host work overlapped with the GPU); "
+                            "`value` has its inputs resident in HBM and stops at tensors on the device"}
             finally:
                 shutil.rmtree(tmpd, ignore_errors=True)
+                if keep is None:
+                    os.environ.pop("DMPFOLD_PRECISION", None)
+                else:
+                    os.environ["DMPFOLD_PRECISION"] = keep
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
             line["cpu_baseline"] = cpu_baseline(mode)
+            try:
+                line["cpu_baseline"]["all_host_threads"] = all_threads_probe(line["cpu_baseline"]["cores"])
+            except Exception as exc:                      # informational: never costs the line
+                line["cpu_baseline"]["all_host_threads"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

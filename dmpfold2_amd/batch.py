@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from . import shard
-from .predict import (MAX_SEQS, Pipeline, default_iterations, default_minsteps, encode_aln, load_state_dict,
+from .predict import (MAX_SEQS, Pipeline, drop_in_precision, default_iterations, default_minsteps, encode_aln, load_state_dict,
                       pdb_text, read_a3m, read_aln, read_template_ca)
 
 
@@ -234,7 +234,7 @@ def run_batch(targets, out_dir, iterations=default_iterations, minsteps=default_
         if pipe is None:
             dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
             sd = state_dict if state_dict is not None else load_state_dict(weights_file)
-            pipe = Pipeline(dev, max_L, max_N, sd, streams=streams)
+            pipe = Pipeline(dev, max_L, max_N, sd, streams=streams, precision=drop_in_precision())
             if dev.type == "cuda":
                 # every copy of this front end goes through its own (non-blocking) stream: nothing is ever enqueued on
                 # the process's default stream while the engines run
@@ -401,7 +401,7 @@ def main(argv=None):
     if world > 1:
         shard.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     targets = (read_target_list(args.list) if args.list else []) + expand_inputs(args.input)
-    status = 0
+    status, n_failed, broke = 0, 0, 0
     store = job_store if (world > 1 and not args.static_shards) else None
     try:
         n, elapsed, _ = run_batch(targets, args.out_dir, args.iterations, args.minsteps,
@@ -410,15 +410,22 @@ def main(argv=None):
     except BatchFailures as bf:                      # keep going: the other ranks wait in job_summary
         for aln_path, exc in bf.failed:
             print(f"dmpfold-batch: {aln_path}: {type(exc).__name__}: {exc}", file=sys.stderr)
-        n, elapsed, status = bf.n_done, bf.elapsed, 1
+        n, elapsed, status, n_failed = bf.n_done, bf.elapsed, 1, len(bf.failed)
     except Exception as exc:                         # noqa: BLE001 - whatever went wrong on THIS rank, the others are
-        # waiting in job_summary's reduction: report, take part in it, and fail the job through the exit status
+        # waiting in job_summary's reduction: report, take part in it, and fail the job through the exit status.  What
+        # this rank had already taken from the shared queue is lost with it: the summary says so
         print(f"dmpfold-batch: rank {rank}: {type(exc).__name__}: {exc}", file=sys.stderr)
-        n, elapsed, status = 0, 0.0, 2
-    total, tmax = shard.job_summary(n, elapsed)
+        n, elapsed, status, broke = 0, 0.0, 2, 1
+    total, tmax, failed_all, broke_all = shard.job_summary(n, elapsed, failures=(n_failed, broke))
     if rank == 0:
-        print(json.dumps({"targets": total, "seconds": tmax, "structures_per_s": total / tmax if tmax > 0 else 0.0,
-                          "n_gpus": world}), flush=True)
+        summary = {"targets": total, "seconds": tmax, "structures_per_s": total / tmax if tmax > 0 else 0.0,
+                   "n_gpus": world, "failed_targets": failed_all, "failed_ranks": broke_all}
+        if broke_all:
+            summary["note"] = ("%d rank(s) broke down: the targets they had taken are missing from the output directory - "
+                               "compare it with the target list" % broke_all)
+        print(json.dumps(summary), flush=True)
+    if (failed_all or broke_all) and status == 0:
+        status = 1                                   # every rank of a job that lost targets fails, rank 0 included
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -548,11 +548,14 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "vgru_debug_drop_wg") { ctx->vgru_debug_drop_wg = value ? 1 : 0; return DMP_OK; }     // tests only
   if (k == "vgru_f32") { DMP_ARG(value >= -1 && value <= 1, "vgru_f32 must be -1 (follow conv_mode), 0 or 1"); ctx->vgru_f32 = value; return DMP_OK; }
   if (k == "precision") {
-    // 0: float32-grade split-f16 products in the convolutions and the vertical GRU (the default); 1: the reference's
-    // arithmetic end to end - float32 MFMAs in both, library gate functions
-    DMP_ARG(value == 0 || value == 1, "precision must be 0 (split f16) or 1 (float32)");
+    // 0: float32-grade split-f16 products in the convolutions and the vertical GRU (22-bit operands; the fast mode);
+    // 1: the reference's arithmetic instruction for instruction - float32 MFMAs in both, library gate functions;
+    // 2: full-width operands at the 16-bit matrix cores' rate - every float32 operand of the convolutions split EXACTLY
+    //    into three bf16 pieces (3 x 8 = 24 significand bits), the six piece products above 2^-24 accumulated in float32
+    //    (conv_bf16.h), and the float32 vertical GRU of setting 1
+    DMP_ARG(value >= 0 && value <= 2, "precision must be 0 (split f16), 1 (float32 MFMA) or 2 (exact bf16 x 3 split + float32 GRU)");
     ctx->conv_mode = value;
-    ctx->vgru_f32 = -1;
+    ctx->vgru_f32 = value == 2 ? 1 : -1;
     return DMP_OK;
   }
   if (k == "conv_mode") {
@@ -574,9 +577,9 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "vgru_persistent") { *h_value = ctx->vgru_persist && ctx->vgru_persist_ok; return DMP_OK; }
   if (k == "vgru_debug_drop_wg") { *h_value = ctx->vgru_debug_drop_wg; return DMP_OK; }
   if (k == "vgru_f32") { *h_value = vgru_runs_f32(ctx); return DMP_OK; }          // what the next prediction will run
-  if (k == "precision") {                                                          // 1 / 0, or -1 for a mixed setting
+  if (k == "precision") {                                                          // 0 / 1 / 2, or -1 for a mixed setting
     const int v = vgru_runs_f32(ctx);
-    *h_value = (ctx->conv_mode == 1 && v) ? 1 : ((ctx->conv_mode != 1 && !v) ? 0 : -1);
+    *h_value = (ctx->conv_mode == 1 && v) ? 1 : ((ctx->conv_mode == 2 && v) ? 2 : ((ctx->conv_mode == 0 && !v) ? 0 : -1));
     return DMP_OK;
   }
   // read-only: 1 once every launch of the group chain this context leads has been issued (the scheduler hands the
@@ -1174,6 +1177,9 @@ int dmp_predict_group_vgru(dmp_ctx* const* ctxs, int n) {
             "member %d: group its vertical GRU right after dmp_predict_begin_units, before any unit is issued", i);
     DMP_ARG(c->device == lead->device, "the members of a group must live on one GPU");
     DMP_ARG(c->W.ready && c->W.hash == lead->W.hash, "member %d does not hold the leader's weights", i);
+    // the chain runs in the LEADER's arithmetic: a member set to another one would silently get the leader's
+    DMP_ARG(vgru_runs_f32(c) == vgru_runs_f32(lead), "member %d: its vertical-GRU arithmetic (options precision / vgru_f32) "
+            "differs from the leader's", i);
     cols += round_up(c->last_L, 32);
     maxN = std::max(maxN, c->last_N);
   }

@@ -1,23 +1,30 @@
 // conv 5x5 (128 -> 512) + bias + 4-way maxout with float32 semantics on the bf16 matrix cores.
 //
 // Every float32 operand is split EXACTLY into three bf16 pieces (x = x0 + x1 + x2: 3 x 8 significand
-// bits = the 24 of a float32).  Of the nine piece products w_i * x_j the six with i + j <= 2 are
-// accumulated in float32 by v_mfma_f32_32x32x16_bf16; the three dropped ones are below 2^-24 of the
-// product, i.e. below the rounding of a float32 multiply.  The result equals the float32 convolution
-// to float32 rounding error (measured: max error vs float64 2e-6, the plain f32 kernel 5e-6) at
-// 16/6 = 2.67x the f32 MFMA rate.
+// bits = the 24 of a float32; round-to-nearest pieces, so a finite float32 is the exact sum).  Of the nine piece
+// products w_i * x_j the six with i + j <= 2 are accumulated in float32 by v_mfma_f32_32x32x16_bf16; the three
+// dropped ones are below 2^-24 of the product, i.e. below the rounding of a float32 multiply.  The result equals
+// the float32 convolution to float32 rounding error (measured: max error vs float64 2e-6, the plain f32 kernel
+// 5e-6) at 16/6 = 2.67x the f32 MFMA rate.  No range limit (bf16 has float32's exponent), no scales.
+// This is the convolution of option "precision" = 2: full-width (24-bit) operands on the 16-bit matrix cores.
 //
-// Layouts
-//   activations  xs[piece 3][c/8 16][P][P][8]   bf16, zero border (same geometry as the f32 planes);
-//                a pixel's 8 channels are one 16-byte LDS/MFMA operand
-//   weights      wq[split 4][cgrp 8][tap 25][wave 4][piece 3][cg 2][m 32][8]   bf16
+// Round 6: row reuse, the structure of conv_f16.h.  The 32 pixels of the MFMA N axis are 2 rows x 16 columns, so
+// accumulator q (rows 2q, 2q+1 of the 16 x 16 tile) at tap (dy, dx) reads the B fragment "row pair r = 2q + dy at
+// column offset dx": one fragment (x 3 pieces) serves every (q, dy) with 2q + dy = r.  A tap column dx is two passes -
+// taps dy = 0, 2, 4 against r = 0, 2, .., 18 and taps dy = 1, 3 against r = 1, 3, .., 17 - with the pass's weight
+// fragments (9 / 6 x 16 bytes per lane) in registers and a per-wave weight buffer of 3 tap slots (9 KB) refilled by
+// LDS-DMA for the next pass as soon as the fragments are in registers.  72 LDS reads per tap column and wave instead
+// of 135 for the same 240 MFMAs (the round-1 kernel went tap by tap: 3 weight + 24 activation fragments per tap).
+//
+// Layouts (one 16-byte load = one MFMA operand)
+//   activations  xs[piece 3][c/8 16][P][P][8]   bf16, zero border (same geometry as the f32 planes)
+//   weights      wq[split 4][cgrp 8][dx 5][wave 4][dy: 0 2 4 1 3][piece 3][cg 2][m 32][8]   bf16
 //                (conv channel = split*128 + wave*32 + m, input channel = cgrp*16 + cg*8 + e):
-//                one wave's operands for one tap are 3 KB contiguous = three 1 KB LDS-DMA pieces
-// Workgroup = 4 waves x (32 conv channels each) x one 16x16 pixel tile (eight 4x8 patches = MFMA N
-// blocks); K = 16 input channels x 25 taps per input stage, 8 stages.  The input halo tile
-// (3 pieces x 2 x 20 x 24 slots) is shared by the waves (2 barriers per stage); each wave streams
-// its own weights tap by tap through a private 2-slot LDS ring with LDS-DMA issued one tap ahead
-// (inline asm, counted vmcnt) - no workgroup barrier inside the 25-tap loop.
+//                one wave's operands for one pass are 9 / 6 KB contiguous = 1 KB LDS-DMA pieces
+// Workgroup = 4 waves x (32 conv channels each) x one 16x16 pixel tile; 8 input stages of 16 channels, whose 20 x 20
+// halo tile (3 pieces) is shared by the waves (2 barriers per stage); no workgroup barrier inside a stage.
+// Lane -> pixel of a fragment follows the lane groups ds_read_b128 is served in (conv_f16.h): conflict free at any
+// row pitch >= 20.
 #pragma once
 #include "common.h"
 #include <vector>
@@ -27,12 +34,17 @@ namespace dmp {
 typedef float cq_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 cq_bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int CQ_HALO = 20, CQ_PITCH = 24;
-constexpr int CQ_IN_SLOTS = 3 * 2 * CQ_HALO * CQ_PITCH;               // 2880 16-byte slots
-constexpr int CQ_IN_BYTES = CQ_IN_SLOTS * 16;                         // 46080
-constexpr int CQ_WSLOT = 3 * 2 * 32;                                  // 192 slots per wave and tap
-constexpr int CQ_RING = 2;
-constexpr int CONVQ_LDS_BYTES = CQ_IN_BYTES + 4 * CQ_RING * CQ_WSLOT * 16;   // 70656
+#ifndef CQ_PITCH_N
+#define CQ_PITCH_N 20        // row pitch of the halo tile in LDS (16-byte slots)
+#endif
+constexpr int CQ_HALO = 20, CQ_PITCH = CQ_PITCH_N;
+constexpr int CQ_IN_SLOTS = 3 * 2 * CQ_HALO * CQ_PITCH;               // 2400 16-byte slots at pitch 20
+constexpr int CQ_IN_PAD = (CQ_IN_SLOTS + 63) / 64 * 64;               // the tile's DMA goes in whole waves of 64 slots
+constexpr int CQ_IN_BYTES = CQ_IN_PAD * 16;                           // 38912
+constexpr int CQ_WSLOT = 3 * 2 * 32;                                  // 192 slots = 3 KB per wave and tap
+constexpr int CQ_WCOL = 5 * CQ_WSLOT;                                 // one tap column of one wave in the packed weights
+constexpr int CQ_WBUF = 3 * CQ_WSLOT;                                 // per-wave LDS weight buffer: 3 tap slots
+constexpr int CONVQ_LDS_BYTES = CQ_IN_BYTES + 4 * CQ_WBUF * 16;       // 75776: two workgroups per CU
 
 // round-to-nearest-even float32 -> bf16 bits
 __host__ __device__ inline uint16_t cq_bf16_rne(float f) {
@@ -52,22 +64,24 @@ __host__ __device__ inline void split3_bf16(float x, uint16_t p[3]) {
   p[2] = cq_bf16_rne(r2);
 }
 
-// w: [512][128][5][5] float32 -> packed bf16 pieces
+// w: [512][128][5][5] float32 -> packed bf16 pieces (layout above)
 inline std::vector<uint16_t> pack_conv_weights_bf16(const float* w) {
+  const int tap_row[5] = {0, 2, 4, 1, 3};              // slot order inside a column: even pass, then odd pass
   std::vector<uint16_t> q((size_t)4 * 8 * 25 * 4 * 3 * 2 * 32 * 8);
   for (int split = 0; split < 4; ++split)
     for (int g = 0; g < 8; ++g)
-      for (int tap = 0; tap < 25; ++tap)
+      for (int dx = 0; dx < 5; ++dx)
         for (int wave = 0; wave < 4; ++wave)
-          for (int cg = 0; cg < 2; ++cg)
-            for (int m = 0; m < 32; ++m)
-              for (int e = 0; e < 8; ++e) {
-                const int oc = split * 128 + wave * 32 + m, ic = g * 16 + cg * 8 + e;
-                uint16_t p3[3];
-                split3_bf16(w[((size_t)oc * 128 + ic) * 25 + tap], p3);
-                for (int p = 0; p < 3; ++p)
-                  q[((((((((size_t)split * 8 + g) * 25 + tap) * 4 + wave) * 3 + p) * 2 + cg) * 32 + m) * 8) + e] = p3[p];
-              }
+          for (int sl = 0; sl < 5; ++sl)
+            for (int cg = 0; cg < 2; ++cg)
+              for (int m = 0; m < 32; ++m)
+                for (int e = 0; e < 8; ++e) {
+                  const int oc = split * 128 + wave * 32 + m, ic = g * 16 + cg * 8 + e;
+                  uint16_t p3[3];
+                  split3_bf16(w[((size_t)oc * 128 + ic) * 25 + tap_row[sl] * 5 + dx], p3);
+                  for (int p = 0; p < 3; ++p)
+                    q[(((((((((size_t)split * 8 + g) * 5 + dx) * 4 + wave) * 5 + sl) * 3 + p) * 2 + cg) * 32 + m) * 8) + e] = p3[p];
+                }
   return q;
 }
 
@@ -89,12 +103,54 @@ __device__ __forceinline__ cq_f32x16 cq_mfma(uint4 a, uint4 b, cq_f32x16 c) {
                                                  __builtin_bit_cast(cq_bf16x8, b), c, 0, 0, 0);
 }
 
-// grid: round_up(tiles*tiles*4, 8) blocks, XCD-aware map as the f32 kernel   block: 256
-// dynamic LDS: CONVQ_LDS_BYTES
-// Scheduling note: hand software-pipelining of the LDS fragment reads (one patch pair ahead, 2-tap
-// DMA distance, with and without sched_group_barrier) measured 5-9 % SLOWER than hipcc's own
-// schedule at 2 waves per SIMD; PMC: MFMA pipe 78 % busy while the clock sits at 1.74 GHz - the
-// kernel runs into the power limit, not into issue stalls.
+// lane (0..31 of a half wave) -> (row, column) of the 2 x 16 pixel fragment (the map of conv_f16.h)
+__device__ __forceinline__ void cq_lane_pixel(int li, int& row, int& x) {
+  const bool a = li < 4 || (li >= 12 && li < 16) || (li >= 20 && li < 28);
+  row = a ? 0 : 1;
+  if (a) x = li < 4 ? li : (li < 16 ? li - 8 : li - 12);
+  else x = li < 12 ? li - 4 : (li < 20 ? li - 8 : li - 16);
+}
+
+// One pass of a tap column: NT taps (rows dy = PAR, PAR + 2, ..) whose weight fragments a[t][piece] sit in registers,
+// against the row pairs r = PAR, PAR + 2, .. < 19 read from the halo tile at `il`; the next row pair's three pieces are
+// requested before this one's MFMAs.  Per fragment the smallest products go first: w0 x2, w1 x1, w2 x0 (2^-16), then
+// w0 x1, w1 x0 (2^-8), then w0 x0 - each product type over the pass's taps, i.e. over different accumulators.
+template <int NT, int PAR>
+__device__ __forceinline__ void cq_column_pass(const uint4 (&a)[NT][3], const uint4* il, cq_f32x16 (&acc)[8]) {
+  constexpr int PIECE = 2 * CQ_HALO * CQ_PITCH;
+  uint4 bn0 = il[PAR * CQ_PITCH], bn1 = il[PAR * CQ_PITCH + PIECE], bn2 = il[PAR * CQ_PITCH + 2 * PIECE];
+#pragma unroll
+  for (int r = PAR; r < 19; r += 2) {
+    const uint4 b0 = bn0, b1 = bn1, b2 = bn2;
+    if (r + 2 < 19) {
+      bn0 = il[(r + 2) * CQ_PITCH];
+      bn1 = il[(r + 2) * CQ_PITCH + PIECE];
+      bn2 = il[(r + 2) * CQ_PITCH + 2 * PIECE];
+    }
+#define CQ_TAPS(AP, BV)                                                          \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                             \
+      const int q = (r - PAR - 2 * t) / 2;                                       \
+      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = cq_mfma(a[t][AP], BV, acc[q]); \
+    }
+    CQ_TAPS(0, b2)
+    CQ_TAPS(1, b1)
+    CQ_TAPS(2, b0)
+    CQ_TAPS(0, b1)
+    CQ_TAPS(1, b0)
+    CQ_TAPS(0, b0)
+#undef CQ_TAPS
+  }
+}
+
+// number of workgroups to launch for tiles x tiles pixel tiles: the XCD-aware block map of conv_f16.h (block b runs on
+// XCD b % 8; XCD x works on ONE channel split (x & 3) of a contiguous half of the tiles, so its share of the weight
+// pieces - 2.46 MB - stays in its 4 MB L2)
+inline int conv_bf16_grid(int tiles) {
+  const int nt = tiles * tiles;
+  return 8 * ((nt + 1) / 2);
+}
+
+// grid: conv_bf16_grid(tiles) blocks   block: 256   dynamic LDS: CONVQ_LDS_BYTES (two workgroups per CU)
 __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* __restrict__ xs,
                                                                 const uint16_t* __restrict__ wq,
                                                                 const float* __restrict__ bias, int L, int P,
@@ -102,10 +158,12 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
                                                                 double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cq_smem[];
   const int id = blockIdx.x;
-  const int per = gridDim.x >> 3;
-  const int work = (id & 7) * per + (id >> 3);
-  if (work >= nwork) return;
-  const int tile = work >> 2, split = work & 3;
+  const int xcd = id & 7, slot = id >> 3;
+  const int ntiles = tiles * tiles;
+  const int tper = (ntiles + 1) >> 1;
+  const int tile = (xcd >> 2) * tper + slot;
+  const int split = xcd & 3;
+  if (slot >= tper || tile >= ntiles) return;
   const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,34 +171,31 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
   const int64_t PP = (int64_t)P * P;
 
   const uint4* in_l = reinterpret_cast<const uint4*>(cq_smem);
-  const uint4* w_l = reinterpret_cast<const uint4*>(cq_smem + CQ_IN_BYTES) + wave * (CQ_RING * CQ_WSLOT);
+  const uint4* w_l = reinterpret_cast<const uint4*>(cq_smem + CQ_IN_BYTES) + wave * CQ_WBUF;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)cq_smem;
-  const unsigned w_lds_addr = lds_base + CQ_IN_BYTES + wave * (CQ_RING * CQ_WSLOT * 16);
+  const unsigned w_lds_addr = lds_base + CQ_IN_BYTES + wave * (CQ_WBUF * 16);
 
-  // ---- input-tile DMA plan: slot s = e*256 + tid, e = 0..11 (2880 slots)
+  // input-tile DMA plan: slot s = e*256 + tid (CQ_IN_PAD slots: the pad slots and the slots of the row pitch beyond the
+  // 20 halo columns re-read a valid pixel)
   const uint4* xs4 = reinterpret_cast<const uint4*>(xs);
-  int64_t in_src[12];
+  constexpr int NE = (CQ_IN_PAD + 255) / 256;
+  int in_src[NE];
 #pragma unroll
-  for (int e = 0; e < 12; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int s = e * 256 + tid;
     const int sc = s < CQ_IN_SLOTS ? s : 0;
-    const int p = sc / 960, r = sc % 960;
-    const int cg = r / 480, r2 = r % 480;
+    const int p = sc / (2 * CQ_HALO * CQ_PITCH), r = sc % (2 * CQ_HALO * CQ_PITCH);
+    const int cg = r / (CQ_HALO * CQ_PITCH), r2 = r % (CQ_HALO * CQ_PITCH);
     const int yy = r2 / CQ_PITCH;
     int xx = r2 % CQ_PITCH;
-    xx = xx < CQ_HALO ? xx : 0;                     // pad slots re-read a valid pixel
-    in_src[e] = ((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx;
+    xx = xx < CQ_HALO ? xx : 0;
+    in_src[e] = (int)(((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx);
   }
-  const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 25 * 4 * CQ_WSLOT +
-                     (int64_t)wave * CQ_WSLOT + lane;
-
-  // fragment offsets (16-byte slots)
-  int b_off[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int y = (q >> 1) * 4 + (li >> 3), x = (q & 1) * 8 + (li & 7);
-    b_off[q] = (kk * CQ_HALO + y) * CQ_PITCH + x;
-  }
+  const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 5 * 4 * CQ_WCOL +
+                     (int64_t)wave * CQ_WCOL + lane;
+  int prow, px;
+  cq_lane_pixel(li, prow, px);
+  const int b_base = (kk * CQ_HALO + prow) * CQ_PITCH + px;      // + r * CQ_PITCH + dx (+ piece stride)
   const int a_off = kk * 32 + li;
 
   cq_f32x16 acc[8];
@@ -149,14 +204,19 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-  auto wdma = [&](int g, int tap, int slot) {
-    const uint4* src = wq4 + ((int64_t)g * 25 + tap) * 4 * CQ_WSLOT;
-    const unsigned dst = w_lds_addr + slot * (CQ_WSLOT * 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier LDS reads of the slot are complete
-    cq_dma16(src, dst);
-    cq_dma16(src + 64, dst + 1024);
-    cq_dma16(src + 128, dst + 2048);
+  // pass h = 2 * (g * 5 + dx) + odd: stream its 3 (even) or 2 (odd) tap slots into this wave's buffer
+  auto wdma = [&](int h) {
+    const int odd = h & 1;
+    const uint4* src = wq4 + (int64_t)(h >> 1) * 4 * CQ_WCOL + odd * 3 * CQ_WSLOT;
+    if (odd) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) cq_dma16(src + 64 * i, w_lds_addr + 1024 * i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) cq_dma16(src + 64 * i, w_lds_addr + 1024 * i);
+    }
   };
+  wdma(0);
 
   for (int g = 0; g < 8; ++g) {
     __syncthreads();                                   // every wave is done with the previous tile
@@ -164,48 +224,37 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
       const uint4* src = xs4 + (int64_t)g * 2 * PP;
       const unsigned dst = lds_base + (wave * 64) * 16;
 #pragma unroll
-      for (int e = 0; e < 11; ++e) cq_dma16(src + in_src[e], dst + e * 4096);
-      if (wave == 0) cq_dma16(src + in_src[11], dst + 11 * 4096);
+      for (int e = 0; e < CQ_IN_PAD / 256; ++e) cq_dma16(src + in_src[e], dst + e * 4096);
+      if (wave * 64 < CQ_IN_PAD % 256) cq_dma16(src + in_src[NE - 1], dst + (CQ_IN_PAD / 256) * 4096);
     }
-    wdma(g, 0, 0);
     cq_wait_vm<0>();
     __syncthreads();                                   // the tile of every wave has landed
 #pragma unroll 1
-    for (int dy = 0; dy < 5; ++dy) {
+    for (int dx = 0; dx < 5; ++dx) {
+      const uint4* il = in_l + b_base + dx;
+      const int h0 = 2 * (g * 5 + dx);
+      {
+        // this pass's weights: issued one pass ago (at the head of a stage everything was drained with the tile)
+        cq_wait_vm<0>();
+        uint4 a[3][3];
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        const int tap = dy * 5 + dx;
-        const int slot = tap & 1;
-        if (tap + 1 < 25) {
-          wdma(g, tap + 1, slot ^ 1);
-          cq_wait_vm<3>();                             // this tap's three pieces are in LDS
-        } else {
-          cq_wait_vm<0>();
-        }
-        const uint4* wl = w_l + slot * CQ_WSLOT + a_off;
-        const uint4 a0 = wl[0], a1 = wl[64], a2 = wl[128];
-        const uint4* il = in_l + dy * CQ_PITCH + dx;
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int qp = 0; qp < 4; ++qp) {
-          uint4 b[2][3];
+          for (int p = 0; p < 3; ++p) a[t][p] = w_l[t * CQ_WSLOT + p * 64 + a_off];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wdma(h0 + 1);                                  // the buffer is free: stream the next pass
+        cq_column_pass<3, 0>(a, il, acc);
+      }
+      {
+        cq_wait_vm<0>();
+        uint4 a[2][3];
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[h][p] = il[p * (2 * CQ_HALO * CQ_PITCH) + b_off[2 * qp + h]];
-          // smallest terms first; the two accumulators alternate
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = cq_mfma(a0, b[h][2], acc[2 * qp + h]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = cq_mfma(a1, b[h][1], acc[2 * qp + h]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = cq_mfma(a2, b[h][0], acc[2 * qp + h]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = cq_mfma(a0, b[h][1], acc[2 * qp + h]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = cq_mfma(a1, b[h][0], acc[2 * qp + h]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[2 * qp + h] = cq_mfma(a0, b[h][0], acc[2 * qp + h]);
-        }
+          for (int p = 0; p < 3; ++p) a[t][p] = w_l[t * CQ_WSLOT + p * 64 + a_off];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (h0 + 2 < 80) wdma(h0 + 2);
+        cq_column_pass<2, 1>(a, il, acc);
       }
     }
   }
@@ -226,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
       v = fmaxf(v, acc[q][4 * g4 + 1] + b1);
       v = fmaxf(v, acc[q][4 * g4 + 2] + b2);
       v = fmaxf(v, acc[q][4 * g4 + 3] + b3);
-      const int y = ty0 + (q >> 1) * 4 + (li >> 3), x = tx0 + (q & 1) * 8 + (li & 7);
+      const int y = ty0 + 2 * q + prow, x = tx0 + px;
       if (y < L && x < L) {
         u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
         s1 += v;

@@ -68,7 +68,10 @@ static int64_t norm_ws_floats(int L) {
 // the one workspace of the context, sized for max_L (both halves and every L <= max_L use the same carving)
 static int bwd_workspace(dmp_ctx* c, BwdWs* w) {
   const int64_t L = c->max_L, P = act_pitch(c->max_L);
-  const int64_t n_norm = (norm_ws_floats(c->max_L) + 3) & ~(int64_t)3, n_xpad = (int64_t)CW * P * P;
+  // the norm region also holds the bias gradient's first-stage partials (conv5x5_maxout_bwd: CW x DB_CHUNKS x 4 doubles),
+  // which are larger than norm_ws_floats below max_L = 73 (they ran into xpad at max_L = 64)
+  const int64_t n_norm = (std::max<int64_t>(norm_ws_floats(c->max_L), 2 * (int64_t)CW * DB_CHUNKS * 4) + 3) & ~(int64_t)3;
+  const int64_t n_xpad = (int64_t)CW * P * P;
   const int64_t n_wd = (int64_t)DG_MSPLIT * DG_NCHUNK * DG_WSLAB, n_part = (int64_t)WG_KSPLIT * 512 * 3200;
   const int64_t n_idx = ((int64_t)CW * L * L + 3) / 4;
   // the stem's backward (below) uses the space behind the norm region differently: DZ (384 L^2) + one GEMM panel

@@ -684,7 +684,7 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
       if (rc) return rc;
     }
     if (c->conv_mode == 2)
-      hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(grid), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
+      hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(conv_bf16_grid(tiles)), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
                          B.bias, L, P, tiles, nwork, d_u, c->part);
     else
       hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,

@@ -45,9 +45,12 @@ constexpr int VP_MAX_XCD_TILES = 64;                           // (+ 1.1 KB of s
 constexpr int VP_GRID = 256;                                 // one workgroup per CU, 32 per XCD
 struct VPSync { unsigned count[8]; unsigned pad[24]; unsigned flag[8][32]; };              // zeroed before every launch
 static_assert(sizeof(VPSync) == 128 + 1024, "VPSync layout");
-// polls of a row barrier before it gives up (about 0.3 us each: a quarter of a second; the longest legitimate wait is
-// the start of a launch, while the last convolutions of other engines leave the CUs: milliseconds)
+// polls of a row barrier before it gives up (about 0.3 us each: a quarter of a second).  The FIRST barrier of a launch is
+// also the residency wait - its 256 workgroups become resident as the kernels of other engines leave the CUs, and a
+// float32 convolution at L ~ 2048 runs for 0.1-0.2 s - so it gets eight times the bound (two seconds); later rows only
+// wait for workgroups that are known to be running.
 constexpr unsigned VP_BARRIER_SPINS = 800000u;
+constexpr unsigned VP_BARRIER_SPINS_FIRST = 8u * VP_BARRIER_SPINS;
 
 
 // vgru_f32.hip: rows [t_lo, t_hi) of the group set up on `lead` in float32 (option "vgru_f32")

@@ -718,7 +718,8 @@ void vgru_persist_kernel(VStatic st, const VGroupRec* __restrict__ rec, VPSync* 
     if (w == 0) {
       const unsigned* fp = &sync->flag[xcc][lane & 31];
       bool ok = false;
-      for (unsigned spins = 0; spins < VP_BARRIER_SPINS && !ok; ++spins) {
+      const unsigned bound = t == t_lo ? VP_BARRIER_SPINS_FIRST : VP_BARRIER_SPINS;      // vgru.h: the first barrier is the residency wait
+      for (unsigned spins = 0; spins < bound && !ok; ++spins) {
         unsigned v;
         asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(fp) : "memory");
         ok = __builtin_amdgcn_ballot_w64(v < epoch) == 0ull;

@@ -303,7 +303,8 @@ void vgru_persist_f32_kernel(VStaticF32 st, const VGroupRec* __restrict__ rec, V
     if (w == 0) {
       const unsigned* fp = &sync->flag[xcc][lane & 31];
       bool ok = false;
-      for (unsigned spins = 0; spins < VP_BARRIER_SPINS && !ok; ++spins) {
+      const unsigned bound = t == t_lo ? VP_BARRIER_SPINS_FIRST : VP_BARRIER_SPINS;      // vgru.h: the first barrier is the residency wait
+      for (unsigned spins = 0; spins < bound && !ok; ++spins) {
         unsigned v;
         asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(fp) : "memory");
         ok = __builtin_amdgcn_ballot_w64(v < epoch) == 0ull;
@@ -327,10 +328,6 @@ int vgru_f32_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
   if (t_hi > lead->vg_maxN + 1) t_hi = lead->vg_maxN + 1;
   if (t_lo < 0) t_lo = 0;
   if (t_lo >= t_hi) return DMP_OK;
-  if (!lead->vgru_persist_ok) {
-    set_error("the float32 vertical GRU is laid out for 256 CUs in 8 XCDs (MI355X); this device differs");
-    return DMP_ERR_ARG;
-  }
   const Weights& W = lead->W;
   VStaticF32 st{};
   st.wh0 = reinterpret_cast<const float4*>(W.v_f32[0]);
@@ -342,7 +339,9 @@ int vgru_f32_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
     for (int p = 0; p < 2; ++p) st.hT[l][p] = lead->hT[l][p];
   const VGroupRec* rec = reinterpret_cast<const VGroupRec*>(lead->vgru_run);
   VPSync* sync = reinterpret_cast<VPSync*>(lead->vgru_sync);
-  if (lead->vgru_persist) {
+  // A device without 256 CUs in 8 XCDs (partitioned / CPX modes: vgru_persist_ok is false) gets the launch-per-row form
+  // below: with the barrier off the kernel takes its (XCD, slice) from the block id and depends on no placement.
+  if (lead->vgru_persist && lead->vgru_persist_ok) {
     // needs every one of its 256 workgroups resident (row barriers): ordered against the process's other persistent
     // launches and cluster kernels on this device (CoResident, common.h)
     CoResident guard(lead, s, true);

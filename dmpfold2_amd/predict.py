@@ -22,6 +22,7 @@ import argparse
 import ctypes as C
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -160,21 +161,38 @@ def raise_for_faults(bits):
 # engine: one dmp_ctx per GPU
 # ---------------------------------------------------------------------------
 def _env_precision():
-    """DMPFOLD_PRECISION=1 selects the reference's float32 arithmetic end to end (option "precision": float32 matrix-core
-    convolutions and vertical GRU, about a third of the default's speed) for the drop-in entry points - aln_to_coords, the
-    CLI, the batch front end - which have no argument for it; 0 / unset = the default split-f16 products."""
+    """DMPFOLD_PRECISION selects the arithmetic (option "precision" of include/dmpfold_hip.h) for the drop-in entry points -
+    aln_to_coords, the CLI, the batch front end - which have no argument for it:
+      2  full-width operands on the 16-bit matrix cores: the convolutions' float32 operands as three exact bf16 pieces (24
+         significand bits, six products), float32 vertical GRU;
+      1  the reference's instructions: float32 matrix-core convolutions and vertical GRU (about half the speed of 2);
+      0  the fast mode: two f16 pieces per operand (22-23 significand bits), about 1.8 x the speed of 2.
+    Unset = the library's default."""
     v = os.environ.get("DMPFOLD_PRECISION", "").strip()
     if v == "":
         return None
-    if v not in ("0", "1"):
-        raise ValueError(f"DMPFOLD_PRECISION must be 0 or 1, got {v!r}")
+    if v not in ("0", "1", "2"):
+        raise ValueError(f"DMPFOLD_PRECISION must be 0, 1 or 2, got {v!r}")
     return int(v)
+
+
+# What the reference's own entry points compute in is float32 (predict.py:136 `.float()`, network.py:25-31), so the DROP-IN
+# entry points of this package - aln_to_coords, the CLI, the batch front end - default to the setting whose operands carry
+# float32's 24 significand bits at the 16-bit matrix cores' rate (option "precision" = 2); DMPFOLD_PRECISION=0 selects the
+# fast 22-23-bit mode (about 1.8 x the speed), 1 the f32 matrix-core instructions.  A context made through the C ABI or
+# an `Engine` made directly starts in the library's setting (precision 0) unless DMPFOLD_PRECISION says otherwise.
+DROP_IN_PRECISION = 2
+
+
+def drop_in_precision():
+    v = _env_precision()
+    return DROP_IN_PRECISION if v is None else v
 
 
 class Engine:
     """Owns one `dmp_ctx` (device buffers + packed weights) on one GPU."""
 
-    def __init__(self, device, max_L, max_N, stream=None):
+    def __init__(self, device, max_L, max_N, stream=None, precision=None):
         self.lib = _lib.load()
         self.device = _resolve_device(device)
         self.max_L = int(max_L)
@@ -186,7 +204,7 @@ class Engine:
                                                C.byref(self._ctx)))
         self.weights_tag = None
         self.last_fallback = False     # the last predict_*_checked call fell back to conv_mode 2
-        prec = _env_precision()
+        prec = precision if precision is not None else _env_precision()
         if prec is not None:
             self.set_option("precision", prec)
 
@@ -381,13 +399,13 @@ class Pipeline:
     an engine that is still in its eigensolver or front end.  Targets are taken from one queue by
     whichever engine is free."""
 
-    def __init__(self, device, max_L, max_N, state_dict, streams=2):
+    def __init__(self, device, max_L, max_N, state_dict, streams=2, precision=None):
         self.lib = _lib.load()
         self.device = _resolve_device(device)
         self.engines = []
         for _ in range(max(1, int(streams))):
             st = _take_stream(self.device)
-            eng = Engine(self.device, max_L, max_N, stream=st)
+            eng = Engine(self.device, max_L, max_N, stream=st, precision=precision)
             if self.engines:
                 eng.share_weights(self.engines[0])       # packed once per pipeline, not once per engine
             else:
@@ -433,6 +451,12 @@ class Pipeline:
         self._riding = {}             # ticket -> True: a rider whose chain has not been issued to its end yet
         self._rider_wait = [None] * S  # per leading engine: (jobs, outs) of the riders in the chain it has yet to issue
         self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain it rode in)
+
+    def set_option(self, name, value):
+        """An engine option on EVERY engine of the pipeline (a group's vertical-GRU chain runs in its leader's arithmetic
+        and serves all members: the engines must agree on "precision" / "vgru_f32" / "vgru_persistent")."""
+        for e in self.engines:
+            e.set_option(name, value)
 
     def close(self):
         for e in self.engines:
@@ -739,31 +763,74 @@ class Pipeline:
         raise_for_faults(bits)
 
 
-_ENGINES = {}
+class _EngineCache(dict):
+    """device index -> the engine used last there (what tests and diagnostics look at).  Behind it a small LRU of
+    engines per device, one per weights file: the reference builds a fresh network on every call (predict.py:79), so
+    callers may alternate between weight files - or call from several threads - without re-packing 140 MB each time."""
+    MAX_PER_DEVICE = 2
+
+    def __init__(self):
+        super().__init__()
+        self.lru = {}                 # device index -> [engine, ...], most recently used last
+
+    def clear(self):
+        for engines in self.lru.values():
+            for e in engines:
+                e.close()
+        self.lru = {}
+        super().clear()
+
+
+_ENGINES = _EngineCache()
+_DEVICE_LOCKS = {}
+_LOCKS_GUARD = threading.Lock()
+
+
+def device_lock(device):
+    """One re-entrant lock per GPU for the drop-in entry points: `aln_to_coords` may be called from several threads (the
+    reference's function is re-entrant - every call builds its own network, predict.py:79); here the calls of a device
+    share cached engines whose buffers one prediction owns from its first kernel to its synchronisation, so they take
+    turns.  (Throughput across targets is what `Pipeline` / the batch front end are for.)"""
+    dev = _resolve_device(device)
+    with _LOCKS_GUARD:
+        return _DEVICE_LOCKS.setdefault(dev.index, threading.RLock())
 
 
 def get_engine(device, L, N, weights_file=None, state_dict=None):
-    """Cached engine for `device`, grown when an alignment exceeds its capacity; weights are
-    packed once per (engine, weights file)."""
+    """Cached engine for `device` and these weights, grown when an alignment exceeds its capacity; weights are packed
+    once per (engine, weights file).  Call it - and use the engine - under `device_lock(device)` when other threads may
+    do the same."""
     if L > MAX_L:
         raise RuntimeError(f"alignment has {L} columns; this build supports at most {MAX_L} "
                            "(include/dmpfold_hip.h DMP_MAX_L: the eigensolver's LDS image)")
     dev = _resolve_device(device)
-    eng = _ENGINES.get(dev.index)
-    if eng is None or L > eng.max_L or min(N, MAX_SEQS) > eng.max_N:
-        old = eng
-        max_L = max(L, old.max_L if old else 0)
-        max_N = max(min(N, MAX_SEQS), old.max_N if old else 0)
-        if old is not None:
-            old.close()
-        eng = Engine(dev, max_L, max_N)
-        _ENGINES[dev.index] = eng
+    N = min(N, MAX_SEQS)
     if state_dict is not None:
-        eng.set_weights(state_dict, tag=None)
+        tag = None
     else:
         files = [weights_file] if weights_file is not None else default_weight_files()
         tag = tuple((f, os.path.getmtime(f)) for f in files if os.path.isfile(f))
-        if eng.weights_tag != tag or not tag:
+    with device_lock(dev):
+        lru = _ENGINES.lru.setdefault(dev.index, [])
+        eng = next((e for e in lru if tag and e.weights_tag == tag), None)
+        if eng is None and lru and (not tag or len(lru) >= _EngineCache.MAX_PER_DEVICE):
+            eng = lru[0]                                  # recycle the least recently used one (new weights below)
+        if eng is not None:
+            lru.remove(eng)
+        if eng is None or L > eng.max_L or N > eng.max_N:
+            max_L = max(L, eng.max_L if eng else 0)
+            max_N = max(N, eng.max_N if eng else 0)
+            if eng is not None:
+                eng.close()
+            eng = Engine(dev, max_L, max_N)              # (weights_tag None: packed below)
+        lru.append(eng)
+        _ENGINES[dev.index] = eng
+        want = drop_in_precision()
+        if eng.get_option("precision") != want:
+            eng.set_option("precision", want)
+        if state_dict is not None:
+            eng.set_weights(state_dict, tag=None)
+        elif eng.weights_tag != tag or not tag:
             eng.set_weights(load_state_dict(weights_file), tag=tag)
     return eng
 
@@ -780,8 +847,9 @@ def aln_to_coords(input_file, device=default_device, template=None, iterations=d
     template_ca = read_template_ca(template) if template is not None else None
     alnmat = encode_aln(aln)
     nseqs, length = alnmat.shape
-    eng = get_engine(dev, length, nseqs, weights_file=weights_file)
-    coords, confs = eng.predict_checked(alnmat, template_ca, iterations, minsteps)
+    with device_lock(dev):                  # re-entrant like the reference's function: callers of one GPU take turns
+        eng = get_engine(dev, length, nseqs, weights_file=weights_file)
+        coords, confs = eng.predict_checked(alnmat, template_ca, iterations, minsteps)
     if return_alnmat:
         return coords, confs, alnmat
     return coords, confs

@@ -30,19 +30,24 @@ def partition_targets(costs, world: int):
     return shards
 
 
-def job_summary(n_done: int, elapsed: float, group=None):
-    """(total targets, max elapsed) over all ranks - the only communication of a sharded job."""
+def job_summary(n_done: int, elapsed: float, group=None, failures=None):
+    """(total targets, max elapsed) over all ranks - the only communication of a sharded job.  With `failures` = (failed
+    targets of this rank, 1 if this rank itself broke down else 0) the answer also carries their sums over the ranks:
+    (total, max elapsed, failed targets, broken ranks) - so that rank 0's summary shows that ANOTHER rank lost targets."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return n_done, elapsed
+        return (n_done, elapsed) if failures is None else (n_done, elapsed, int(failures[0]), int(failures[1]))
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    cnt = torch.tensor([float(n_done)], dtype=torch.float64, device=dev)
+    f = failures if failures is not None else (0, 0)
+    cnt = torch.tensor([float(n_done), float(f[0]), float(f[1])], dtype=torch.float64, device=dev)
     tmax = torch.tensor([float(elapsed)], dtype=torch.float64, device=dev)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
-    return int(round(cnt.item())), float(tmax.item())
+    if failures is None:
+        return int(round(cnt[0].item())), float(tmax.item())
+    return int(round(cnt[0].item())), float(tmax.item()), int(round(cnt[1].item())), int(round(cnt[2].item()))
 
 
 def job_store(rank: int, world: int, timeout_s: float = 1800.0):

@@ -415,6 +415,31 @@ def main():
                             "coord_gru_mds_scale": np.float64(eps),
                             "msa_seed": np.int64(0), "msa_rows": np.int64(2000)})
 
+    # Round 6: the minimiser ON at the metric configuration a SECOND time and at the two large
+    # configurations.  Same stability design as fitns_* (coord_fc fitted with ridge 1e-3 to a protein-like trace of the
+    # target's length, the coordinate GRU's 8 MDS columns x 0.02), other seeds:
+    #   fitns2_*  L=300 N=2000 10+100, alignment seed 7, WEIGHT seed 1, trace seed 1 - independent of fitns_* in every input
+    #   fit_L500_N5000_n30_m200    BASELINE configs[2] in full: 5000 rows cut to 3000, 31 trunk passes, 2 x 200 steps
+    #   fit_L1000_N2000_n3_m1000   BASELINE configs[4] at reduced depth: 4 trunk passes, 2 x 1000 steps
+    # Hours of this container's CPU: made only when named in --only.
+    for name, fL, fN, mseed, wseed, fn, fm, kw in (
+            ("fitns2_L300_N2000_n10_m100", 300, 2000, 7, 1, 10, 100, dict(noise_threads=(4, 5))),
+            ("fit_L1000_N2000_n3_m1000", 1000, 2000, 0, 0, 3, 1000, dict(noise_threads=(4,), oracle8=False)),
+            ("fit_L500_N5000_n30_m200", 500, 5000, 5, 0, 30, 200, dict(noise_threads=(4,), oracle8=False))):
+        if name not in only:
+            continue
+        rowsf = synth.synth_msa(fL, fN, mseed)
+        targetf = protein_like_trace(fL, wseed + mseed)
+        sdf = synth.headline_fixture_weights(np.zeros((3, 512), np.float32), 0.02, seed=wseed)
+        sdf["coord_fc.weight"] = fit_coord_fc(sdf, rowsf, targetf, 1e-3)
+        wff = f"/tmp/golden_weights_{name}.pt"
+        synth.save_state_dict(wff, sdf)
+        capture_case(name, rowsf, fn, fm, wff, synth.weights_checksum(sdf), stages=False, report=report,
+                     store_aln=False,
+                     extra={"coord_fc": sdf["coord_fc.weight"], "target_ca": targetf, "ridge": np.float64(1e-3),
+                            "coord_gru_mds_scale": np.float64(0.02), "weights_seed": np.int64(wseed),
+                            "msa_seed": np.int64(mseed), "msa_rows": np.int64(fN)}, **kw)
+
     # a second weight set: different seed AND a different activation regime (InstanceNorm gamma / beta x 4:
     # the residual stream of the trunk reaches several hundred instead of tens), VERDICT r02 item 1c
     name = "w1x4_L128_N500_n3_m0"

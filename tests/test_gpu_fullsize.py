@@ -266,8 +266,9 @@ def test_cluster_tridiagonalisation_is_bitwise_the_per_step_launches(synth_sd):
         st.eng.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("name", ["synth_L200_N1000_n10_m0", "synth_L500_N5000_n1_m0", "synth_L1000_N2000_n0_m0"])
-def test_baseline_config_sizes_vs_reference(synth_sd, name):
+def test_baseline_config_sizes_vs_reference(synth_sd, name, precision):
     """The single-target configurations of BASELINE.json at their own sizes against outputs of the reference
     itself (tests/golden/make_goldens.py; minimiser off - it is chaotic on random weights): configs[1]
     L=200, N=1000, 10 iterations; configs[2] L=500, N=5000 (cut to 3000 rows), 1 iteration; configs[4]
@@ -287,6 +288,7 @@ def test_baseline_config_sizes_vs_reference(synth_sd, name):
     n = int(g["iterations"])
     eng = Engine("cuda:0", L, alnmat.shape[0])
     eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+    eng.set_option("precision", precision)
     try:
         coords, confs = eng.predict(alnmat, None, n, 0)
         eng.sync_check()
@@ -303,7 +305,7 @@ def test_baseline_config_sizes_vs_reference(synth_sd, name):
         assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
         final = ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1])
         dconf = float(np.abs(confs.cpu().numpy() - g["confs"]).max())
-        print(name, "per-pass CA-RMSD", dev, "final", final, "max|dconf|", dconf)
+        print(name, "precision", precision, "per-pass CA-RMSD", dev, "final", final, "max|dconf|", dconf)
         if name == "synth_L1000_N2000_n0_m0":
             # the documented ill-conditioned case (two of the top eight MDS eigenvalues 3e-4 apart: the reference's
             # float32 LAPACK eigenvectors are 1.8e-3 A from the exact ones of its own matrix); the well-separated
@@ -311,7 +313,10 @@ def test_baseline_config_sizes_vs_reference(synth_sd, name):
             assert final <= max(1e-3, 3.0 * max(float(g["noise_ca_rmsd"]), eig))
         else:
             assert final <= 1e-3                       # the output of aln_to_coords: plain north-star tolerance
-        assert dconf < 1e-4
+        # confidences: the plain tolerance where the reference's OWN thread-count spread allows it - on the L = 200
+        # fixture (eleven passes) its 8- and 4-thread runs are 8.0e-5 apart, and the float32-MFMA setting lands 1.5e-4
+        # from the 8-thread run (round 6: the test used to run in the fast mode only, which lands below 1e-4)
+        assert dconf < max(1e-4, 3.0 * float(g["noise_conf"])), (dconf, float(g["noise_conf"]))
     finally:
         eng.close()
 
@@ -334,13 +339,13 @@ def test_config4_L1000_well_separated_spectrum_vs_reference(synth_sd):
     eng = Engine("cuda:0", L, alnmat.shape[0])
     eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
     try:
-        for mode in (0, 1):
-            eng.set_option("conv_mode", mode)
+        for mode in (0, 1, 2):
+            eng.set_option("precision", mode)
             coords, confs = eng.predict(alnmat, None, 1, 0)
             eng.sync_check()
             ca_pass = eng.fetch("ca_pass", 2 * L * 3).cpu().numpy().reshape(2, L, 3)
             dev = np.array([ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(2)])
-            print("L=1000 well-separated, conv_mode", mode, "per-pass CA-RMSD", dev)
+            print("L=1000 well-separated, precision", mode, "per-pass CA-RMSD", dev)
             assert (dev <= 1e-3).all(), (mode, dev)
             means = eng.fetch("conf_means", 2).cpu().numpy()
             assert np.abs(means - g["conf_mean_pass"]).max() < 1e-4
@@ -350,8 +355,9 @@ def test_config4_L1000_well_separated_spectrum_vs_reference(synth_sd):
         eng.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("name,L", [("deep_L500_N5000_n30_m0", 500), ("deep_L1000_N2000_n10_m0", 1000)])
-def test_deep_recycling_at_the_large_configurations_vs_reference(synth_sd, name, L):
+def test_deep_recycling_at_the_large_configurations_vs_reference(synth_sd, name, L, precision):
     """the recycling loop (network.py:264-306) at DEPTH at the large configurations, through the
     reference itself - configs[2] (L=500, 5000 rows cut to 3000) at 31 trunk passes and configs[4] (L=1000, the
     well-separated seed 0) at 11 - every pass's trace and confidence mean.  One reference run takes most of an hour
@@ -372,6 +378,7 @@ def test_deep_recycling_at_the_large_configurations_vs_reference(synth_sd, name,
     assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
     eng = Engine("cuda:0", L, alnmat.shape[0])
     eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
+    eng.set_option("precision", precision)
     try:
         coords, confs = eng.predict(alnmat, None, n, 0)
         eng.sync_check()
@@ -381,7 +388,7 @@ def test_deep_recycling_at_the_large_configurations_vs_reference(synth_sd, name,
         means = eng.fetch("conf_means", P).cpu().numpy()
         final = ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1])
         dconf = float(np.abs(confs.cpu().numpy() - g["confs"]).max())
-        print(name, "per-pass CA-RMSD", np.array2string(dev, precision=2), "floors", np.array2string(floor, precision=2),
+        print(name, "precision", precision, "per-pass CA-RMSD", np.array2string(dev, precision=2), "floors", np.array2string(floor, precision=2),
               "final", final, "max|dconf|", dconf, "max|dmean|", float(np.abs(means - g["conf_mean_pass"]).max()))
         assert (dev <= np.maximum(1e-3, 4.0 * floor)).all(), (dev, floor)
         assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
@@ -413,8 +420,8 @@ def test_above_the_former_length_limit_vs_reference(synth_sd):
     eng = Engine("cuda:0", L, alnmat.shape[0])
     eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
     try:
-        for mode in (0, 1):
-            eng.set_option("conv_mode", mode)
+        for mode in (0, 1, 2):
+            eng.set_option("precision", mode)
             coords, confs = eng.predict(alnmat, None, 0, 0)
             eng.sync_check()
             ca = eng.fetch("ca_pass", L * 3).cpu().numpy().reshape(L, 3)
@@ -422,7 +429,7 @@ def test_above_the_former_length_limit_vs_reference(synth_sd):
             means = eng.fetch("conf_means", 1).cpu().numpy()
             final = ca_rmsd(coords.cpu().numpy()[:, 1], g["coords"][:, 1])
             dconf = float(np.abs(confs.cpu().numpy() - g["confs"]).max())
-            print("L=1344, conv_mode", mode, "CA-RMSD pass 0", dev, "final", final, "max|dconf|", dconf)
+            print("L=1344, precision", mode, "CA-RMSD pass 0", dev, "final", final, "max|dconf|", dconf)
             assert dev <= 1e-3 and final <= 1e-3, (mode, dev, final)
             assert np.abs(means - g["conf_mean_pass"]).max() < 1e-4
             assert dconf < 1e-4
@@ -482,3 +489,58 @@ def test_largest_length_end_to_end(synth_sd, oracle_weights):
         assert np.array_equal(gram, gram.T)
     finally:
         st.eng.close()
+
+
+@pytest.mark.parametrize("precision", [0, 1, 2])
+@pytest.mark.parametrize("name,L", [("fitns2_L300_N2000_n10_m100", 300), ("fit_L500_N5000_n30_m200", 500),
+                                    ("fit_L1000_N2000_n3_m1000", 1000)])
+def test_minimiser_on_at_the_configured_sizes_vs_reference(name, L, precision):
+    """the minimiser ON, through the reference itself (network.py:106-137, 257-258, 308-309), at
+    - the metric's configuration a SECOND time (fitns2_*: L=300 N=2000 10+100 with another alignment seed, another weight
+      seed and another regression target than fitns_*: the headline parity is no longer one sample),
+    - BASELINE configs[2] IN FULL (L=500, 5000 rows cut to 3000, 30 iterations + 200 steps),
+    - BASELINE configs[4] at reduced depth (L=1000, 3 iterations + 1000 steps),
+    on weight sets of the stability design of fitns_* (coord_fc fitted to a protein-like trace of the target's length,
+    the coordinate GRU's MDS columns x 0.02; tests/golden/make_goldens.py).  In all three arithmetic settings: final
+    structure max(1e-3, 3 x the reference's own thread-count floor) A, confidences 1e-4 (or 3 x their floor), every pass's
+    trace max(1e-3, 4 x that pass's floor), bonds of the refined trace near 3.8 A."""
+    import hashlib
+    import os
+    import sys
+    from conftest import GOLDEN, load_golden
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated: " + name)
+    g = load_golden(name)
+    n, m = int(g["iterations"]), int(g["minsteps"])
+    sd = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]), seed=int(g["weights_seed"]))
+    assert synth.weights_checksum(sd) == bytes(g["weights_sha256"]).decode()
+    alnmat = encode_aln(synth.synth_msa(L, int(g["msa_rows"]), int(g["msa_seed"])))
+    assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
+    eng = Engine("cuda:0", L, alnmat.shape[0])
+    eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    eng.set_option("precision", precision)
+    try:
+        coords, confs = eng.predict(alnmat, None, n, m)
+        eng.sync_check()
+        coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
+        P = n + 1
+        ca_pass = eng.fetch("ca_pass", P * L * 3).cpu().numpy().reshape(P, L, 3)
+        dev = np.array([ca_rmsd(ca_pass[p], g["ca_pass"][p]) for p in range(P)])
+        floor = np.asarray(g["noise_ca_pass"])
+        means = eng.fetch("conf_means", P).cpu().numpy()
+        final = ca_rmsd(coords[:, 1], g["coords"][:, 1])
+        dconf = float(np.abs(confs - g["confs"]).max())
+        print(name, "precision", precision, "per-pass CA-RMSD", np.array2string(dev, precision=2), "floors",
+              np.array2string(floor, precision=2), "final", final, "floor", float(g["noise_ca_rmsd"]), "max|dconf|", dconf,
+              file=sys.stderr)
+        # (pass 0: the fixture's trace is the coordinate head's output, the engine records it after the first refinement)
+        assert (dev[1:] <= np.maximum(1e-3, 4.0 * floor)[1:]).all(), (dev, floor)
+        assert np.abs(means - g["conf_mean_pass"]).max() < 1e-3
+        assert final <= max(1e-3, 3.0 * float(g["noise_ca_rmsd"])), (final, float(g["noise_ca_rmsd"]))
+        assert dconf < max(1e-4, 3.0 * float(g["noise_conf"]))
+        bonds = np.linalg.norm(coords[1:, 1] - coords[:-1, 1], axis=1)
+        assert 3.6 < bonds.min() and bonds.max() < 4.0          # the minimiser ran in its regular regime
+    finally:
+        eng.close()

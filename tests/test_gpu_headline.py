@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 import dmpfold_oracle as O          # noqa: E402  (test infrastructure: the checker)
 
-MODES = {"f16x3": 0, "f32": 1}
+MODES = {"f16x3": 0, "f32": 1, "bf16x3": 2}       # option "precision": split f16 / f32 MFMA / exact 3 x bf16 + f32 GRU
 
 
 def _engine(sd, max_L, max_N):
@@ -68,7 +68,7 @@ def test_pf10963_eleven_passes_vs_reference(small_engine, mode):
     pass's CA trace and confidence mean against the reference's, then the final structure."""
     g = load_golden("pf10963_n10_m0")
     eng = small_engine
-    eng.set_option("conv_mode", MODES[mode])
+    eng.set_option("precision", MODES[mode])
     try:
         coords, confs = eng.predict(g["alnmat"], None, 10, 0)
         eng.sync_check()
@@ -78,7 +78,7 @@ def test_pf10963_eleven_passes_vs_reference(small_engine, mode):
         assert np.abs(confs - g["confs"]).max() < 1e-4
         assert np.abs(coords - g["coords"]).max() < 2e-2
     finally:
-        eng.set_option("conv_mode", 0)
+        eng.set_option("precision", 0)
 
 
 # ------------------------------------------------------------------ the benchmark's size
@@ -99,7 +99,7 @@ def test_north_star_size_vs_reference(ns_engine, mode):
     alnmat = encode_aln(synth.synth_msa(300, 2000, int(g["msa_seed"])))
     assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
     eng = ns_engine
-    eng.set_option("conv_mode", MODES[mode])
+    eng.set_option("precision", MODES[mode])
     try:
         coords, confs = eng.predict(alnmat, None, 1, 0)
         eng.sync_check()
@@ -108,7 +108,7 @@ def test_north_star_size_vs_reference(ns_engine, mode):
         assert ca_rmsd(coords[:, 1], g["coords"][:, 1]) <= 1e-3
         assert np.abs(confs - g["confs"]).max() < 1e-4
     finally:
-        eng.set_option("conv_mode", 0)
+        eng.set_option("precision", 0)
 
 
 @pytest.mark.parametrize("mode", list(MODES))
@@ -121,7 +121,7 @@ def test_north_star_size_and_depth_vs_reference(ns_engine, mode):
     alnmat = encode_aln(synth.synth_msa(300, 2000, int(g["msa_seed"])))
     assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
     eng = ns_engine
-    eng.set_option("conv_mode", MODES[mode])
+    eng.set_option("precision", MODES[mode])
     try:
         coords, confs = eng.predict(alnmat, None, 10, 0)
         eng.sync_check()
@@ -132,7 +132,7 @@ def test_north_star_size_and_depth_vs_reference(ns_engine, mode):
         # convolution lands at 7.8e-5, the exact-f32 one at 1.7e-4
         assert np.abs(confs - g["confs"]).max() < max(1e-4, 3.0 * float(g["noise_conf"]))
     finally:
-        eng.set_option("conv_mode", 0)
+        eng.set_option("precision", 0)
 
 
 # ------------------------------------------------------------------ the benchmark's workload itself
@@ -156,7 +156,7 @@ def test_headline_workload_with_minimiser_vs_reference(mode):
     assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
     eng = _engine(sd, 300, 2000)
     try:
-        eng.set_option("conv_mode", MODES[mode])
+        eng.set_option("precision", MODES[mode])
         coords, confs = eng.predict(alnmat, None, 10, 100)
         eng.sync_check()
         coords, confs = coords.cpu().numpy(), confs.cpu().numpy()
@@ -196,7 +196,7 @@ def test_headline_size_at_full_mds_gain_vs_reference(mode):
     assert hashlib.sha256(alnmat.tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
     eng = _engine(sd, 300, 2000)
     try:
-        eng.set_option("conv_mode", MODES[mode])
+        eng.set_option("precision", MODES[mode])
         n, m = int(g["iterations"]), int(g["minsteps"])
         coords, confs = eng.predict(alnmat, None, n, m)
         eng.sync_check()
@@ -323,8 +323,8 @@ def test_small_activation_regimes_vs_reference(name):
                 check("block1_p0", x)
         check("block16_p0", x)
         print(name, "worst |f16x3 - f32| / scale over the 16 convolutions:", worst)
-        for mode in ("f16x3", "f32"):
-            eng.set_option("conv_mode", MODES[mode])
+        for mode in MODES:
+            eng.set_option("precision", MODES[mode])
             coords, confs = eng.predict(alnmat, None, 3, 0)
             eng.sync_check()
             dev = _check_passes(eng, g, 4, L, 1e-3)
@@ -333,7 +333,7 @@ def test_small_activation_regimes_vs_reference(name):
             print(name, mode, "per-pass CA-RMSD", dev, "final", final, "max|dconf|", dconf)
             assert final <= 1e-3 and dconf < 1e-4
     finally:
-        eng.set_option("conv_mode", 0)
+        eng.set_option("precision", 0)
         eng.close()
 
 
@@ -403,7 +403,7 @@ def test_minimiser_end_to_end_on_protein_like_traces(synth_sd, name, mode):
     from dmpfold2_amd import synth
     assert synth.weights_checksum(sd) == bytes(g["weights_sha256"]).decode()
     eng = _engine(sd, 96, 64)
-    eng.set_option("conv_mode", MODES[mode])
+    eng.set_option("precision", MODES[mode])
     try:
         n, m = int(g["iterations"]), int(g["minsteps"])
         coords, confs = eng.predict(g["alnmat"], None, n, m)
@@ -436,7 +436,7 @@ def _hot_weights(synth_sd):
     return sd
 
 
-def test_f16_range_fault_is_reported_poisoned_and_cured(synth_sd, tmp_path, capsys):
+def test_f16_range_fault_is_reported_poisoned_and_cured(synth_sd, tmp_path, capsys, monkeypatch):
     from dmpfold2_amd import aln_to_coords, synth
     from dmpfold2_amd import predict as P
     sd = _hot_weights(synth_sd)
@@ -481,7 +481,10 @@ def test_f16_range_fault_is_reported_poisoned_and_cured(synth_sd, tmp_path, caps
         assert eng.get_option("conv_mode") == 0
     finally:
         eng.close()
-    # the public function: same cure through aln_to_coords, and the engine is healthy afterwards
+    # the public function: same cure through aln_to_coords, and the engine is healthy afterwards (the FAST mode, selected
+    # through the environment: the drop-in default, precision 2, has float32's range and nothing to cure)
+    monkeypatch.setenv("DMPFOLD_PRECISION", "0")
+    P._ENGINES.clear()
     wf, aln = str(tmp_path / "hot.pt"), str(tmp_path / "t.aln")
     synth.save_state_dict(wf, sd)
     synth.write_aln(aln, rows)
@@ -498,6 +501,18 @@ def test_f16_range_fault_is_reported_poisoned_and_cured(synth_sd, tmp_path, caps
     assert "conv_mode=2" not in capsys.readouterr().err              # scaled pieces: no fault, no re-run
     assert ca_rmsd(c.cpu().numpy()[:, 1], ref_c.numpy()[:, 1]) <= 1e-3
     assert np.abs(f.cpu().numpy() - ref_f.numpy()).max() < 1e-4
+    # ... and in the drop-in default (full-width operands, float32's range) there is nothing to cure even unscaled
+    monkeypatch.delenv("DMPFOLD_PRECISION")
+    cached = P.get_engine("cuda:0", 40, 64, weights_file=wf)
+    assert cached.get_option("precision") == 2
+    cached.set_option("act_scaling", 0)
+    try:
+        c, f = aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=wf)
+        assert "conv_mode=2" not in capsys.readouterr().err
+        assert ca_rmsd(c.cpu().numpy()[:, 1], ref_c.numpy()[:, 1]) <= 1e-3
+    finally:
+        cached.set_option("act_scaling", 1)
+        P._ENGINES.clear()
 
 
 def test_unknown_residue_code_raises_index_error(small_engine, tmp_path, weights_file):
@@ -627,38 +642,88 @@ def test_two_part_default_weights_route(synth_sd, tmp_path, monkeypatch, weights
     P._ENGINES.clear()
 
 
-def test_env_selects_the_references_float32_arithmetic_for_the_drop_in_api(monkeypatch, weights_file, synth_sd):
-    """DMPFOLD_PRECISION=1: aln_to_coords / the CLI have no argument for the arithmetic, so the environment selects option
-    "precision" = 1 (float32 matrix-core convolutions and vertical GRU) for the engines they create; the result is the bits
-    of an engine set to precision 1 by hand, and differs from the default's."""
+def test_drop_in_default_is_full_width_and_the_environment_selects_the_arithmetic(monkeypatch, weights_file, synth_sd):
+    """aln_to_coords / the CLI have no argument for the arithmetic.  Their default is option "precision" = 2 - the
+    reference computes in float32 (predict.py:136, network.py:25-31), so the drop-in carries float32's 24-bit operands
+    (three exact bf16 pieces, float32 vertical GRU) - and DMPFOLD_PRECISION selects the others: 1 = the f32 matrix-core
+    instructions, 0 = the fast 22-bit mode.  Each gives the bits of an engine set to that precision by hand; the three
+    differ from each other by rounding only."""
     from dmpfold2_amd import predict as P
     aln = os.path.join(os.path.dirname(__file__), "golden", "PF10963.aln")
-    P._ENGINES.clear()
-    c0, f0 = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=weights_file)
-    P._ENGINES.clear()
-    monkeypatch.setenv("DMPFOLD_PRECISION", "1")
-    try:
-        c1, f1 = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=weights_file)
-        eng = P._ENGINES[0]
-        assert eng.get_option("precision") == 1 and eng.get_option("vgru_f32") == 1 and eng.get_option("conv_mode") == 1
-    finally:
-        monkeypatch.delenv("DMPFOLD_PRECISION")
-        P._ENGINES.clear()
     alnmat = P.encode_aln(P.read_aln(aln))
+    monkeypatch.delenv("DMPFOLD_PRECISION", raising=False)
+    got = {}
+    for env, want in ((None, 2), ("1", 1), ("0", 0), ("2", 2)):
+        P._ENGINES.clear()
+        if env is None:
+            monkeypatch.delenv("DMPFOLD_PRECISION", raising=False)
+        else:
+            monkeypatch.setenv("DMPFOLD_PRECISION", env)
+        c, f = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=weights_file)
+        eng = P._ENGINES[0]
+        assert eng.get_option("precision") == want and eng.get_option("vgru_f32") == (1 if want else 0)
+        assert eng.get_option("conv_mode") == want
+        if want in got:
+            assert torch.equal(got[want][0], c) and torch.equal(got[want][1], f)       # unset == "2"
+        got[want] = (c, f)
+    monkeypatch.delenv("DMPFOLD_PRECISION")
+    P._ENGINES.clear()
     e = P.Engine("cuda:0", alnmat.shape[1], alnmat.shape[0])
     try:
         e.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
-        assert e.get_option("precision") == 0
-        e.set_option("precision", 1)
-        c2, f2 = e.predict_checked(alnmat, None, 1, 0)
+        assert e.get_option("precision") == 0              # an engine made directly starts in the library's setting
+        for prec in (0, 1, 2):
+            e.set_option("precision", prec)
+            c2, f2 = e.predict_checked(alnmat, None, 1, 0)
+            assert torch.equal(got[prec][0], c2) and torch.equal(got[prec][1], f2), prec
     finally:
         e.close()
-    assert torch.equal(c1, c2) and torch.equal(f1, f2)
-    assert not torch.equal(c0, c1)
-    assert float((c0[:, 1] - c1[:, 1]).pow(2).sum(-1).mean().sqrt()) < 1e-3       # ... by rounding only
-    monkeypatch.setenv("DMPFOLD_PRECISION", "2")
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        assert not torch.equal(got[a][0], got[b][0])
+        assert float((got[a][0][:, 1] - got[b][0][:, 1]).pow(2).sum(-1).mean().sqrt()) < 1e-3       # ... by rounding only
+    monkeypatch.setenv("DMPFOLD_PRECISION", "3")
     with pytest.raises(ValueError, match="DMPFOLD_PRECISION"):
         P.Engine("cuda:0", 64, 8)
+
+
+def test_aln_to_coords_is_reentrant_two_threads_two_weight_files(tmp_path, synth_sd, weights_file):
+    """The reference builds a fresh network per call (predict.py:79), so its aln_to_coords may be called from several
+    threads, each with its own weights.  Here the calls of a GPU share cached engines: two threads, two weight files, two
+    alignments, interleaved a few times each - every result equals the same call made alone, bit for bit."""
+    import threading
+    from dmpfold2_amd import predict as P, synth
+    sd2 = synth.synth_weights(1, coord_scale=5.0)
+    wf2 = str(tmp_path / "seed1.pt")
+    synth.save_state_dict(wf2, sd2)
+    alns = []
+    for i, (L, N) in enumerate(((40, 64), (56, 48))):
+        a = str(tmp_path / f"t{i}.aln")
+        synth.write_aln(a, synth.synth_msa(L, N, 30 + i))
+        alns.append(a)
+    jobs = [(alns[0], weights_file), (alns[1], wf2)]
+    P._ENGINES.clear()
+    alone = [P.aln_to_coords(a, device="cuda:0", iterations=2, minsteps=5, weights_file=w) for a, w in jobs]
+    P._ENGINES.clear()
+    results, errors = [[], []], []
+
+    def worker(k):
+        try:
+            for _ in range(4):
+                results[k].append(P.aln_to_coords(jobs[k][0], device="cuda:0", iterations=2, minsteps=5, weights_file=jobs[k][1]))
+        except Exception as exc:                      # noqa: BLE001
+            errors.append(exc)
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert len(results[k]) == 4
+        for c, f in results[k]:
+            assert torch.equal(c, alone[k][0]) and torch.equal(f, alone[k][1]), k
+    assert len(P._ENGINES.lru[0]) == 2               # one cached engine per weights file: no re-packing in between
+    P._ENGINES.clear()
 
 
 @pytest.mark.parametrize("precision", [0, 1])

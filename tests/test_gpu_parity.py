@@ -760,6 +760,16 @@ def test_float32_vertical_gru_is_the_references_arithmetic(st_engine, synth_sd, 
         eng.set_option("precision", 0)
         assert eng.get_option("precision") == 0 and eng.get_option("conv_mode") == 0
         assert torch.equal(chain(msas[:2], 1)[0], split[0])
+        # precision 2 (round 6): the exact three-piece bf16 convolution WITH the float32 vertical GRU; conv_mode 2 alone (the
+        # range fallback of the fast mode) keeps the split-f16 GRU and reads back as a mixed setting
+        eng.set_option("precision", 2)
+        assert eng.get_option("precision") == 2 and eng.get_option("conv_mode") == 2 and eng.get_option("vgru_f32") == 1
+        assert torch.equal(chain(msas[:2], 1)[0], grouped[0])
+        eng.set_option("precision", 0)
+        eng.set_option("conv_mode", 2)
+        assert eng.get_option("precision") == -1 and eng.get_option("vgru_f32") == 0
+        eng.set_option("precision", 0)
+        assert eng.get_option("precision") == 0 and eng.get_option("conv_mode") == 0 and eng.get_option("vgru_f32") == 0
     finally:
         eng.set_option("precision", 0)
         eng.set_option("vgru_persistent", 1)

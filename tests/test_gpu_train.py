@@ -259,3 +259,29 @@ def test_whole_resnet_backward_stem_blocks_head_vs_reference_autograd(synth_sd):
               "stage: " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     finally:
         st.eng.close()
+
+
+@pytest.mark.parametrize("max_L", [32, 64])
+def test_block_backward_in_a_small_context(synth_sd, max_L):
+    """the bias gradient's first-stage partial sums (128 x 16 x 4 doubles) live in the workspace's norm
+    region, which was sized by the InstanceNorm scratch alone - smaller than those partials for contexts of max_L <= 72, so
+    they ran into the padded input planes behind them and dW of input channel 0 came out wrong, silently.  The whole-block
+    fixture at L = 24 (the reference's autograd through ResNet_Block 3) in contexts created for max_L = 32 and 64."""
+    from abi import Stages
+    g = load_golden("bwd_block3_full_L24")
+    st = Stages(synth_sd, max_L=max_L, max_N=8)
+    blk = int(g["block"])
+    du, dp = st.norm_bwd(blk, st.to(g["u"]), st.to(g["dout"]))
+    dx, dw, db = st.conv_bwd(blk, st.to(g["x"]), du)
+    st.eng.sync_check()
+    close_full(du, g["du"], what="du")
+    close_full(dx + st.to(g["dout"]), g["dx"], what="dx")
+    close_full(db, g["db"], what="db")
+    close_full(dp[0:128], g["dgamma"], what="dgamma")
+    close_sample(dw, g, "dw")
+    # input channel 0's rows of dW are the ones the overflow destroyed: every sampled entry of them, explicitly
+    flat = dw.reshape(512, 128, 25)
+    ch0 = torch.from_numpy(g["dw.idx"][(g["dw.idx"] // 25) % 128 == 0]).to(dw.device)
+    want = g["dw.val"][(g["dw.idx"] // 25) % 128 == 0]
+    if len(want):
+        assert float(np.abs(flat.reshape(-1)[ch0].cpu().numpy() - want).max()) <= 1e-4 * float(np.abs(g["dw.val"]).max())

@@ -142,6 +142,9 @@ assert abs(tmax - max(0.01 * (r + 1) for r in range(world))) < 0.05
 gathered = [None] * world
 dist.all_gather_object(gathered, mine)
 assert sorted(i for p in gathered for i in p) == list(range(23))
+# a rank that broke down (rank 1) and a rank with two failed targets (rank 0): EVERY rank's summary shows both
+t4 = shard.job_summary(done if rank == 0 else 0, elapsed, failures=(2, 0) if rank == 0 else (0, 1))
+assert t4[2] == 2 and t4[3] == 1 and t4[0] == len(gathered[0]), t4
 dist.destroy_process_group()
 print("rank", rank, "ok", len(mine))
 """
@@ -385,7 +388,7 @@ class _FakePipeline:
     results can be compared across shardings.  A target completes two scheduling rounds after its submission."""
     made = 0
 
-    def __init__(self, device, max_L, max_N, state_dict, streams=2, stagger=False):
+    def __init__(self, device, max_L, max_N, state_dict, streams=2, stagger=False, precision=None):
         _FakePipeline.made += 1
         self.jobs, self.max_L, self.max_N = [], max_L, max_N
         self.age, self.ready, self.late, self.max_backlog = {}, {}, {}, 0
@@ -517,7 +520,7 @@ def test_batch_engines_are_sized_for_a_file_without_final_newline(tmp_path, monk
     made = {}
 
     class Sized(_FakePipeline):                          # _FakePipeline.submit refuses what exceeds (max_L, max_N)
-        def __init__(self, device, max_L, max_N, sd, streams=4):
+        def __init__(self, device, max_L, max_N, sd, streams=4, precision=None):
             made["cap"] = (max_L, max_N)
             super().__init__(device, max_L, max_N, sd, streams=streams)
 

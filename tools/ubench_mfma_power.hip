@@ -9,6 +9,9 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// -DUSE_BF16: the same loop on v_mfma_f32_32x32x16_bf16 with bf16 operand data (round 6: the ceiling of the exact
+// three-piece bf16 convolution, conv_bf16.h)
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ ab, int iters, float* __restrict__ out) {
@@ -24,7 +27,11 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ ab, i
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int q = 0; q < 8; ++q)
+#ifdef USE_BF16
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q & 3]), __builtin_bit_cast(bf16x8, b[(q >> 1) & 3]), acc[q], 0, 0, 0);
+#else
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q & 3], b[(q >> 1) & 3], acc[q], 0, 0, 0);
+#endif
   }
   float s = 0.f;
   for (int q = 0; q < 8; ++q)
@@ -49,6 +56,14 @@ int main(int argc, char** argv) {
       _Float16 x = kind[0] == 'z' ? (_Float16)0.f : kind[0] == 's' ? (_Float16)(float)((int)(r * 8)) :
                    kind[7] == 'f' ? (_Float16)(r * 6.f) : (_Float16)(r * 6.f * 0.00048828125f);
       v = __builtin_bit_cast(uint16_t, x);
+#ifdef USE_BF16
+      {
+        const float xf = kind[0] == 'z' ? 0.f : kind[0] == 's' ? (float)((int)(r * 8)) : kind[7] == 'f' ? r * 6.f : r * 6.f * 0.00390625f;
+        unsigned bits = __builtin_bit_cast(unsigned, xf);
+        bits += 0x7FFFu + ((bits >> 16) & 1u);
+        v = (uint16_t)(bits >> 16);
+      }
+#endif
     }
     CK(hipMemcpy(d_ab, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     printf("%-18s %d waves/SIMD: ", kind, waves_per_simd);
