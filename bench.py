@@ -257,6 +257,25 @@ def interval_union(iv):
     return tot
 
 
+def thread_cpu_snapshot():
+    """CPU seconds of every thread of this process: {tid: (name, utime + stime)} from /proc (who burns the host CPU the
+    process reports: the scheduler thread inside the library, or the HIP runtime's own)."""
+    out = {}
+    try:
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open(f"/proc/self/task/{tid}/stat").read()
+                name = raw[raw.index("(") + 1:raw.rindex(")")]
+                f = raw[raw.rindex(")") + 2:].split()
+                out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+            except (OSError, ValueError):
+                pass
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def stub_main(args, rank, world):
     """DMP_BENCH_STUB=1: the launch, barrier and max-over-ranks logic of this file over gloo with a
     stand-in workload (tests/test_host_cpu.py, world_size 2; no GPU)."""
@@ -372,6 +391,8 @@ def main(argv=None):
 
     from dmpfold2_amd import synth, _lib, shard
     from dmpfold2_amd.predict import Pipeline, Engine, encode_aln
+    if os.environ.get("DMP_PY_SCHED") == "1":            # A/B (developer): the round-5 Python scheduler, if the untracked copy is there
+        from dmpfold2_amd._py_sched import Pipeline
     lib = _lib.load()
     if world > 1 and not share_gpu:
         shard.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
@@ -415,16 +436,23 @@ def main(argv=None):
         for e in pipe.engines:
             _lib.check(lib.dmp_profile_enable(e.ctx, 1, cap))
         cpu0 = time.process_time()                       # CPU time of this process, all threads
+        sched0 = pipe.stats()["scheduler_thread_cpu_s"]
+        thr0 = thread_cpu_snapshot()
         t0 = time.perf_counter()
         tickets = []
         for k in range(steps):
             lo = (warmup + k) * B
-            tickets += [pipe.submit(m, ITERS, MINSTEPS) for m in targets[lo:lo + B]]
+            tickets += pipe.submit_many(targets[lo:lo + B], ITERS, MINSTEPS)
             pipe.pump()
         pipe.drain()
         sync_all()
         el = time.perf_counter() - t0
         host_cpu = (time.process_time() - cpu0) / max(1, len(tickets))
+        sched_cpu = (pipe.stats()["scheduler_thread_cpu_s"] - sched0) / max(1, len(tickets))
+        thr1 = thread_cpu_snapshot()
+        by_thread = sorted(((thr1[t][1] - thr0.get(t, (None, 0.0))[1], thr1[t][0], t) for t in thr1), reverse=True)[:5]
+        threads = [{"name": nm, "tid_is_main": tid == os.getpid(), "cpu_s_per_structure": round(c / max(1, len(tickets)), 4)}
+                   for c, nm, tid in by_thread if c > 0]
         timed = [pipe.result(t) for t in tickets]
         # the lane keeps two launches in flight: besides the per-launch duration, measure the time during
         # which at least one launch runs (union of the HIP-event intervals of all engines)
@@ -438,6 +466,7 @@ def main(argv=None):
         pipe.sync_check()
         finite = all(bool(torch.isfinite(c).all()) and bool(torch.isfinite(f).all()) for c, f in warm + timed)
         return {"elapsed": el, "steps": steps, "warmup": warmup, "timed": timed, "finite": finite, "host_cpu": host_cpu,
+                "sched_cpu": sched_cpu, "threads": threads,
                 "cnt": len(iv), "tot": sum(b_ - a_ for a_, b_ in iv), "union": interval_union(iv)}
 
     def roofline_of(name, r):
@@ -502,6 +531,8 @@ def main(argv=None):
                               "value" + sfx: world * args.steps * B / r["elapsed"],
                               "ms_per_step" + sfx: r["elapsed"] / args.steps * 1e3,
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "finite_outputs": r["finite"],
+                              "host_cpu_s_per_structure": r["host_cpu"], "scheduler_thread_cpu_s_per_structure": r["sched_cpu"],
+                              "host_cpu_by_thread": r["threads"],
                               "roofline" + sfx: roofline_of(args.legs, r)}), flush=True)
         if distributed:
             dist.destroy_process_group()
@@ -716,6 +747,10 @@ def main(argv=None):
         # what the scheduler costs the host: CPU time of the whole process (scheduler thread, runtime helper threads)
         # over the timed region per structure
         line["host_cpu_s_per_structure"] = r["host_cpu"]
+        # ... of which the scheduler's own thread inside the library (dmp_pipeline_stats; the rest is the HIP runtime's helper
+        # threads, which spin for as long as kernels are in flight, and this process's main thread)
+        line["scheduler_thread_cpu_s_per_structure"] = r["sched_cpu"]
+        line["host_cpu_by_thread"] = r["threads"]          # the five busiest threads of the process over the timed region
         if host is not None:
             line["host_ms_per_target"] = host
         if single:

@@ -64,9 +64,25 @@ SIGNATURES = {
     "dmp_debug_fetch": (_i64, [_vp, C.c_char_p, _fp, _i64, _vp]),
     "dmp_profile_enable": (_i, [_vp, _i, _i]),
     "dmp_profile_conv_intervals": (_i, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, C.POINTER(_i)]),
+    "dmp_pipeline_create": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
+    "dmp_pipeline_create_on": (_i, [_i, _i, _i, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "dmp_pipeline_destroy": (None, [_vp]),
+    "dmp_pipeline_engines": (_i, [_vp]),
+    "dmp_pipeline_ctx": (_vp, [_vp, _i]),
+    "dmp_pipeline_stream": (_vp, [_vp, _i]),
+    "dmp_pipeline_weights_ready": (_i, [_vp]),
+    "dmp_pipeline_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "dmp_pipeline_submit": (_i64, [_vp, _fp, _i, _i, _fp, _i, _i, _fp, _fp, _vp]),
+    "dmp_pipeline_wait": (_i, [_vp, _i]),
+    "dmp_pipeline_poll": (_i, [_vp, C.POINTER(_i64), _i, C.POINTER(_i)]),
+    "dmp_pipeline_status": (_i, [_vp, _i64, C.POINTER(_i), C.POINTER(_i)]),
+    "dmp_pipeline_release": (_i, [_vp, _i64]),
+    "dmp_pipeline_backlog": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "dmp_pipeline_stats": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
+    "dmp_pipeline_pause": (_i, [_vp, _i]),
 }
 
-ABI_VERSION = 4      # include/dmpfold_hip.h DMP_ABI_VERSION
+ABI_VERSION = 5      # include/dmpfold_hip.h DMP_ABI_VERSION
 
 _lib = None
 

@@ -406,14 +406,17 @@ static int coords_from_mds(dmp_ctx* c, const float* mat1d, const float* mds, int
 // invalid structure can never be mistaken for a result, and a batch can tell WHICH target failed) and
 // the fault bits are latched into the word dmp_sync_faults reports.
 __global__ void fault_latch_kernel(int* __restrict__ words, float* __restrict__ coords,
-                                   float* __restrict__ conf, int L) {
+                                   float* __restrict__ conf, int L, int* __restrict__ report) {
   const int f = words[0];
   if (!f) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const float nan = __builtin_nanf("");
   if (i < 15 * L) coords[i] = nan;
   if (i < L) conf[i] = nan;
-  if (i == 0) atomicOr(&words[1], f);
+  if (i == 0) {
+    atomicOr(&words[1], f);
+    if (report) *report = f;          // the pipeline's per-ticket fault word (pinned host memory)
+  }
 }
 
 }  // namespace dmp
@@ -1321,7 +1324,7 @@ int dmp_predict_end(dmp_ctx* ctx, float* d_coords, float* d_conf, void* stream) 
   rc = ca_to_backbone(c->best_ca, c->best_conf, L, d_coords, d_conf, s);
   if (rc) return rc;
   hipLaunchKernelGGL(fault_latch_kernel, dim3(cdiv(15 * L, 256)), dim3(256), 0, s, c->seq_abort, d_coords,
-                     d_conf, L);
+                     d_conf, L, c->end_fault_out);
   DMP_LAUNCH_CHECK();
   return DMP_OK;
 }

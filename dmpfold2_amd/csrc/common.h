@@ -230,6 +230,8 @@ struct dmp_ctx {
   float* ca_pass = nullptr;    // [P][L][3]
   float* best_ca_snapshot = nullptr;
   int passes_done = 0;
+  int* end_fault_out = nullptr;  // pipeline.hip: device-visible host word that the NEXT dmp_predict_end's latch kernel writes this
+                                 // prediction's fault bits to (per-ticket status without a synchronising copy); not owned
   bool end_refined = false;    // dmp_predict_end_refine already issued for the prediction in flight
   int unit_next = 0;           // next unit of the current pass (0 open, 1..16 blocks, 17 close + MDS + coordinates)
   float *trunk_cur = nullptr, *trunk_oth = nullptr;   // ping-pong activations of the pass in flight

@@ -362,109 +362,77 @@ class Engine:
         return out[:n]
 
 
-# Engine streams are reused from one pipeline of the process to the next: which hardware queues a stream gets depends
-# on how many streams were created before it, and on this runtime the SECOND set of four costs the scheduler 15 %
-# (tools/pipeline_order.py: 5.87 structures/s on pool streams 5-8 against 6.9-7.0 on every other set).
-_STREAM_POOL = {}            # device index -> [[stream, in use]]
+class _PipelineEngine(Engine):
+    """Engine i of a `Pipeline`: a view of the context and stream the C pipeline owns (options, introspection, the
+    repeat of a faulted target on an idle pipeline); closing it does nothing."""
+
+    def __init__(self, lib, device, ctx, stream_ptr, max_L, max_N):       # noqa: super().__init__ creates a context
+        self.lib = lib
+        self.device = device
+        self.max_L, self.max_N = int(max_L), int(max_N)
+        self._ctx = C.c_void_p(ctx)
+        self._stream = torch.cuda.ExternalStream(stream_ptr, device=device)
+        self.weights_tag = None
+        self.last_fallback = False
+
+    def close(self):
+        self._ctx = C.c_void_p()
+
+    def __del__(self):
+        pass
 
 
-def _take_stream(device):
-    pool = _STREAM_POOL.setdefault(device.index, [])
-    for item in pool:
-        if not item[1]:
-            item[1] = True
-            return item[0]
-    with torch.cuda.device(device):
-        st = torch.cuda.Stream(device=device)
-    pool.append([st, True])
-    return st
-
-
-def _release_stream(device, st):
-    for item in _STREAM_POOL.get(device.index, []):
-        if item[0] is st:
-            item[1] = False
+# ticket states of the C pipeline (include/dmpfold_hip.h, DMP_TICKET_*)
+_T_QUEUED, _T_RUNNING, _T_ISSUED, _T_DONE, _T_FAILED = 0, 1, 2, 3, 4
 
 
 class Pipeline:
-    """Throughput mode on one GPU: `streams` engines (each its own context and HIP stream) share a
-    lane, so their machine-filling convolutions take turns while the latency-bound kernels of one
-    target (eigensolver, sequence GRUs, minimiser, the vertical GRU's per-row launches) run under
-    the convolutions of another.
+    """Throughput mode on one GPU: `streams` engines (each its own context and HIP stream) share a lane, so their
+    machine-filling convolutions take turns while the latency-bound kernels of one target (eigensolver, sequence GRUs,
+    minimiser) run under the convolutions of another; targets that start together run their vertical GRUs as one chain.
 
-    One host thread schedules all engines unit by unit (include/dmpfold_hip.h,
-    dmp_predict_issue_unit): light units are enqueued at once, a residual block - whose convolution
-    takes the lane, in issue order - only when everything its engine was given has completed, so
-    the lane is always handed to a convolution that can start immediately and never waits behind
-    an engine that is still in its eigensolver or front end.  Targets are taken from one queue by
-    whichever engine is free."""
+    Round 6: the scheduler lives behind the C ABI (csrc/pipeline.hip, dmp_pipeline_*: one host thread inside the library
+    issues every unit); this class allocates the tensors, keeps them alive, and mirrors the interface the Python scheduler
+    of rounds 1-5 had - submit / pump / drain / result, step / poll / peek for the streaming batch front end, collect for
+    the repeat of faulted targets."""
 
     def __init__(self, device, max_L, max_N, state_dict, streams=2, precision=None):
         self.lib = _lib.load()
         self.device = _resolve_device(device)
-        self.engines = []
-        for _ in range(max(1, int(streams))):
-            st = _take_stream(self.device)
-            eng = Engine(self.device, max_L, max_N, stream=st, precision=precision)
-            if self.engines:
-                eng.share_weights(self.engines[0])       # packed once per pipeline, not once per engine
+        S = max(1, int(streams))
+        self._p = C.c_void_p()
+        max_N = int(min(max_N, MAX_SEQS))
+        with torch.cuda.device(self.device):
+            if os.environ.get("DMP_PIPE_TORCH_STREAMS") == "1":          # the engines on PyTorch pool streams (dmp_pipeline_create_on)
+                self._torch_streams = [torch.cuda.Stream(device=self.device) for _ in range(S)]
+                arr = (C.c_void_p * S)(*[st.cuda_stream for st in self._torch_streams])
+                _lib.check(self.lib.dmp_pipeline_create_on(self.device.index, int(max_L), max_N, S, arr, C.byref(self._p)))
             else:
-                eng.set_weights(state_dict)
-            if streams > 1:
-                if self.engines:
-                    _lib.check(self.lib.dmp_ctx_share_lane(eng.ctx, self.engines[0].ctx))    # one lane for all of them
-                # Several engines: the eigensolver's Householder steps as one launch each, not as the cluster kernel
-                # (same bits).  The cluster is the faster form for ONE prediction (0.9 against 1.9 ms at L = 300), but
-                # its 32 resident workgroups poll beside the other engines' convolutions for that long: measured
-                # 7.39 / 7.32 structures/s with the launches against 7.29 / 7.30 (bench.py, alternating, one box).
-                eng.set_option("tridiag_cluster", 0)
-            self.engines.append(eng)
-        S = len(self.engines)
-        self._pending = []            # (ticket, d_msa, iterations, minsteps)
-        self._slot = [None] * S       # per engine: (ticket, coords, confs) of the prediction in flight
-        self._done = [0] * S          # residual blocks issued / in total for the prediction in flight
-        self._total = [0] * S
-        self._results = {}
-        self._done_ev = {}            # ticket -> event recorded behind dmp_predict_end (poll)
-        self._jobs = {}               # ticket -> job, kept until the result is handed out (retry of faults)
-        self._tickets = 0
-        # An engine issues its first residual block only when the engine that started before it is half a pass
-        # (8 blocks) into its own.  The lane deals the blocks out in turn, so engines that leave their front
-        # ends together would also reach the end of every pass together and sit in their pass tails
-        # (eigensolver, coordinate GRU: 6 ms without a convolution) at the same time; half a pass apart the
-        # tails interleave.  Measured on three boxes, alternating runs: +0.8 .. +1.5 % structures/s for 5-12
-        # blocks against 0 (7.06-7.11 against 7.01; 7.00 against 6.92).  DMP_TAIL_STAGGER overrides (0 = off).
-        self._tail_stagger = int(os.environ.get("DMP_TAIL_STAGGER", "8"))
-        # Group start: predictions that begin together run their vertical GRUs (2001 dependent launches each at the
-        # north-star size) as ONE launch chain that serves the columns of all of them (dmp_predict_group_vgru): four
-        # targets take 52-55 ms in one chain against 110 ms as four chains side by side.  A free engine therefore
-        # waits for the engines that are about to finish (at most DMP_GROUP_PATIENCE residual blocks left) and
-        # starts together with them, up to DMP_VGRU_GROUP members (1 = every prediction runs its own chain).
-        self._group_max = max(1, min(4, int(os.environ.get("DMP_VGRU_GROUP", "4"))))   # engines that start together (the state buffers hold 8 x max_L columns: members + riders)
-        self._group_patience = int(os.environ.get("DMP_GROUP_PATIENCE", "40"))
-        # Riders: a group's chain also serves the NEXT targets in the queue (dmp_predict_group_riders; members + riders
-        # <= 8), whose results are handed over when those targets start (dmp_predict_set_vgru_result): a chain costs
-        # 10.5 us per alignment row whatever it serves (launch boundary, cold L2s), so one chain of eight every second
-        # round replaces two chains of four.  The chain still runs in a front-end phase - beside no convolution.
-        # DMP_VGRU_RIDERS=0 switches it off.
-        self._riders_max = max(0, min(7, int(os.environ.get("DMP_VGRU_RIDERS", "4")))) if S > 1 else 0
-        self._riding = {}             # ticket -> True: a rider whose chain has not been issued to its end yet
-        self._rider_wait = [None] * S  # per leading engine: (jobs, outs) of the riders in the chain it has yet to issue
-        self._ahead = {}              # ticket -> (result tensor (L, 512), event recorded behind the chain it rode in)
+                _lib.check(self.lib.dmp_pipeline_create(self.device.index, int(max_L), max_N, S, C.byref(self._p)))
+        self.engines = [_PipelineEngine(self.lib, self.device, self.lib.dmp_pipeline_ctx(self._p, i),
+                                        self.lib.dmp_pipeline_stream(self._p, i), max_L, max_N) for i in range(S)]
+        self.engines[0].set_weights(state_dict)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dmp_pipeline_weights_ready(self._p), RuntimeError)    # packed once per pipeline
+        prec = precision if precision is not None else _env_precision()
+        if prec is not None:
+            self.set_option("precision", prec)
+        self._jobs = {}               # ticket -> (d_msa, iterations, minsteps, d_tpl, coords, confs, ready event): kept alive
+        self._handed = []             # tickets whose result was handed out before the GPU finished them: released later
 
     def set_option(self, name, value):
-        """An engine option on EVERY engine of the pipeline (a group's vertical-GRU chain runs in its leader's arithmetic
-        and serves all members: the engines must agree on "precision" / "vgru_f32" / "vgru_persistent")."""
-        for e in self.engines:
-            e.set_option(name, value)
+        """An engine option on EVERY engine of the (idle) pipeline: a group's vertical-GRU chain runs in its leader's
+        arithmetic and serves all members, so the engines must agree on "precision" / "vgru_f32" / "vgru_persistent"."""
+        _lib.check(self.lib.dmp_pipeline_set_option(self._p, name.encode(), int(value)))
 
     def close(self):
+        if self._p:
+            self.lib.dmp_pipeline_destroy(self._p)           # joins the scheduler thread, synchronises the streams
+            self._p = C.c_void_p()
         for e in self.engines:
             e.close()
-            if e._stream is not None:
-                _release_stream(self.device, e._stream)
         self.engines = []
-        self._ahead = {}
+        self._jobs = {}
 
     def __del__(self):
         try:
@@ -472,7 +440,7 @@ class Pipeline:
         except Exception:
             pass
 
-    # ---- scheduler ---------------------------------------------------------------------------
+    # ---- submission --------------------------------------------------------------------------
     def submit(self, d_msa, iterations=default_iterations, minsteps=default_minsteps, template_ca=None):
         """Queue one target (uint8 (N, L) tensor on the GPU, optional template CA trace (L, 3));
         returns a ticket for `result`."""
@@ -484,229 +452,122 @@ class Pipeline:
             raise RuntimeError(f"alignment {n} x {L} exceeds the pipeline capacity "
                                f"{self.engines[0].max_N} x {self.engines[0].max_L}")
         d_tpl = None
-        if template_ca is not None:
-            d_tpl = torch.as_tensor(template_ca, dtype=torch.float32).reshape(-1, 3).to(self.device).contiguous()
-            if d_tpl.shape[0] != L:
-                raise RuntimeError(f"Sizes of tensors must match: template has {d_tpl.shape[0]} CA atoms, "
-                                   f"alignment has {L} columns")
-        t = self._tickets
-        self._tickets += 1
-        # the stream that is current NOW produced d_msa (the caller's copy stream, say); the engine that takes the
-        # target later orders itself behind this point, whatever stream is current then
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(self.device))
-        job = (t, d_msa, int(max(iterations, 0)), int(max(minsteps, 0)), d_tpl, ready)
-        self._pending.append(job)
-        self._jobs[t] = job
-        return t
-
-    def _begin_group(self, slots):
-        """Start the next len(slots) queued targets on these free engines; those whose vertical GRU did not ride in an
-        earlier chain form one vertical-GRU group (the first of them leads), and the chain takes the next queued
-        targets along as riders."""
-        grouped = []
-        for s in slots:
-            job = self._pending.pop(0)
-            self._done[s] = 0
-            self._total[s] = (job[2] + 1) * 16
-            self._begin(s, job)
-            ahead = self._ahead.pop(job[0], None)
-            if ahead is not None:
-                out, ev = ahead
-                out.record_stream(self.engines[s]._stream)
-                _lib.check(self.lib.dmp_predict_set_vgru_result(self.engines[s].ctx, out.data_ptr(),
-                                                                C.c_void_p(ev.cuda_event)))
-                self._slot[s] = self._slot[s] + (ahead,)          # keeps the tensor and the event alive
-            else:
-                grouped.append(s)
-        slots = grouped
-        if len(slots) > 1:
-            lead = self.engines[slots[0]]
-            for s in slots[1:]:                       # the leader's stream reads every member's alignment
-                for x in self._slot[s][3]:
-                    if x is not None:
-                        x.record_stream(lead._stream)
-            ctxs = (C.c_void_p * len(slots))(*[self.engines[s].ctx for s in slots])
-            _lib.check(self.lib.dmp_predict_group_vgru(ctxs, len(slots)))
-            if self._riders_max:
-                room = min(self._riders_max, 8 - len(slots))
-                jobs = [j for j in self._pending[:room] if j[0] not in self._ahead and j[0] not in self._riding]
-                if jobs:
-                    k = len(jobs)
-                    with torch.cuda.device(self.device):
-                        outs = [torch.empty((j[1].shape[1], 512), dtype=torch.float32, device=self.device) for j in jobs]
-                    for j, o in zip(jobs, outs):
-                        lead._stream.wait_event(j[5])             # the rider's alignment is ready
-                        j[1].record_stream(lead._stream)
-                        o.record_stream(lead._stream)
-                    mp = (C.c_void_p * k)(*[j[1].data_ptr() for j in jobs])
-                    op = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
-                    Ns = (C.c_int * k)(*[j[1].shape[0] for j in jobs])
-                    Ls = (C.c_int * k)(*[j[1].shape[1] for j in jobs])
-                    _lib.check(self.lib.dmp_predict_group_riders(lead.ctx, k, mp, Ns, Ls, op))
-                    self._rider_wait[slots[0]] = (jobs, outs)
-                    for j in jobs:
-                        self._riding[j[0]] = True
-
-    def _begin(self, s, job):
-        t, d_msa, nloops, minsteps, d_tpl, ready = job
-        e = self.engines[s]
-        cur = torch.cuda.current_stream(self.device)
-        e._stream.wait_stream(cur)
-        e._stream.wait_event(ready)
-        n, L = d_msa.shape
-        # The outputs belong to the caller's stream (drain() orders it after the engine); inputs and
-        # outputs are used on the engine's stream, which the caching allocator has to know before it
-        # recycles their blocks.
         with torch.cuda.device(self.device):
+            if template_ca is not None:
+                d_tpl = torch.as_tensor(template_ca, dtype=torch.float32).reshape(-1, 3).to(self.device).contiguous()
+                if d_tpl.shape[0] != L:
+                    raise RuntimeError(f"Sizes of tensors must match: template has {d_tpl.shape[0]} CA atoms, "
+                                       f"alignment has {L} columns")
             coords = torch.empty((L, 5, 3), dtype=torch.float32, device=self.device)
             confs = torch.empty((L,), dtype=torch.float32, device=self.device)
-        for x in (coords, confs, d_msa, d_tpl):
-            if x is not None:
-                x.record_stream(e._stream)
-        _lib.check(self.lib.dmp_predict_begin_units(
-            e.ctx, d_msa.data_ptr(), n, L, d_tpl.data_ptr() if d_tpl is not None else None,
-            L if d_tpl is not None else 0, nloops, minsteps))
-        self._slot[s] = (t, coords, confs, (d_msa, d_tpl))
+            # the stream that is current NOW produced d_msa (the caller's copy stream, say); the engine that takes the
+            # target orders itself behind this point
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+        # Inputs and outputs are used on the stream of whichever engine takes the target (and, as a rider, on a group
+        # leader's): the caching allocator has to know before it recycles their blocks.
+        for e in self.engines:
+            for x in (coords, confs, d_msa, d_tpl):
+                if x is not None:
+                    x.record_stream(e._stream)
+        t = _lib.check(self.lib.dmp_pipeline_submit(
+            self._p, d_msa.data_ptr(), n, L, d_tpl.data_ptr() if d_tpl is not None else None,
+            int(max(iterations, 0)), int(max(minsteps, 0)), coords.data_ptr(), confs.data_ptr(),
+            C.c_void_p(ready.cuda_event)))
+        self._jobs[t] = (d_msa, int(max(iterations, 0)), int(max(minsteps, 0)), d_tpl, coords, confs, ready)
+        self._reap()
+        return t
 
-    def _pump(self):
-        """One scheduling round over the engines; True if anything was enqueued."""
-        lib = self.lib
-        gated = len(self.engines) > 1
-        progressed = False
-        # engines whose next unit is a residual block: when there is only one, nobody else can use the
-        # lane, so it may queue its next block behind the running one instead of draining first
-        n_conv = sum(1 for s, e in enumerate(self.engines)
-                     if self._slot[s] is not None and lib.dmp_predict_next_unit(e.ctx) == 2) if gated else 0
-        free = [s for s in range(len(self.engines)) if self._slot[s] is None]
-        startable = free[:len(self._pending)]
-        if self._riding and any(j[0] in self._riding for j in self._pending[:len(startable)]):
-            startable = []            # the chain these targets ride in has not been issued to its end yet
-        if startable:
-            # engines about to finish: wait for them and start together (one vertical-GRU chain for the group)
-            soon = [r for r in range(len(self.engines)) if self._slot[r] is not None
-                    and self._total[r] - self._done[r] <= self._group_patience]
-            soon_with_work = min(len(self._pending) - len(startable), len(soon))
-            want = min(self._group_max, len(startable) + soon_with_work)
-            if len(startable) >= want or not soon_with_work or self._group_max == 1:
-                if self._group_max == 1:
-                    for s in startable:
-                        self._begin_group([s])
-                else:
-                    self._begin_group(startable[:max(want, 1)])
-                progressed = True
-        for s, e in enumerate(self.engines):
-            if self._slot[s] is None:
-                continue
-            while True:
-                kind = lib.dmp_predict_next_unit(e.ctx)
-                if kind == 3:                         # waits for its group leader's vertical-GRU chain
-                    break
-                if kind == 0:
-                    # final refinement + backbone; neither needs the lane
-                    t, coords, confs = self._slot[s][:3]
-                    _lib.check(lib.dmp_predict_end(e.ctx, coords.data_ptr(), confs.data_ptr(), e.stream()))
-                    self._results[t] = (coords, confs)
-                    ev = torch.cuda.Event()
-                    ev.record(e._stream)
-                    self._done_ev[t] = ev
-                    self._slot[s] = None
-                    progressed = True
-                    break
-                if self._tail_stagger and kind == 2 and self._done[s] == 0:
-                    older = [r for r in range(len(self.engines)) if r != s and self._slot[r] is not None
-                             and self._slot[r][0] < self._slot[s][0]]
-                    if older:
-                        prev = max(older, key=lambda r: self._slot[r][0])
-                        # only behind an engine that is in (or at the door of) its trunk passes: one that is
-                        # still in its front end must not hold the lane back
-                        in_trunk = self._done[prev] > 0 or lib.dmp_predict_next_unit(self.engines[prev].ctx) == 2
-                        if in_trunk and self._done[prev] < min(self._tail_stagger, self._total[prev]):
-                            break
-                if gated:
-                    # a convolution is handed the lane only when it can start at once; light units
-                    # are kept one deep so this loop returns to the other engines quickly
-                    busy = _lib.check(lib.dmp_ctx_pending(e.ctx))
-                    if busy > (0 if (kind == 2 and n_conv > 1) else 1):
-                        break
-                _lib.check(lib.dmp_predict_issue_unit(e.ctx, e.stream()))
-                progressed = True
-                if self._rider_wait[s] is not None and e.get_option("chain_issued"):
-                    # the riders' results are behind this point of the leader's stream
-                    jobs, outs = self._rider_wait[s]
-                    self._rider_wait[s] = None
-                    ev = torch.cuda.Event()
-                    ev.record(e._stream)
-                    for j, o in zip(jobs, outs):
-                        self._ahead[j[0]] = (o, ev)
-                        self._riding.pop(j[0], None)
-                if kind == 2:
-                    self._done[s] += 1
-                if gated:
-                    break
-        return progressed
+    def _status(self, ticket):
+        st, bits = C.c_int(0), C.c_int(0)
+        rc = self.lib.dmp_pipeline_status(self._p, ticket, C.byref(st), C.byref(bits))
+        return st.value, bits.value, rc
 
-    def _idle(self):
-        """Nothing could be issued: every engine waits for the GPU (or for an engine that does).  Rounds 1-3 spun on
-        sched_yield here - one core per GPU at 100 %.  Now the thread sleeps.  "Until the oldest outstanding unit of an
-        engine has completed" was tried first (blocking-sync events) and lost a fifth of the throughput: units complete
-        out of order across the engines, and a thread blocked on one engine's 40 ms vertical-GRU chain serves nobody.
-        A bounded 20 us sleep per idle round instead (round 3 measured: costs the throughput nothing; 100 us: 1.3 %).
-        The lane keeps two convolutions queued, so the wake-up latency never leaves it empty."""
-        time.sleep(2e-5)
+    def _reap(self):
+        keep = []
+        for t in self._handed:
+            st, _, _ = self._status(t)
+            if st in (_T_DONE, _T_FAILED):
+                self.lib.dmp_pipeline_release(self._p, t)
+            else:
+                keep.append(t)
+        self._handed = keep
+
+    def _raise_failed(self):
+        """A target whose units could not be issued (a HIP or capacity error inside the scheduler) fails its ticket; the
+        Python scheduler of rounds 1-5 raised from pump() / drain() at that point, and so does this."""
+        for t in list(self._jobs):
+            st, _, rc = self._status(t)
+            if st == _T_FAILED:
+                _lib.check(rc if rc < 0 else -5)
 
     def pump(self):
-        """Schedule until every queued target has been started on an engine."""
-        with torch.cuda.device(self.device):          # launches and graph builds need the current device
-            while self._pending:
-                if not self._pump():
-                    self._idle()
+        """Block until every queued target has been started on an engine."""
+        _lib.check(self.lib.dmp_pipeline_wait(self._p, 0))
+        self._raise_failed()
 
     def drain(self):
-        """Schedule until every queued target is fully enqueued; the current stream then waits for
-        the engines' streams (nothing is synchronised with the host)."""
-        with torch.cuda.device(self.device):
-            while self._pending or any(x is not None for x in self._slot):
-                if not self._pump():
-                    self._idle()
+        """Block until every queued target is fully enqueued; the current stream then waits for
+        the engines' streams (the host is not synchronised with the GPU)."""
+        _lib.check(self.lib.dmp_pipeline_wait(self._p, 1))
         cur = torch.cuda.current_stream(self.device)
         for e in self.engines:
             cur.wait_stream(e._stream)
+        self._raise_failed()
 
     def result(self, ticket):
-        self._jobs.pop(ticket, None)
-        self._done_ev.pop(ticket, None)
-        return self._results.pop(ticket)
+        job = self._jobs.pop(ticket)
+        self._handed.append(ticket)
+        self._reap()
+        return job[4], job[5]
 
     # ---- streaming use (dmpfold2_amd.batch): submit / step / poll, no barrier between targets ----------------
     def step(self, rounds=32):
-        """Up to `rounds` scheduling rounds (fewer when a round finds nothing to issue: the core is yielded and the
-        call returns, so that the caller can do a piece of host work while the GPU is busy).  True if the LAST round
-        enqueued something - i.e. the scheduler may have more to issue right away."""
-        with torch.cuda.device(self.device):
-            for _ in range(max(1, int(rounds))):
-                if not self._pump():
-                    self._idle()
-                    return False
-        return True
+        """The scheduler runs in its own thread inside the library: there is nothing to step.  Yields the core for a moment
+        (the caller's loop does a piece of host work per call) and answers False - "nothing more for you to issue"."""
+        time.sleep(2e-4)
+        return False
 
     def backlog(self):
         """Targets queued but not yet started on an engine."""
-        return len(self._pending)
+        q, r = C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.dmp_pipeline_backlog(self._p, C.byref(q), C.byref(r)))
+        return q.value
 
     def busy(self):
-        return bool(self._pending) or any(x is not None for x in self._slot)
+        q, r = C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.dmp_pipeline_backlog(self._p, C.byref(q), C.byref(r)))
+        return q.value > 0 or r.value > 0
 
     def poll(self):
         """Tickets whose prediction has COMPLETED on the GPU since the last call (their tensors may be read from
         any stream); `peek` / `result` hand the tensors out."""
-        done = [t for t, ev in self._done_ev.items() if ev.query()]
-        for t in done:
-            del self._done_ev[t]
-        return done
+        buf, n = (C.c_int64 * 64)(), C.c_int(0)
+        out = []
+        while True:
+            _lib.check(self.lib.dmp_pipeline_poll(self._p, buf, 64, C.byref(n)))
+            out += [buf[i] for i in range(n.value)]
+            if n.value < 64:
+                return out
 
     def peek(self, ticket):
-        return self._results[ticket]
+        job = self._jobs[ticket]
+        return job[4], job[5]
+
+    def stats(self):
+        v = (C.c_longlong * 8)()
+        _lib.check(self.lib.dmp_pipeline_stats(self._p, v, 8))
+        return {"groups": v[0], "max_group": v[1], "rider_chains": v[2], "max_riders": v[3], "riders_left": v[4],
+                "idle_rounds": v[5], "rounds": v[6], "scheduler_thread_cpu_s": v[7] * 1e-6}
+
+    def submit_many(self, d_msas, iterations=default_iterations, minsteps=default_minsteps):
+        """Submit a batch with the scheduler paused, so that the first vertical-GRU group is formed from the whole batch
+        (the scheduler's thread would otherwise start whatever has arrived when it looks)."""
+        _lib.check(self.lib.dmp_pipeline_pause(self._p, 1))
+        try:
+            return [self.submit(m, iterations, minsteps) for m in d_msas]
+        finally:
+            _lib.check(self.lib.dmp_pipeline_pause(self._p, 0))
 
     def collect(self, tickets):
         """drain + synchronise + verify.  Returns {ticket: (coords, confs) or Exception}: a target
@@ -716,19 +577,25 @@ class Pipeline:
         costs the others their results.  Once one repeat needed the range-free convolution the
         remaining repeats run in it directly (the weights, not the alignment, put a trunk outside the
         f16 range: the others would only fault again first), with one note on stderr for all of them."""
-        self.drain()
-        bits = 0
+        _lib.check(self.lib.dmp_pipeline_wait(self._p, 2))
+        cur = torch.cuda.current_stream(self.device)
         for e in self.engines:
-            bits |= e.sync_faults()
+            cur.wait_stream(e._stream)
+        for e in self.engines:
+            e.sync_faults()                     # the engines' latched words: cleared, the per-ticket words below decide
         out = {}
         eng = self.engines[0]
         mode0 = eng.get_option("conv_mode")
         try:
             for t in tickets:
+                st, bits, rc = self._status(t)
                 job = self._jobs.get(t)
                 coords, confs = self.result(t)
-                if bits and bool(torch.isnan(confs[0])):
-                    _, d_msa, nloops, minsteps, d_tpl = job[:5]
+                if st == _T_FAILED:
+                    out[t] = _lib.DmpError(_lib.load().dmp_last_error().decode("utf-8", "replace") or f"error {rc}")
+                    continue
+                if bits:
+                    d_msa, nloops, minsteps, d_tpl = job[:4]
                     try:
                         coords, confs = eng.predict_device_checked(d_msa, d_tpl, nloops, minsteps)
                         if eng.last_fallback:
@@ -737,8 +604,7 @@ class Pipeline:
                             # the repeat fell back to one vertical-GRU launch per row (another process holds CUs of
                             # this GPU): the other engines - and a group chain led by one of them - would only
                             # fault again, target after target
-                            for other in self.engines:
-                                other.set_option("vgru_persistent", 0)
+                            self.set_option("vgru_persistent", 0)
                     except (IndexError, _lib.DmpError) as exc:
                         out[t] = exc
                         continue
@@ -750,7 +616,7 @@ class Pipeline:
     def run(self, d_msas, iterations=default_iterations, minsteps=default_minsteps):
         """Predict every target (uint8 (N, L) tensors on the GPU).  Returns [(coords, confs)] in
         input order, ordered on the current stream; the host is not synchronised with the tail."""
-        tickets = [self.submit(m, iterations, minsteps) for m in d_msas]
+        tickets = self.submit_many(d_msas, iterations, minsteps)
         self.drain()
         return [self.result(t) for t in tickets]
 

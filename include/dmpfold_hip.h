@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-/* 4 (round 5): 49 functions.  New: dmp_block_conv5x5_maxout_winners (the training slice's forward: maxout output + the
+/* 5 (round 6): 65 functions.  New: the dmp_pipeline_* family (16 functions) - the throughput scheduler behind the C ABI;
+ *    option "precision" accepts 2 (exact three-piece bf16 convolution + float32 vertical GRU: full-width operands at the
+ *    16-bit matrix cores' rate).
+ * 4 (round 5): 49 functions.  New: dmp_block_conv5x5_maxout_winners (the training slice's forward: maxout output + the
  *    winners autograd saves), dmp_head_conv_bwd, dmp_stem_maxout_winners and dmp_stem_bwd; dmp_block_conv5x5_maxout_bwd takes the saved winners (d_idx, NULL = run
  *    the forward again: the ABI-3 behaviour).  New options: precision (0 split-f16 / 1 the reference's float32 end to end),
  *    vgru_f32, gj_diag_blocked.
@@ -38,7 +41,7 @@ extern "C" {
  *    holds every launch's interval; the three lane functions became dmp_ctx_share_lane.  Options vgru_legacy and gj_lds are gone;
  *    act_scaling and vgru_persistent are new; fault bit DMP_FAULT_VGRU_HANDOFF is new.
  * 2: dmp_sync_faults clears what it reports, dmp_ctx_get_option and dmp_dca_features added. */
-#define DMP_ABI_VERSION 4
+#define DMP_ABI_VERSION 5
 #define DMP_MAX_SEQS 3000 /* predict.py:130-132: deeper MSAs are truncated */
 
 typedef struct dmp_ctx dmp_ctx;
@@ -88,11 +91,15 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  *   1            the f32 matrix-core instruction (bitwise an fmaf chain);
  *   2            exact 3-way bf16 split, 6 bf16 MFMA products (no range limit, 2.7x the f32 rate).
  * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default).
- * "precision" = 0 / 1 (round 5) is the end-to-end switch: 0 = the default above (split-f16 products in the convolutions
- * AND in the vertical GRU, whose gates use the hardware v_exp_f32 / v_rcp_f32); 1 = the reference's arithmetic
- * throughout - conv_mode 1 and the float32 vertical GRU (v_mfma_f32_16x16x4_f32 products, the device library's
- * expf / tanhf in the gates: nn.GRU in float32, network.py:189, 223-224); with it no f16 / bf16 matrix-core kernel runs.
- * Reads back 1 / 0, or -1 for a mixed setting.
+ * "precision" = 0 / 1 / 2 is the end-to-end switch: 0 = a context's initial setting, the FAST mode (split-f16 products
+ * of 22-23-bit operands in the convolutions AND in the vertical GRU, whose gates use the hardware v_exp_f32 / v_rcp_f32);
+ * 1 = the reference's arithmetic instruction for instruction - conv_mode 1 and the float32 vertical GRU
+ * (v_mfma_f32_16x16x4_f32 products, the device library's expf / tanhf in the gates: nn.GRU in float32, network.py:189,
+ * 223-224); with it no f16 / bf16 matrix-core kernel runs; 2 (round 6) = FULL-WIDTH operands at the 16-bit matrix cores'
+ * rate - conv_mode 2 (every float32 operand as three exact bf16 pieces = 24 significand bits, the six piece products
+ * above 2^-24 accumulated in float32) and the float32 vertical GRU of setting 1: the setting the drop-in entry points
+ * (aln_to_coords, the CLI, the batch front end) default to, 1.7 x the speed of setting 1.
+ * Reads back 0 / 1 / 2, or -1 for a mixed setting.
  * "vgru_f32" = -1 / 0 / 1: the vertical GRU alone; -1 (default) follows the convolution (float32 exactly when
  * conv_mode is 1, so "conv_mode" 1 and "precision" 1 select the same thing), 0 / 1 force the split-f16 / the float32
  * form whatever the convolution does.  Reads back what the next prediction will run (0 / 1).  The float32 form costs
@@ -373,6 +380,65 @@ int dmp_ctx_pending(dmp_ctx* ctx);
  * lives as long as a context refers to it); other = NULL detaches.  All contexts of a lane must be driven by the same
  * host thread. */
 int dmp_ctx_share_lane(dmp_ctx* ctx, dmp_ctx* other);
+
+/* ---- throughput mode behind the C ABI (ABI 5, round 6) ------------------------------------------------------------
+ * The batch form of the reference's one call per alignment (predict.py:74-158): N independent alignments through one
+ * GPU.  A pipeline owns `engines` contexts (1..8; 4 is the measured optimum on one MI355X), each on a HIP stream of its
+ * own, sharing one lane, and ONE host thread inside the library that schedules all of them unit by unit
+ * (csrc/pipeline.hip: the units above, the lane, group start of the vertical GRUs, riders, tail stagger - nothing of
+ * the issue loop runs in the caller's language).  Use:
+ *   dmp_pipeline_create(device, max_L, max_N, 4, &p);
+ *   dmp_weights_set(dmp_pipeline_ctx(p, 0), ...) x 184; dmp_weights_finalize(dmp_pipeline_ctx(p, 0));
+ *   dmp_pipeline_weights_ready(p);                       (the other engines share that ONE packed copy)
+ *   dmp_pipeline_set_option(p, "precision", 2);          (any option of dmp_ctx_set_option, on every engine; idle pipeline only)
+ *   t = dmp_pipeline_submit(p, d_msa, N, L, d_template_ca | NULL, iterations, minsteps, d_coords, d_conf, ready_event | NULL);
+ *   ... dmp_pipeline_poll(p, tickets, cap, &n) / dmp_pipeline_wait(p, 2) ... dmp_pipeline_status(p, t, &state, &fault_bits);
+ *   dmp_pipeline_release(p, t);  dmp_pipeline_destroy(p);
+ * Ownership: every buffer is the caller's (device memory; d_coords L x 5 x 3, d_conf L) and must stay valid until the
+ * ticket is DMP_TICKET_DONE or DMP_TICKET_FAILED.  `ready_event` (hipEvent_t or NULL): recorded by the caller behind
+ * whatever produces d_msa / d_template_ca; the engine that takes the target orders its stream behind it.  submit returns
+ * the ticket (>= 0) or a negative dmp_status; it never blocks on the GPU and may be called from any thread.
+ * dmp_pipeline_wait(p, what): block until every submitted target has 0 = been started on an engine, 1 = been issued to
+ * its end (the engines' streams then hold all the work: dmp_pipeline_stream(p, i) can be waited for on another stream),
+ * 2 = completed on the GPU.  dmp_pipeline_poll: tickets that completed (or failed) since the last call, each once.
+ * dmp_pipeline_status: *h_state = DMP_TICKET_*; for a DONE ticket *h_fault_bits = the DMP_FAULT_* bits recorded during
+ * THAT prediction (non-zero: its outputs are NaN; the caller repeats it, e.g. alone through dmp_predict with
+ * "vgru_persistent" 0 or "conv_mode" 2 as the bit suggests); a FAILED ticket (a HIP / capacity error while it was being
+ * issued) returns that error.  dmp_pipeline_release forgets a finished ticket (its event and fault word are reused).
+ * Scheduler knobs are read from the environment at creation (DMP_VGRU_GROUP, DMP_VGRU_RIDERS, DMP_GROUP_PATIENCE,
+ * DMP_TAIL_STAGGER: DESIGN.md section 6); results are bit-identical to dmp_predict on a lone context with
+ * "tridiag_cluster" = 0, whatever the grouping. */
+typedef struct dmp_pipeline dmp_pipeline;
+#define DMP_TICKET_QUEUED 0
+#define DMP_TICKET_RUNNING 1
+#define DMP_TICKET_ISSUED 2
+#define DMP_TICKET_DONE 3
+#define DMP_TICKET_FAILED 4
+int dmp_pipeline_create(int device, int max_L, int max_N, int engines, dmp_pipeline** out);
+/* the same on `engines` streams of the caller's (hipStream_t[engines], non-blocking streams, used by nothing else while the
+ * pipeline lives; not destroyed with it) - a host whose memory allocator tracks streams (PyTorch) passes its own */
+int dmp_pipeline_create_on(int device, int max_L, int max_N, int engines, void* const* streams, dmp_pipeline** out);
+void dmp_pipeline_destroy(dmp_pipeline* p);
+int dmp_pipeline_engines(const dmp_pipeline* p);
+dmp_ctx* dmp_pipeline_ctx(dmp_pipeline* p, int i);
+void* dmp_pipeline_stream(dmp_pipeline* p, int i);
+int dmp_pipeline_weights_ready(dmp_pipeline* p);
+int dmp_pipeline_set_option(dmp_pipeline* p, const char* name, int value);
+int64_t dmp_pipeline_submit(dmp_pipeline* p, const uint8_t* d_msa, int N, int L, const float* d_template_ca, int nloops,
+                            int refine_steps, float* d_coords, float* d_conf, void* ready_event);
+int dmp_pipeline_wait(dmp_pipeline* p, int what);
+int dmp_pipeline_poll(dmp_pipeline* p, int64_t* h_tickets, int capacity, int* h_n);
+int dmp_pipeline_status(dmp_pipeline* p, int64_t ticket, int* h_state, int* h_fault_bits);
+int dmp_pipeline_release(dmp_pipeline* p, int64_t ticket);
+int dmp_pipeline_backlog(dmp_pipeline* p, int* h_queued, int* h_running);
+/* dmp_pipeline_pause(p, 1): no NEW target is started until (p, 0) - a caller that submits a batch in a loop pauses around
+ * it so that the first vertical-GRU group is formed from the whole batch and not from whatever had arrived when the
+ * scheduler looked (results do not depend on it, the first chain's width does). */
+int dmp_pipeline_pause(dmp_pipeline* p, int on);
+/* counters since creation: [0] vertical-GRU groups formed, [1] largest group, [2] chains that carried riders, [3] most
+ * riders in one chain, [4] rider results not yet consumed (0 on an idle pipeline), [5] scheduling rounds that found nothing
+ * to issue, [6] scheduling rounds, [7] CPU microseconds of the scheduler thread */
+int dmp_pipeline_stats(dmp_pipeline* p, long long* h_stats, int capacity);
 
 /* Synchronise `stream` and report the device-side faults recorded since the last report
  * (DMP_FAULT_* bits in *h_bits; 0 = every result handed out since then is valid).  Reporting clears

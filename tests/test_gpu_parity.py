@@ -616,28 +616,16 @@ def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(synth_sd, monkeypatch
         e.set_option("precision", precision)
     assert pipe.engines[0].get_option("vgru_f32") == precision
     assert pipe.engines[0].get_option("vgru_persistent") == persistent        # a 256-CU device has the persistent form
-    assert pipe._group_max == group and pipe._riders_max == riders
-    rode = []
-    if riders and group > 1:
-        pipe_lib = pipe.lib                               # count the chains that carried riders
-
-        class Counting:
-            def __getattr__(self, name):
-                fn = getattr(pipe_lib, name)
-                if name != "dmp_predict_group_riders":
-                    return fn
-
-                def counted(*a):
-                    rode.append(a[1])
-                    return fn(*a)
-                return counted
-        pipe.lib = Counting()
     msas = msas + msas[:5]                       # more targets than engines
-    tickets = [pipe.submit(torch.from_numpy(m).to(dev), 1, 3) for m in msas]
+    tickets = pipe.submit_many([torch.from_numpy(m).to(dev) for m in msas], 1, 3)
     pipe.drain()
     pipe.sync_check()
+    stats = pipe.stats()                        # the C scheduler's counters (dmp_pipeline_stats)
+    assert stats["max_group"] == (group if group > 1 else 0), stats
     if riders and group > 1:
-        assert rode and max(rode) == min(riders, 8 - group) and not pipe._riding and not pipe._ahead
+        assert stats["rider_chains"] > 0 and stats["max_riders"] == min(riders, 8 - group) and stats["riders_left"] == 0, stats
+    else:
+        assert stats["rider_chains"] == 0, stats
     try:
         for m, t in zip(msas, tickets):
             coords, confs = pipe.result(t)
@@ -1056,3 +1044,80 @@ def test_cluster_kernels_agree_with_and_without_the_xcd_local_handoff(synth_sd):
             assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
     finally:
         eng.close()
+
+
+def test_c_abi_pipeline_submit_poll_status_release(synth_sd):
+    """The throughput scheduler through the C ABI alone (dmp_pipeline_*, what INTEGRATION.md section 3 binds): weights set
+    on engine 0 and shared, nine ragged targets submitted with caller-owned buffers, polled to completion without
+    touching the scheduler, every ticket DONE with a clean fault word and bit-identical to dmp_predict on a lone context;
+    argument errors answer at once; released tickets are forgotten."""
+    import ctypes as C
+    import time
+    from dmpfold2_amd import _lib, synth
+    from dmpfold2_amd.predict import Engine, encode_aln
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    p = C.c_void_p()
+    _lib.check(lib.dmp_pipeline_create(0, 128, 512, 4, C.byref(p)))
+    try:
+        assert lib.dmp_pipeline_engines(p) == 4
+        ctx0 = C.c_void_p(lib.dmp_pipeline_ctx(p, 0))
+        # before the weights: submit refuses
+        z = torch.zeros((4, 16), dtype=torch.uint8, device=dev)
+        o1, o2 = torch.empty(16 * 15, device=dev), torch.empty(16, device=dev)
+        assert lib.dmp_pipeline_submit(p, z.data_ptr(), 4, 16, None, 0, 0, o1.data_ptr(), o2.data_ptr(), None) < 0
+        for key, val in synth_sd.items():
+            arr = np.ascontiguousarray(val, dtype=np.float32)
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _lib.check(lib.dmp_weights_set(ctx0, key.encode(), arr.ctypes.data, shape, arr.ndim))
+        _lib.check(lib.dmp_weights_finalize(ctx0))
+        _lib.check(lib.dmp_pipeline_weights_ready(p))
+        _lib.check(lib.dmp_pipeline_set_option(p, b"precision", 2))
+        v = C.c_int(0)
+        for i in range(4):
+            _lib.check(lib.dmp_ctx_get_option(C.c_void_p(lib.dmp_pipeline_ctx(p, i)), b"precision", C.byref(v)))
+            assert v.value == 2
+        assert lib.dmp_pipeline_set_option(p, b"no_such_option", 1) < 0
+        # capacity and argument errors answer at once
+        big = torch.zeros((4, 200), dtype=torch.uint8, device=dev)
+        assert lib.dmp_pipeline_submit(p, big.data_ptr(), 4, 200, None, 0, 0, o1.data_ptr(), o2.data_ptr(), None) == -4
+        assert lib.dmp_pipeline_submit(p, z.data_ptr(), 4, 7, None, 0, 0, o1.data_ptr(), o2.data_ptr(), None) == -1
+        shapes = [(82, 200), (33, 64), (128, 300), (40, 1), (64, 257), (96, 31), (120, 129), (50, 64), (128, 17)]
+        msas = [torch.from_numpy(encode_aln(synth.synth_msa(L, N, 90 + i))).to(dev) for i, (L, N) in enumerate(shapes)]
+        outs = [(torch.empty((m.shape[1], 5, 3), device=dev), torch.empty((m.shape[1],), device=dev)) for m in msas]
+        torch.cuda.synchronize()
+        tickets = [lib.dmp_pipeline_submit(p, m.data_ptr(), m.shape[0], m.shape[1], None, 2, 5, c.data_ptr(), f.data_ptr(), None)
+                   for m, (c, f) in zip(msas, outs)]
+        assert tickets == list(range(9))
+        done, buf, n = [], (C.c_int64 * 4)(), C.c_int(0)
+        t0 = time.time()
+        while len(done) < 9 and time.time() - t0 < 120:
+            _lib.check(lib.dmp_pipeline_poll(p, buf, 4, C.byref(n)))
+            done += [buf[i] for i in range(n.value)]
+            time.sleep(0.001)
+        assert sorted(done) == tickets                      # each exactly once
+        q, r = C.c_int(1), C.c_int(1)
+        _lib.check(lib.dmp_pipeline_backlog(p, C.byref(q), C.byref(r)))
+        assert q.value == 0 and r.value == 0
+        single = Engine(dev, 128, 512)
+        single.set_weights(synth_sd)
+        single.set_option("precision", 2)
+        single.set_option("tridiag_cluster", 0)
+        try:
+            st, bits = C.c_int(0), C.c_int(0)
+            for t, m, (c, f) in zip(tickets, msas, outs):
+                _lib.check(lib.dmp_pipeline_status(p, t, C.byref(st), C.byref(bits)))
+                assert st.value == 3 and bits.value == 0
+                rc_, rf_ = single.predict_device(m, None, 2, 5)
+                single.sync_check()
+                assert torch.equal(c, rc_) and torch.equal(f, rf_), tuple(m.shape)
+                _lib.check(lib.dmp_pipeline_release(p, t))
+                assert lib.dmp_pipeline_status(p, t, C.byref(st), C.byref(bits)) < 0        # forgotten
+        finally:
+            single.close()
+        _lib.check(lib.dmp_pipeline_wait(p, 2))             # nothing outstanding: returns at once
+        stats = (C.c_longlong * 6)()
+        _lib.check(lib.dmp_pipeline_stats(p, stats, 6))
+        assert stats[0] >= 1 and 2 <= stats[1] <= 4 and stats[4] == 0
+    finally:
+        lib.dmp_pipeline_destroy(p)

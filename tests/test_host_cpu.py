@@ -18,14 +18,14 @@ from dmpfold2_amd import _lib, predict, shard, synth
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "dmpfold_hip.h")).read()
     declared = set(re.findall(r"\b(dmp_[a-z0-9_]+)\s*\(", header))
-    declared -= {"dmp_ctx", "dmp_lane", "dmp_status"}
-    assert 35 <= len(declared) <= 49                     # 45 after the round-4 prune + the training slice's forward-with-winners and head backward (round 5)
+    declared -= {"dmp_ctx", "dmp_lane", "dmp_status", "dmp_pipeline"}
+    assert len(declared) == 65                           # 49 of round 5 + the 16 dmp_pipeline_* entry points (round 6, ABI 5)
     lib = C.CDLL(_lib.LIB_PATH)
     missing = [name for name in sorted(declared) if not hasattr(lib, name)]
     assert not missing, missing
     # the ctypes binding covers the same set
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().dmp_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().dmp_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_residue_encoding_all_bytes():

@@ -3,5 +3,5 @@
 # waited on an empty argument once cost a whole GPU call); outputs under gpurun_out/job/.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/job; mkdir -p $OUT
-timeout 900 bash tools/pmc_conv.sh 2 300 m2 > $OUT/pmc_m2.txt 2>&1; tail -22 $OUT/pmc_m2.txt
 timeout 2400 python -m pytest tests -q -m gpu > $OUT/all.log 2>&1; tail -25 $OUT/all.log
+timeout 1500 python bench.py --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json; tail -5 $OUT/bench.err
