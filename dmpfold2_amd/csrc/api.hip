@@ -491,7 +491,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
   A_(xb, (int64_t)CW * P * P);
   A_(xdense, (int64_t)CW * LL);
   A_(xsplit, (int64_t)3 * CW * P * P);
-  A_(part, std::max<int64_t>(T * T, 8) * CW * 2);
+  A_(part, std::max<int64_t>(2 * T * T, 8) * CW * 2);
   A_(stats, CW * 2);
   A_(ab, CW * 2);
   A_(head0, LL);
@@ -547,6 +547,7 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "gj_lookahead") { DMP_ARG(value >= 0 && value <= 2, "gj_lookahead must be 0, 1 or 2"); ctx->gj_lookahead = value; return DMP_OK; }
   if (k == "gj_diag_groups") { DMP_ARG(value == 2 || value == 4 || value == 8, "gj_diag_groups must be 2, 4 or 8"); ctx->gj_diag_groups = value; return DMP_OK; }
   if (k == "act_scaling") { ctx->act_scaling = value ? 1 : 0; return DMP_OK; }
+  if (k == "conv_tile_bands") { DMP_ARG(value >= 0 && value <= 2, "conv_tile_bands must be 0 (by length), 1 (16 x 16) or 2 (8 x 16)"); ctx->conv_tile_bands = value; return DMP_OK; }
   if (k == "vgru_persistent") { ctx->vgru_persist = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_debug_drop_wg") { ctx->vgru_debug_drop_wg = value ? 1 : 0; return DMP_OK; }     // tests only
   if (k == "vgru_f32") { DMP_ARG(value >= -1 && value <= 1, "vgru_f32 must be -1 (follow conv_mode), 0 or 1"); ctx->vgru_f32 = value; return DMP_OK; }
@@ -576,6 +577,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "conv_mode") { *h_value = ctx->conv_mode; return DMP_OK; }
   if (k == "conv_f32_exact") { *h_value = ctx->conv_mode == 1; return DMP_OK; }
   if (k == "act_scaling") { *h_value = ctx->act_scaling; return DMP_OK; }
+  if (k == "conv_tile_bands") { *h_value = ctx->conv_tile_bands; return DMP_OK; }
   if (k == "device_mib") { *h_value = (int)((ctx->bytes + (1 << 20) - 1) >> 20); return DMP_OK; }    // read only
   if (k == "vgru_persistent") { *h_value = ctx->vgru_persist && ctx->vgru_persist_ok; return DMP_OK; }
   if (k == "vgru_debug_drop_wg") { *h_value = ctx->vgru_debug_drop_wg; return DMP_OK; }

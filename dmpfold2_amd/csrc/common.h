@@ -207,7 +207,9 @@ struct dmp_ctx {
   int act_scaling = 1;         // conv_mode 0: f16 pieces of x_scale * activation per block (0 = unscaled pieces)
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
   bool ab_current = false;     // the statistics reduction already wrote this block's InstanceNorm coefficients
-  double* part = nullptr;   // [tiles][128][2]
+  double* part = nullptr;   // [half tiles][128][2] partial sums of the convolution launched last (or the stem's blocks)
+  int part_count = 0;       // ... how many of them it wrote (conv5x5_reduce_stats)
+  int conv_tile_bands = 0;  // option "conv_tile_bands": 0 = chosen by L (8-row tiles up to L = 240), 1 = 16 x 16, 2 = 8 x 16 pixels
   double* stats = nullptr;  // [128][2]
   float* ab = nullptr;      // [128][2] alpha, beta of the norm
   float* bwd_ws = nullptr;     // training-side slice (train.hip): the one workspace of both backward halves, allocated at

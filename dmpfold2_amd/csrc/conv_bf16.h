@@ -21,7 +21,7 @@
 //   weights      wq[split 4][cgrp 8][dx 5][wave 4][dy: 0 2 4 1 3][piece 3][cg 2][m 32][8]   bf16
 //                (conv channel = split*128 + wave*32 + m, input channel = cgrp*16 + cg*8 + e):
 //                one wave's operands for one pass are 9 / 6 KB contiguous = 1 KB LDS-DMA pieces
-// Workgroup = 4 waves x (32 conv channels each) x one 16x16 pixel tile; 8 input stages of 16 channels, whose 20 x 20
+// Workgroup = 4 waves x (32 conv channels each) x one 16x16 (small L: 8x16, CqShape) pixel tile; 8 input stages of 16 channels, whose 20 x 20
 // halo tile (3 pieces) is shared by the waves (2 barriers per stage); no workgroup barrier inside a stage.
 // Lane -> pixel of a fragment follows the lane groups ds_read_b128 is served in (conv_f16.h): conflict free at any
 // row pitch >= 20.
@@ -37,14 +37,23 @@ typedef __bf16 cq_bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef CQ_PITCH_N
 #define CQ_PITCH_N 20        // row pitch of the halo tile in LDS (16-byte slots)
 #endif
-constexpr int CQ_HALO = 20, CQ_PITCH = CQ_PITCH_N;
-constexpr int CQ_IN_SLOTS = 3 * 2 * CQ_HALO * CQ_PITCH;               // 2400 16-byte slots at pitch 20
-constexpr int CQ_IN_PAD = (CQ_IN_SLOTS + 63) / 64 * 64;               // the tile's DMA goes in whole waves of 64 slots
-constexpr int CQ_IN_BYTES = CQ_IN_PAD * 16;                           // 38912
+constexpr int CQ_PITCH = CQ_PITCH_N;
+constexpr int CQ_HCOLS = 20;                                          // columns of the halo tile
+// Tile shapes as in conv_f16.h (ChShape): NQ = 8 -> 16 x 16 pixels, NQ = 4 -> 8 rows x 16 columns for small L.
+template <int NQ> struct CqShape {
+  static constexpr int ROWS = 2 * NQ;
+  static constexpr int HALO = ROWS + 4;                                 // 20 or 12 halo rows
+  static constexpr int RP = ROWS + 3;                                   // row pairs
+  static constexpr int PIECE = 2 * HALO * CQ_PITCH;                     // slots of one piece
+  static constexpr int IN_SLOTS = 3 * PIECE;                            // 2400 / 1440 16-byte slots at pitch 20
+  static constexpr int IN_PAD = (IN_SLOTS + 63) / 64 * 64;              // the tile's DMA goes in whole waves of 64 slots
+  static constexpr int IN_BYTES = IN_PAD * 16;                          // 38912 / 23552
+};
 constexpr int CQ_WSLOT = 3 * 2 * 32;                                  // 192 slots = 3 KB per wave and tap
 constexpr int CQ_WCOL = 5 * CQ_WSLOT;                                 // one tap column of one wave in the packed weights
 constexpr int CQ_WBUF = 3 * CQ_WSLOT;                                 // per-wave LDS weight buffer: 3 tap slots
-constexpr int CONVQ_LDS_BYTES = CQ_IN_BYTES + 4 * CQ_WBUF * 16;       // 75776: two workgroups per CU
+template <int NQ> constexpr int convq_lds_bytes() { return CqShape<NQ>::IN_BYTES + 4 * CQ_WBUF * 16; }     // 75776 / 60416
+constexpr int CONVQ_LDS_BYTES = convq_lds_bytes<8>();                 // two workgroups per CU
 
 // round-to-nearest-even float32 -> bf16 bits
 __host__ __device__ inline uint16_t cq_bf16_rne(float f) {
@@ -115,22 +124,22 @@ __device__ __forceinline__ void cq_lane_pixel(int li, int& row, int& x) {
 // against the row pairs r = PAR, PAR + 2, .. < 19 read from the halo tile at `il`; the next row pair's three pieces are
 // requested before this one's MFMAs.  Per fragment the smallest products go first: w0 x2, w1 x1, w2 x0 (2^-16), then
 // w0 x1, w1 x0 (2^-8), then w0 x0 - each product type over the pass's taps, i.e. over different accumulators.
-template <int NT, int PAR>
-__device__ __forceinline__ void cq_column_pass(const uint4 (&a)[NT][3], const uint4* il, cq_f32x16 (&acc)[8]) {
-  constexpr int PIECE = 2 * CQ_HALO * CQ_PITCH;
+template <int NQ, int NT, int PAR>
+__device__ __forceinline__ void cq_column_pass(const uint4 (&a)[NT][3], const uint4* il, cq_f32x16 (&acc)[NQ]) {
+  constexpr int PIECE = CqShape<NQ>::PIECE, RP = CqShape<NQ>::RP;
   uint4 bn0 = il[PAR * CQ_PITCH], bn1 = il[PAR * CQ_PITCH + PIECE], bn2 = il[PAR * CQ_PITCH + 2 * PIECE];
 #pragma unroll
-  for (int r = PAR; r < 19; r += 2) {
+  for (int r = PAR; r < RP; r += 2) {
     const uint4 b0 = bn0, b1 = bn1, b2 = bn2;
-    if (r + 2 < 19) {
+    if (r + 2 < RP) {
       bn0 = il[(r + 2) * CQ_PITCH];
       bn1 = il[(r + 2) * CQ_PITCH + PIECE];
       bn2 = il[(r + 2) * CQ_PITCH + 2 * PIECE];
     }
-#define CQ_TAPS(AP, BV)                                                          \
-    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                             \
-      const int q = (r - PAR - 2 * t) / 2;                                       \
-      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = cq_mfma(a[t][AP], BV, acc[q]); \
+#define CQ_TAPS(AP, BV)                                                           \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                              \
+      const int q = (r - PAR - 2 * t) / 2;                                        \
+      if (r - PAR - 2 * t >= 0 && q < NQ) acc[q] = cq_mfma(a[t][AP], BV, acc[q]); \
     }
     CQ_TAPS(0, b2)
     CQ_TAPS(1, b1)
@@ -142,65 +151,81 @@ __device__ __forceinline__ void cq_column_pass(const uint4 (&a)[NT][3], const ui
   }
 }
 
-// number of workgroups to launch for tiles x tiles pixel tiles: the XCD-aware block map of conv_f16.h (block b runs on
-// XCD b % 8; XCD x works on ONE channel split (x & 3) of a contiguous half of the tiles, so its share of the weight
-// pieces - 2.46 MB - stays in its 4 MB L2)
-inline int conv_bf16_grid(int tiles) {
-  const int nt = tiles * tiles;
+// number of workgroups to launch for tiles x tiles 16 x 16 pixel tiles cut into `bands` row bands each: the XCD-aware
+// block map of conv_f16.h (block b runs on XCD b % 8; XCD x works on ONE channel split (x & 3) of a contiguous half of
+// the tiles, so its share of the weight pieces - 2.46 MB - stays in its 4 MB L2)
+inline int conv_bf16_grid(int tiles, int bands = 1) {
+  const int nt = tiles * tiles * bands;
   return 8 * ((nt + 1) / 2);
 }
 
-// grid: conv_bf16_grid(tiles) blocks   block: 256   dynamic LDS: CONVQ_LDS_BYTES (two workgroups per CU)
+// grid: conv_bf16_grid(tiles, 16 / (2 NQ)) blocks   block: 256   dynamic LDS: convq_lds_bytes<NQ>() (two workgroups per CU)
+// part: [tiles * tiles * 2 half tiles][CW][2] float64, as conv5x5_f16x3_kernel
+template <int NQ>
 __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* __restrict__ xs,
                                                                 const uint16_t* __restrict__ wq,
                                                                 const float* __restrict__ bias, int L, int P,
                                                                 int tiles, int nwork, float* __restrict__ u,
                                                                 double* __restrict__ part) {
+  using SH = CqShape<NQ>;
+  constexpr int BANDS = 8 / NQ;
   extern __shared__ __attribute__((aligned(16))) unsigned char cq_smem[];
   const int id = blockIdx.x;
   const int xcd = id & 7, slot = id >> 3;
-  const int ntiles = tiles * tiles;
+  const int ntiles = tiles * tiles * BANDS;
   const int tper = (ntiles + 1) >> 1;
   const int tile = (xcd >> 2) * tper + slot;
   const int split = xcd & 3;
   if (slot >= tper || tile >= ntiles) return;
-  const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
+  const int trow = tile / tiles, tcol = tile % tiles;
+  const int ty0 = trow * SH::ROWS, tx0 = tcol * CONV_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = lane >> 5, li = lane & 31;
   const int64_t PP = (int64_t)P * P;
+  const int64_t half0 = ((int64_t)(trow / BANDS) * tiles + tcol) * 2 + (trow % BANDS);
+  if (BANDS == 2 && ty0 >= L) {
+    // a band below the last row (L % 16 in 1 .. 8): nothing to convolve, but the reduction reads this half tile's sums
+    if (li == 0)
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int gch = split * 32 + wave * 8 + 2 * g4 + kk;
+        part[(half0 * CW + gch) * 2 + 0] = 0.0;
+        part[(half0 * CW + gch) * 2 + 1] = 0.0;
+      }
+    return;
+  }
 
   const uint4* in_l = reinterpret_cast<const uint4*>(cq_smem);
-  const uint4* w_l = reinterpret_cast<const uint4*>(cq_smem + CQ_IN_BYTES) + wave * CQ_WBUF;
+  const uint4* w_l = reinterpret_cast<const uint4*>(cq_smem + SH::IN_BYTES) + wave * CQ_WBUF;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)cq_smem;
-  const unsigned w_lds_addr = lds_base + CQ_IN_BYTES + wave * (CQ_WBUF * 16);
+  const unsigned w_lds_addr = lds_base + SH::IN_BYTES + wave * (CQ_WBUF * 16);
 
-  // input-tile DMA plan: slot s = e*256 + tid (CQ_IN_PAD slots: the pad slots and the slots of the row pitch beyond the
+  // input-tile DMA plan: slot s = e*256 + tid (IN_PAD slots: the pad slots and the slots of the row pitch beyond the
   // 20 halo columns re-read a valid pixel)
   const uint4* xs4 = reinterpret_cast<const uint4*>(xs);
-  constexpr int NE = (CQ_IN_PAD + 255) / 256;
+  constexpr int NE = (SH::IN_PAD + 255) / 256;
   int in_src[NE];
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int s = e * 256 + tid;
-    const int sc = s < CQ_IN_SLOTS ? s : 0;
-    const int p = sc / (2 * CQ_HALO * CQ_PITCH), r = sc % (2 * CQ_HALO * CQ_PITCH);
-    const int cg = r / (CQ_HALO * CQ_PITCH), r2 = r % (CQ_HALO * CQ_PITCH);
+    const int sc = s < SH::IN_SLOTS ? s : 0;
+    const int p = sc / SH::PIECE, r = sc % SH::PIECE;
+    const int cg = r / (SH::HALO * CQ_PITCH), r2 = r % (SH::HALO * CQ_PITCH);
     const int yy = r2 / CQ_PITCH;
     int xx = r2 % CQ_PITCH;
-    xx = xx < CQ_HALO ? xx : 0;
+    xx = xx < CQ_HCOLS ? xx : 0;
     in_src[e] = (int)(((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx);
   }
   const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 5 * 4 * CQ_WCOL +
                      (int64_t)wave * CQ_WCOL + lane;
   int prow, px;
   cq_lane_pixel(li, prow, px);
-  const int b_base = (kk * CQ_HALO + prow) * CQ_PITCH + px;      // + r * CQ_PITCH + dx (+ piece stride)
+  const int b_base = (kk * SH::HALO + prow) * CQ_PITCH + px;      // + r * CQ_PITCH + dx (+ piece stride)
   const int a_off = kk * 32 + li;
 
-  cq_f32x16 acc[8];
+  cq_f32x16 acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
@@ -224,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
       const uint4* src = xs4 + (int64_t)g * 2 * PP;
       const unsigned dst = lds_base + (wave * 64) * 16;
 #pragma unroll
-      for (int e = 0; e < CQ_IN_PAD / 256; ++e) cq_dma16(src + in_src[e], dst + e * 4096);
-      if (wave * 64 < CQ_IN_PAD % 256) cq_dma16(src + in_src[NE - 1], dst + (CQ_IN_PAD / 256) * 4096);
+      for (int e = 0; e < SH::IN_PAD / 256; ++e) cq_dma16(src + in_src[e], dst + e * 4096);
+      if (wave * 64 < SH::IN_PAD % 256) cq_dma16(src + in_src[NE - 1], dst + (SH::IN_PAD / 256) * 4096);
     }
     cq_wait_vm<0>();
     __syncthreads();                                   // the tile of every wave has landed
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
           for (int p = 0; p < 3; ++p) a[t][p] = w_l[t * CQ_WSLOT + p * 64 + a_off];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wdma(h0 + 1);                                  // the buffer is free: stream the next pass
-        cq_column_pass<3, 0>(a, il, acc);
+        cq_column_pass<NQ, 3, 0>(a, il, acc);
       }
       {
         cq_wait_vm<0>();
@@ -254,13 +279,13 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
           for (int p = 0; p < 3; ++p) a[t][p] = w_l[t * CQ_WSLOT + p * 64 + a_off];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (h0 + 2 < 80) wdma(h0 + 2);
-        cq_column_pass<2, 1>(a, il, acc);
+        cq_column_pass<NQ, 2, 1>(a, il, acc);
       }
     }
   }
 
-  // ---- epilogue: bias, 4-way max, store, per-channel partial sums (no cross-wave reduction:
-  // a wave owns its 32 conv channels = 8 maxout channels for all 256 pixels of the tile)
+  // ---- epilogue: bias, 4-way max, store, per-channel partial sums per 8-row half tile (no cross-wave reduction:
+  // a wave owns its 32 conv channels = 8 maxout channels for all pixels of the tile)
   const float* bsp = bias + split * 128 + wave * 32;
   const int64_t LL = (int64_t)L * L;
 #pragma unroll
@@ -268,28 +293,31 @@ __global__ __launch_bounds__(256, 2) void conv5x5_bf16x6_kernel(const uint16_t* 
     const int cl = 8 * g4 + 4 * kk;                        // first conv channel of the group in the wave
     const int gch = split * 32 + wave * 8 + 2 * g4 + kk;    // maxout channel
     const float b0 = bsp[cl], b1 = bsp[cl + 1], b2 = bsp[cl + 2], b3 = bsp[cl + 3];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float v = acc[q][4 * g4] + b0;
-      v = fmaxf(v, acc[q][4 * g4 + 1] + b1);
-      v = fmaxf(v, acc[q][4 * g4 + 2] + b2);
-      v = fmaxf(v, acc[q][4 * g4 + 3] + b3);
-      const int y = ty0 + 2 * q + prow, x = tx0 + px;
-      if (y < L && x < L) {
-        u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
-        s1 += v;
-        s2 += v * v;
+    for (int hq = 0; hq < NQ / 4; ++hq) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 4 * hq; q < 4 * hq + 4; ++q) {
+        float v = acc[q][4 * g4] + b0;
+        v = fmaxf(v, acc[q][4 * g4 + 1] + b1);
+        v = fmaxf(v, acc[q][4 * g4 + 2] + b2);
+        v = fmaxf(v, acc[q][4 * g4 + 3] + b3);
+        const int y = ty0 + 2 * q + prow, x = tx0 + px;
+        if (y < L && x < L) {
+          u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
-    }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      s1 += __shfl_xor(s1, off, 32);
-      s2 += __shfl_xor(s2, off, 32);
-    }
-    if (li == 0) {
-      part[((int64_t)tile * CW + gch) * 2 + 0] = (double)s1;
-      part[((int64_t)tile * CW + gch) * 2 + 1] = (double)s2;
+      for (int off = 16; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 32);
+        s2 += __shfl_xor(s2, off, 32);
+      }
+      if (li == 0) {
+        part[((half0 + hq) * CW + gch) * 2 + 0] = (double)s1;
+        part[((half0 + hq) * CW + gch) * 2 + 1] = (double)s2;
+      }
     }
   }
 }

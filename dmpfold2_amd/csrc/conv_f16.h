@@ -20,8 +20,8 @@
 // kernels raise the context's fault flag at |2^e x| >= 60000; a trunk that would leave the range unscaled is scaled
 // DOWN instead.  Option "act_scaling" = 0 restores unscaled pieces (e = 0).
 //
-// Workgroup = 4 waves x 32 conv channels x one 16x16 pixel tile (one of 4 channel splits); 8 input stages
-// of 16 channels, whose 20x20 halo tile (both pieces, 30 KB) is brought in by LDS-DMA.
+// Workgroup = 4 waves x 32 conv channels x one 16x16 (or, at small L, 8x16: ChShape) pixel tile (one of 4 channel splits);
+// 8 input stages of 16 channels, whose 20x20 halo tile (both pieces, 30 KB) is brought in by LDS-DMA.
 //
 // Row reuse.  The 32 pixels of the MFMA N axis are 2 rows x 16 columns, so accumulator q (rows 2q, 2q+1
 // of the tile) at tap (dy, dx) reads the B fragment "row pair r = 2q + dy at column offset dx": one
@@ -57,14 +57,36 @@ typedef _Float16 ch_f16x8 __attribute__((ext_vector_type(8)));
                              // lets a third workgroup in (3 waves per SIMD): sustained 0.665 against 0.667 ms - at
                              // the power cap more occupancy buys nothing, and the room beside the two is worth more
 #endif
-constexpr int CH_HALO = 20, CH_PITCH = CH_PITCH_N;
-constexpr int CH_IN_SLOTS = 2 * 2 * CH_HALO * CH_PITCH;               // 1920 16-byte slots
-constexpr int CH_IN_BYTES = CH_IN_SLOTS * 16;                         // 30720
+// Tile shapes (round 6).  NQ = accumulators per wave = row pairs of the pixel tile: 8 -> 16 x 16 pixels (the shape of
+// rounds 1-5), 4 -> 8 rows x 16 columns.  Measured (profiles/r06_conv_tile_shapes.txt): the duration of a launch is
+// ceil(workgroups / 256 CUs) x T1, T1 = 0.115 ms (f16x3) / 0.175 ms (bf16x6) the time of ONE 16 x 16 workgroup on a CU - a
+// second workgroup on the CU doubles it, so what is lost at mid L is the rounding up (L = 200: 676 workgroups = 2.64 per
+// CU -> 3; L = 300: 5.64 -> 6).  Half-height tiles halve the unit but cost 1.2 x per MFMA (1.8 instead of 2.1 MFMAs per
+// LDS fragment, a 12-row halo for 8 rows, the weight stream per workgroup unchanged): ceil(2 x 2.64) x 0.6 = 3.6 > 3 -
+// they LOSE wherever more than 256 half-height workgroups exist (L = 200: 0.399 against 0.356 ms; L = 82 .. 128: equal)
+// and WIN where the 16 x 16 shape leaves half the CUs idle: L <= 80 (L = 48: 0.064 against 0.114 ms).  conv_split_rows
+// picks them there.  The accumulation order of an output element does not depend on the shape (per stage and tap column:
+// taps dy ascending, the three products of a tap in the order below), and the InstanceNorm partial sums are formed per
+// 8-row half tile in both shapes: the same bits.
+constexpr int CH_PITCH = CH_PITCH_N;
+template <int NQ> struct ChShape {
+  static constexpr int ROWS = 2 * NQ;                                   // pixel rows of the tile
+  static constexpr int HALO = ROWS + 4;                                 // rows of the halo tile (20 or 12)
+  static constexpr int RP = ROWS + 3;                                   // row pairs r = 0 .. RP - 1 (19 or 11)
+  static constexpr int IN_SLOTS = 2 * 2 * HALO * CH_PITCH;              // 1920 / 1152 16-byte slots
+  static constexpr int IN_BYTES = IN_SLOTS * 16;                        // 30720 / 18432
+  static constexpr int PIECE = 2 * HALO * CH_PITCH;                     // slots of one piece
+};
+constexpr int CH_HCOLS = 20;                                          // columns of the halo tile
 constexpr int CH_WSLOT = 2 * 2 * 32;                                  // 128 slots = 2 KB per wave and tap
 constexpr int CH_WCOL = 5 * CH_WSLOT;                                 // one tap column of one wave in the packed weights
 constexpr int CH_WBUF = 3 * CH_WSLOT;                                 // per-wave LDS weight buffer: 3 tap slots
-constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_WBUF * 16;       // 55296
-// number of workgroups to launch for tiles x tiles pixel tiles (XCD-aware block map)
+template <int NQ> constexpr int convh_lds_bytes() { return ChShape<NQ>::IN_BYTES + 4 * CH_WBUF * 16; }      // 55296 / 43008
+constexpr int CONVH_LDS_BYTES = convh_lds_bytes<8>();
+// row bands per 16-row tile row for `tiles` x `tiles` 16 x 16 tiles: 2 = the half-height shape, where its workgroups
+// (2 x 4 x tiles^2) still find a CU each
+inline int conv_split_rows(int tiles) { return 8 * tiles * tiles <= 256 ? 2 : 1; }
+// number of workgroups to launch for tiles x tiles 16 x 16 pixel tiles cut into `bands` row bands each (XCD-aware block map)
 // block -> (tile, channel split) map (round 3, tools/r03_map.sh, profiles/r03_conv_block_maps.txt; block b runs on XCD
 // b % 8).  Sustained ms per launch at L = 300 (one stream / two launches in flight), L2-fabric bytes per launch
 // (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included; 98.7 MB algorithmic), scheduler throughput:
@@ -74,8 +96,8 @@ constexpr int CONVH_LDS_BYTES = CH_IN_BYTES + 4 * CH_WBUF * 16;       // 55296
 // Fewer XCDs per tile do not lower the traffic - the weight set no longer fits the L2 beside the activations and comes
 // back from the Infinity Cache - and the map with the MOST fabric bytes is the fastest: its weights stay in the L2, and
 // what the kernel waits for is the weight stream, not the bytes.  Map 2 is the one built; 0 and 1 are history.
-inline int conv_f16_grid(int tiles) {
-  const int nt = tiles * tiles;
+inline int conv_f16_grid(int tiles, int bands = 1) {
+  const int nt = tiles * tiles * bands;
   return 8 * ((nt + 1) / 2);
 }
 
@@ -157,31 +179,31 @@ __device__ __forceinline__ void ch_lane_pixel(int li, int& row, int& x) {
 // One pass of a tap column: NT taps (rows dy = PAR, PAR + 2, ..) whose weight fragments a[t][piece] sit in
 // registers, against the row pairs r = PAR, PAR + 2, .. < 19 read from the halo tile at `il`.
 // Per fragment the small products go first (w0 x1, w1 x0), then w0 x0.
-template <int NT, int PAR>
-__device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const uint4* il, ch_f32x16 (&acc)[8]) {
-  constexpr int PIECE = 2 * CH_HALO * CH_PITCH;
+template <int NQ, int NT, int PAR>
+__device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const uint4* il, ch_f32x16 (&acc)[NQ]) {
+  constexpr int PIECE = ChShape<NQ>::PIECE, RP = ChShape<NQ>::RP;
   uint4 bn0 = il[PAR * CH_PITCH], bn1 = il[PAR * CH_PITCH + PIECE];
 #pragma unroll
-  for (int r = PAR; r < 19; r += 2) {
+  for (int r = PAR; r < RP; r += 2) {
     const uint4 b0 = bn0, b1 = bn1;
-    if (r + 2 < 19) {
+    if (r + 2 < RP) {
       bn0 = il[(r + 2) * CH_PITCH];
       bn1 = il[(r + 2) * CH_PITCH + PIECE];
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int q = (r - PAR - 2 * t) / 2;
-      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b1, acc[q]);
+      if (r - PAR - 2 * t >= 0 && q < NQ) acc[q] = ch_mfma(a[t][0], b1, acc[q]);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int q = (r - PAR - 2 * t) / 2;
-      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][1], b0, acc[q]);
+      if (r - PAR - 2 * t >= 0 && q < NQ) acc[q] = ch_mfma(a[t][1], b0, acc[q]);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int q = (r - PAR - 2 * t) / 2;
-      if (r - PAR - 2 * t >= 0 && q < 8) acc[q] = ch_mfma(a[t][0], b0, acc[q]);
+      if (r - PAR - 2 * t >= 0 && q < NQ) acc[q] = ch_mfma(a[t][0], b0, acc[q]);
     }
   }
 }
@@ -193,56 +215,73 @@ __device__ __forceinline__ void ch_column_pass(const uint4 (&a)[NT][2], const ui
 // registers per SIMD lane and 52 KB of LDS to the kernels of other targets that run beside the convolutions in
 // throughput mode (vertical GRU step 156 registers / 32 KB, norm 108, Gauss-Jordan update 92); uncapped
 // (194 registers) the same kernel cost the scheduler 6 % although it is faster alone.
-// grid: conv_f16_grid(tiles) blocks (XCD-aware map)   block: 256   dynamic LDS: CONVH_LDS_BYTES
+// grid: conv_f16_grid(tiles, 16 / (2 NQ)) blocks (XCD-aware map)   block: 256   dynamic LDS: convh_lds_bytes<NQ>()
+// part: [tiles * tiles * 2 half tiles][CW][2] float64 - half tile h of 16 x 16 tile t at index 2 t + h, in both shapes
+template <int NQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv5x5_f16x3_kernel(const uint16_t* __restrict__ xs,
                                                                const uint16_t* __restrict__ wq,
                                                                const float* __restrict__ bias, float inv_scale,
                                                                int L, int P, int tiles, int nwork,
                                                                float* __restrict__ u, double* __restrict__ part) {
+  using SH = ChShape<NQ>;
+  constexpr int BANDS = 8 / NQ;                          // row bands per 16-row tile row
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
   const int id = blockIdx.x;
   const int xcd = id & 7, slot = id >> 3;
-  const int ntiles = tiles * tiles;
+  const int ntiles = tiles * tiles * BANDS;
   // XCD x works on ONE channel split (x & 3) of a contiguous half of the tiles: its 1.64 MB of weight pieces stay in
   // its 4 MB L2; a tile's input is read by four XCDs at about the same time (Infinity-Cache hits)
   const int tper = (ntiles + 1) >> 1;
   const int tile = (xcd >> 2) * tper + slot;
   const int split = xcd & 3;
   if (slot >= tper || tile >= ntiles) return;
-  const int ty0 = (tile / tiles) * CONV_TILE, tx0 = (tile % tiles) * CONV_TILE;
+  const int trow = tile / tiles, tcol = tile % tiles;    // trow counts bands of SH::ROWS rows
+  const int ty0 = trow * SH::ROWS, tx0 = tcol * CONV_TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kk = lane >> 5, li = lane & 31;
   const int64_t PP = (int64_t)P * P;
+  // index of this tile's first half tile in `part`: 16 x 16 tile (trow / BANDS, tcol), half trow % BANDS
+  const int64_t half0 = ((int64_t)(trow / BANDS) * tiles + tcol) * 2 + (trow % BANDS);
+  int prow, px;
+  ch_lane_pixel(li, prow, px);
+  if (BANDS == 2 && ty0 >= L) {
+    // a band below the last row (L % 16 in 1 .. 8): nothing to convolve, but the reduction reads this half tile's sums
+    if (li == 0 && prow == 0 && px == 0)
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int gch = split * 32 + wave * 8 + 2 * g4 + kk;
+        part[(half0 * CW + gch) * 2 + 0] = 0.0;
+        part[(half0 * CW + gch) * 2 + 1] = 0.0;
+      }
+    return;
+  }
 
   const uint4* in_l = reinterpret_cast<const uint4*>(ch_smem);
-  const uint4* w_l = reinterpret_cast<const uint4*>(ch_smem + CH_IN_BYTES) + wave * CH_WBUF;
+  const uint4* w_l = reinterpret_cast<const uint4*>(ch_smem + SH::IN_BYTES) + wave * CH_WBUF;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ch_smem;
-  const unsigned w_lds_addr = lds_base + CH_IN_BYTES + wave * (CH_WBUF * 16);
+  const unsigned w_lds_addr = lds_base + SH::IN_BYTES + wave * (CH_WBUF * 16);
 
-  // input-tile DMA plan: slot s = e*256 + tid, e = 0..7 (1920 slots = 7.5 x 256); recomputed at every stage
+  // input-tile DMA plan: slot s = e*256 + tid; recomputed at every stage
   // (a few dozen integer operations, 8 times per workgroup) rather than kept in registers across the tap loops
   const uint4* xs4 = reinterpret_cast<const uint4*>(xs);
   auto in_src = [&](int e, int t) {
     const int s = e * 256 + t;
-    const int sc = s < CH_IN_SLOTS ? s : 0;
-    const int p = sc / (2 * CH_HALO * CH_PITCH), r = sc % (2 * CH_HALO * CH_PITCH);
-    const int cg = r / (CH_HALO * CH_PITCH), r2 = r % (CH_HALO * CH_PITCH);
+    const int sc = s < SH::IN_SLOTS ? s : 0;
+    const int p = sc / SH::PIECE, r = sc % SH::PIECE;
+    const int cg = r / (SH::HALO * CH_PITCH), r2 = r % (SH::HALO * CH_PITCH);
     const int yy = r2 / CH_PITCH;
     int xx = r2 % CH_PITCH;
-    xx = xx < CH_HALO ? xx : 0;                     // pad slots re-read a valid pixel
+    xx = xx < CH_HCOLS ? xx : 0;                    // pad slots re-read a valid pixel
     return (int)(((int64_t)(p * 16 + cg) * P + ty0 + yy) * P + tx0 + xx);
   };
   const uint4* wq4 = reinterpret_cast<const uint4*>(wq) + (int64_t)split * 8 * 5 * 4 * CH_WCOL +
                      (int64_t)wave * CH_WCOL + lane;
-  int prow, px;
-  ch_lane_pixel(li, prow, px);
-  const int b_base = (kk * CH_HALO + prow) * CH_PITCH + px;      // + r * CH_PITCH + dx (+ piece stride)
+  const int b_base = (kk * SH::HALO + prow) * CH_PITCH + px;      // + r * CH_PITCH + dx (+ piece stride)
   const int a_off = kk * 32 + li;
 
-  ch_f32x16 acc[8];
+  ch_f32x16 acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
@@ -268,8 +307,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       int t = tid;
       asm volatile("" : "+v"(t));                    // opaque per stage: the plan is not hoisted out of the loop
 #pragma unroll
-      for (int e = 0; e < CH_IN_SLOTS / 256; ++e) ch_dma16(src + in_src(e, t), dst + e * 4096);
-      if (wave * 64 < CH_IN_SLOTS % 256) ch_dma16(src + in_src(CH_IN_SLOTS / 256, t), dst + (CH_IN_SLOTS / 256) * 4096);
+      for (int e = 0; e < SH::IN_SLOTS / 256; ++e) ch_dma16(src + in_src(e, t), dst + e * 4096);
+      if (wave * 64 < SH::IN_SLOTS % 256) ch_dma16(src + in_src(SH::IN_SLOTS / 256, t), dst + (SH::IN_SLOTS / 256) * 4096);
     }
     ch_wait_vm<0>();
     __syncthreads();                                   // the tile of every wave has landed
@@ -288,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wdma(h0 + 1);                                  // the buffer is free: stream the next pass
-        ch_column_pass<3, 0>(a, il, acc);
+        ch_column_pass<NQ, 3, 0>(a, il, acc);
       }
       {
         ch_wait_vm<0>();
@@ -300,12 +339,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (h0 + 2 < 80) wdma(h0 + 2);
-        ch_column_pass<2, 1>(a, il, acc);
+        ch_column_pass<NQ, 2, 1>(a, il, acc);
       }
     }
   }
 
-  // epilogue: undo the weight scale, bias, 4-way max, store, per-channel partial sums
+  // epilogue: undo the weight scale, bias, 4-way max, store, per-channel partial sums per 8-row half tile
   const float* bsp = bias + split * 128 + wave * 32;
   const int64_t LL = (int64_t)L * L;
 #pragma unroll
@@ -313,28 +352,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int cl = 8 * g4 + 4 * kk;
     const int gch = split * 32 + wave * 8 + 2 * g4 + kk;
     const float b0 = bsp[cl], b1 = bsp[cl + 1], b2 = bsp[cl + 2], b3 = bsp[cl + 3];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float v = acc[q][4 * g4] * inv_scale + b0;
-      v = fmaxf(v, acc[q][4 * g4 + 1] * inv_scale + b1);
-      v = fmaxf(v, acc[q][4 * g4 + 2] * inv_scale + b2);
-      v = fmaxf(v, acc[q][4 * g4 + 3] * inv_scale + b3);
-      const int y = ty0 + 2 * q + prow, x = tx0 + px;
-      if (y < L && x < L) {
-        u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
-        s1 += v;
-        s2 += v * v;
+    for (int hq = 0; hq < NQ / 4; ++hq) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 4 * hq; q < 4 * hq + 4; ++q) {
+        float v = acc[q][4 * g4] * inv_scale + b0;
+        v = fmaxf(v, acc[q][4 * g4 + 1] * inv_scale + b1);
+        v = fmaxf(v, acc[q][4 * g4 + 2] * inv_scale + b2);
+        v = fmaxf(v, acc[q][4 * g4 + 3] * inv_scale + b3);
+        const int y = ty0 + 2 * q + prow, x = tx0 + px;
+        if (y < L && x < L) {
+          u[(int64_t)gch * LL + (int64_t)y * L + x] = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
-    }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      s1 += __shfl_xor(s1, off, 32);
-      s2 += __shfl_xor(s2, off, 32);
-    }
-    if (li == 0) {
-      part[((int64_t)tile * CW + gch) * 2 + 0] = (double)s1;
-      part[((int64_t)tile * CW + gch) * 2 + 1] = (double)s2;
+      for (int off = 16; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 32);
+        s2 += __shfl_xor(s2, off, 32);
+      }
+      if (li == 0) {
+        part[((half0 + hq) * CW + gch) * 2 + 0] = (double)s1;
+        part[((half0 + hq) * CW + gch) * 2 + 1] = (double)s2;
+      }
     }
   }
 }

@@ -613,14 +613,14 @@ __global__ __launch_bounds__(256, 2) void conv5x5_maxout_kernel(const float* __r
 // block = 0: statistics only (stage-level API); block = k: also block k's InstanceNorm coefficients into
 // c->ab, which norm_scse_residual_padded then finds ready (c->ab_current)
 int conv5x5_reduce_stats(dmp_ctx* c, int L, double* d_stats, hipStream_t s, int block) {
-  const int tiles = act_tiles(L);
+  const int nparts = c->part_count;                    // what the convolution launched last wrote (tiles or half tiles)
   if (block > 0) {
     const BlockW& B = c->W.blk[block - 1];
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, tiles * tiles, d_stats,
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, nparts, d_stats,
                        (double)L * (double)L, B.gamma, B.beta, c->ab);
     c->ab_current = true;
   } else {
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, tiles * tiles, d_stats, 1.0,
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(CW), dim3(64), 0, s, c->part, nparts, d_stats, 1.0,
                        (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
   }
   DMP_LAUNCH_CHECK();
@@ -663,10 +663,14 @@ int act_split(dmp_ctx* c, const float* d_xpad, int L, int block, hipStream_t s) 
 int trunk_kernel_attrs(dmp_ctx* c) {
   static bool done[64] = {};
   if (c->device >= 0 && c->device < 64 && done[c->device]) return DMP_OK;
-  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              CONVQ_LDS_BYTES));
-  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              CONVH_LDS_BYTES));
+  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              convq_lds_bytes<8>()));
+  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_bf16x6_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              convq_lds_bytes<4>()));
+  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              convh_lds_bytes<8>()));
+  DMP_HIP(hipFuncSetAttribute((const void*)conv5x5_f16x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              convh_lds_bytes<4>()));
   if (c->device >= 0 && c->device < 64) done[c->device] = true;
   return DMP_OK;
 }
@@ -683,19 +687,33 @@ int conv5x5_maxout_padded(dmp_ctx* c, int block, const float* d_xpad, int L, flo
       int rc = act_split(c, d_xpad, L, block, s);
       if (rc) return rc;
     }
-    if (c->conv_mode == 2)
-      hipLaunchKernelGGL(conv5x5_bf16x6_kernel, dim3(conv_bf16_grid(tiles)), dim3(256), CONVQ_LDS_BYTES, s, c->xsplit, B.wq,
-                         B.bias, L, P, tiles, nwork, d_u, c->part);
-    else
-      hipLaunchKernelGGL(conv5x5_f16x3_kernel, dim3(conv_f16_grid(tiles)), dim3(256), CONVH_LDS_BYTES, s, c->xsplit, B.wh,
-                         B.bias, c->act_scaling ? B.wh_inv_scale / B.x_scale : B.wh_inv_scale, L, P, tiles, nwork, d_u,
-                         c->part);
+    // tile shape: 16 x 16 pixels, or 8 x 16 where the 16 x 16 shape would leave half the CUs without a workgroup
+    // (L <= 80; conv_f16.h ChShape: the same bits either way).  Both write their InstanceNorm partial sums per half tile.
+    const int bands = c->conv_tile_bands > 0 ? c->conv_tile_bands : conv_split_rows(tiles);
+    const float scale = c->act_scaling ? B.wh_inv_scale / B.x_scale : B.wh_inv_scale;
+    if (c->conv_mode == 2) {
+      if (bands == 2)
+        hipLaunchKernelGGL(conv5x5_bf16x6_kernel<4>, dim3(conv_bf16_grid(tiles, 2)), dim3(256), convq_lds_bytes<4>(), s,
+                           c->xsplit, B.wq, B.bias, L, P, tiles, nwork, d_u, c->part);
+      else
+        hipLaunchKernelGGL(conv5x5_bf16x6_kernel<8>, dim3(conv_bf16_grid(tiles, 1)), dim3(256), convq_lds_bytes<8>(), s,
+                           c->xsplit, B.wq, B.bias, L, P, tiles, nwork, d_u, c->part);
+    } else {
+      if (bands == 2)
+        hipLaunchKernelGGL(conv5x5_f16x3_kernel<4>, dim3(conv_f16_grid(tiles, 2)), dim3(256), convh_lds_bytes<4>(), s,
+                           c->xsplit, B.wh, B.bias, scale, L, P, tiles, nwork, d_u, c->part);
+      else
+        hipLaunchKernelGGL(conv5x5_f16x3_kernel<8>, dim3(conv_f16_grid(tiles, 1)), dim3(256), convh_lds_bytes<8>(), s,
+                           c->xsplit, B.wh, B.bias, scale, L, P, tiles, nwork, d_u, c->part);
+    }
     DMP_LAUNCH_CHECK();
+    c->part_count = 2 * tiles * tiles;                 // half tiles
     return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
   }
   hipLaunchKernelGGL(conv5x5_maxout_kernel<false>, dim3(grid), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
                      P, tiles, nwork, d_u, c->part, (uint8_t*)nullptr);
   DMP_LAUNCH_CHECK();
+  c->part_count = tiles * tiles;
   return reduce ? conv5x5_reduce_stats(c, L, d_stats, s) : DMP_OK;
 }
 
@@ -708,6 +726,7 @@ int conv5x5_maxout_winners(dmp_ctx* c, int block, const float* d_xpad, int L, fl
   hipLaunchKernelGGL(conv5x5_maxout_kernel<true>, dim3(round_up(nwork, 8)), dim3(256), 0, s, d_xpad, B.wpack, B.bias, L,
                      P, tiles, nwork, d_u, c->part, d_idx);
   DMP_LAUNCH_CHECK();
+  c->part_count = tiles * tiles;
   return DMP_OK;
 }
 

@@ -184,3 +184,31 @@ def save_state_dict(path, sd):
     """Save in the reference's weight-file format (a pickled tensor dict)."""
     import torch
     torch.save({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, path)
+
+
+def protein_like_trace(L, seed, bond=3.8, min_sep=4.5, radius=None):
+    """A self-avoiding CA trace of L points (builder's own generator, Philox counter RNG): 3.8 A bonds,
+    i / i+2 distance in [5, 7] A, every other pair at least `min_sep` apart, confined to a sphere of the
+    radius a compact chain of that length fills.  A regression target for `fit_coord_fc` at lengths for
+    which the reference tree holds no structure (3FGX chain A has 96 residues)."""
+    rng = np.random.Generator(np.random.Philox(key=int(seed) + 0xCA))
+    radius = radius or 3.3 * L ** (1.0 / 3.0) + 6.0
+    pts = [np.zeros(3), np.array([bond, 0.0, 0.0])]
+    fails = 0
+    while len(pts) < L:
+        u = rng.standard_normal(3)
+        cand = pts[-1] + bond * u / np.linalg.norm(u)
+        P = np.asarray(pts)
+        d2 = np.linalg.norm(cand - P[-2])
+        ok = 5.0 <= d2 <= 7.0 and np.linalg.norm(cand - P.mean(0)) <= radius
+        if ok and len(pts) > 2:
+            ok = np.linalg.norm(P[:-2] - cand, axis=1).min() >= min_sep
+        if ok:
+            pts.append(cand)
+            fails = 0
+        else:
+            fails += 1
+            if fails > 400:                      # dead end: back out of it
+                del pts[max(2, len(pts) - 6):]
+                fails = 0
+    return np.asarray(pts, dtype=np.float32)

@@ -1121,3 +1121,41 @@ def test_c_abi_pipeline_submit_poll_status_release(synth_sd):
         assert stats[0] >= 1 and 2 <= stats[1] <= 4 and stats[4] == 0
     finally:
         lib.dmp_pipeline_destroy(p)
+
+
+@pytest.mark.parametrize("L", [17, 40, 82, 200])
+def test_convolution_tile_shapes_give_the_same_bits(synth_sd, L):
+    """Round 6: at small L the split-product convolutions can run on 8 x 16 pixel tiles instead of
+    16 x 16 (twice the workgroups).  The accumulation order of an output element and the grouping of the InstanceNorm partial sums (per
+    8-row half tile in both shapes) do not depend on the shape: convolution output, statistics and a whole prediction are
+    the same bits with either, in both split arithmetics; the automatic choice (option "conv_tile_bands" = 0) is the
+    half-height tile up to L = 80, where the 16 x 16 shape leaves half the CUs idle (measured: it loses above)."""
+    from abi import Stages
+    st = Stages(synth_sd, max_L=max(L, 64), max_N=64)
+    g = torch.Generator(device="cuda").manual_seed(L)
+    x = torch.randn(128, L, L, device="cuda", generator=g) * 3.0
+    from dmpfold2_amd import synth
+    from dmpfold2_amd.predict import encode_aln
+    msa = encode_aln(synth.synth_msa(L, 48, 200 + L))
+    try:
+        for mode in (0, 2):
+            st.eng.set_option("conv_mode", mode)
+            got = {}
+            for bands in (1, 2, 0):
+                st.eng.set_option("conv_tile_bands", bands)
+                u, stats = st.conv(3, x)
+                c, f = st.eng.predict(msa, None, 2, 5)
+                st.eng.sync_check()
+                got[bands] = (u.clone(), stats.clone(), c.clone(), f.clone())
+            for k in (2, 0):
+                for a, b in zip(got[1], got[k]):
+                    assert torch.equal(a, b), (mode, k)
+            # and the values are a convolution's: against the float32 matrix-core kernel
+            st.eng.set_option("conv_mode", 1)
+            u32, _ = st.conv(3, x)
+            st.eng.sync_check()
+            assert float((got[2][0] - u32).abs().max()) <= 2e-5 * float(u32.abs().max())
+    finally:
+        st.eng.set_option("conv_tile_bands", 0)
+        st.eng.set_option("conv_mode", 0)
+        st.eng.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU box: every configuration of BASELINE.json on one MI355X, each with a roofline fraction of
-its dominant kernel - in both arithmetic settings (option "precision" 0: split-f16 products, 1: the reference's float32).
+its dominant kernel - in the three arithmetic settings (option "precision" 2: exact 3 x bf16 pieces, the headline; 1: f32 MFMA; 0: split f16).
 
     python tools/bench_configs.py [--c4 256] [--skip-c5-f32]  > profiles/r05_configs.jsonl
 
@@ -34,7 +34,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see bench.py
 from dmpfold2_amd import synth, _lib                 # noqa: E402
 from dmpfold2_amd.predict import Engine, Pipeline, encode_aln, read_aln   # noqa: E402
 
-PEAK = {0: 2500.0 / 3.0, 1: 157.3}                   # TFLOP/s the algorithmic float32 FLOPs are priced against
+PEAK = {0: 2500.0 / 3.0, 1: 157.3, 2: 2500.0 / 6.0}  # TFLOP/s the algorithmic float32 FLOPs are priced against
 lib = _lib.load()
 
 
@@ -56,12 +56,15 @@ def conv_intervals(engines, cap):
     return iv
 
 
-def quantisation(L):
+def quantisation(L, prec):
     t = math.ceil(L / 16)
-    wgs = 4 * t * t
-    return {"pixel_tiles": t * t, "workgroups": wgs, "rounds_of_512": wgs / 512.0,
-            "slot_fill_of_last_round": round(wgs / (math.ceil(wgs / 512) * 512), 3),
-            "real_pixels_per_tile_area": round(L * L / float(t * t * 256), 3)}
+    # the split-product kernels use 8 x 16 pixel tiles where 16 x 16 would leave half the CUs idle (round 6: L <= 80)
+    bands = 2 if (prec != 1 and 8 * t * t <= 256) else 1
+    rows = math.ceil(L / (16 // bands))
+    wgs = 4 * t * rows
+    slots = 512 if prec != 0 or bands == 1 else 768          # workgroups resident per chip (f16 8 x 16: three per CU)
+    return {"tile_rows": 16 // bands, "pixel_tiles": t * rows, "workgroups": wgs, "rounds_of_slots": wgs / float(slots),
+            "real_pixels_per_tile_area": round(L * L / float(t * rows * 256 // bands), 3)}
 
 
 def single(eng, msa, n, m, reps, warm=True):
@@ -106,7 +109,7 @@ def main():
                  ("NS L=300 N=2000 10+100", encode_aln(synth.synth_msa(300, 2000, seed=1)), 10, 100, 3),
                  ("C3 L=500 N=5000->3000 30+200", encode_aln(synth.synth_msa(500, 3000, seed=1)), 30, 200, 2),
                  ("C5 L=1000 N=2000 100+1000", encode_aln(synth.synth_msa(1000, 2000, seed=1)), 100, 1000, 1)]
-        for prec in (0, 1):
+        for prec in (2, 1, 0):
             eng.set_option("precision", prec)
             for name, msa, n, m, reps in cases:
                 if prec == 1 and name.startswith("C5") and args.skip_c5_f32:
@@ -115,7 +118,7 @@ def main():
                 dt, ms, tf, cnt = single(eng, msa, n, m, reps)
                 report(name, precision=prec, seconds_per_structure=dt, structures_per_s_single_stream=1.0 / dt,
                        conv_chip_ms_per_launch=ms, conv_launches_timed=cnt, conv_tflops=tf, peak_tflops=PEAK[prec],
-                       frac=tf / PEAK[prec], conv_share_of_time=ms * 1e-3 * 16 * (n + 1) / dt, **quantisation(L))
+                       frac=tf / PEAK[prec], conv_share_of_time=ms * 1e-3 * 16 * (n + 1) / dt, **quantisation(L, prec))
         eng.close()
 
     # ---- through the 4-engine scheduler
@@ -125,9 +128,8 @@ def main():
     lens = rng.integers(100, 301, size=args.c4)
     c4 = [torch.from_numpy(encode_aln(synth.synth_msa(int(L), 2000, seed=1000 + i))).to(dev) for i, L in enumerate(lens)]
     order = sorted(range(len(c4)), key=lambda i: -int(lens[i]))          # longest first, as shard.py deals them
-    for prec in (0, 1):
-        for e in pipe.engines:
-            e.set_option("precision", prec)
+    for prec in (2, 1, 0):
+        pipe.set_option("precision", prec)
         for name, tg, flops in (("C2 x12 through the 4-engine scheduler", c2, [2.0 * 128 * 512 * 25 * 200 * 200] * 12),
                                 (f"C4 {args.c4} targets L in [100,300] N=2000 10+100 through the 4-engine scheduler",
                                  [c4[i] for i in order], [2.0 * 128 * 512 * 25 * float(lens[i]) ** 2 for i in order])):

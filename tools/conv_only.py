@@ -21,8 +21,10 @@ from abi import Stages                               # noqa: E402
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+bands = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # option "conv_tile_bands": 0 by length, 1 = 16 x 16, 2 = 8 x 16
 st = Stages(synth.synth_weights(0, coord_scale=5.0), L, 8)
 st.eng.set_option("conv_mode", mode)
+st.eng.set_option("conv_tile_bands", bands)
 dev = st.dev
 
 # calibration kernels
@@ -35,4 +37,4 @@ z0 = torch.randn(384, L, L, device=dev)
 dmap = torch.full((L, L), -1.0, device=dev)
 st.trunk_pass(z0, dmap)                              # warm
 ms = st.conv_ms(z0, dmap, passes)
-print(f"conv5x5 L={L} conv_mode={mode}: {ms:.3f} ms per launch, {2.0 * 128 * 512 * 25 * L * L / ms / 1e9:.1f} TFLOP/s")
+print(f"conv5x5 L={L} conv_mode={mode} bands={bands}: {ms:.3f} ms per launch, {2.0 * 128 * 512 * 25 * L * L / ms / 1e9:.1f} TFLOP/s")

@@ -34,6 +34,9 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--eps", type=float, nargs="*", default=[0.0, 0.02, 0.1, 0.3, 1.0])
 ap.add_argument("--ridge", type=float, nargs="*", default=[1e-3, 1e-1])
 ap.add_argument("--out", default="gpurun_out/coord_fc")
+ap.add_argument("--n", type=int, default=10, help="iterations of the stability runs")
+ap.add_argument("--m", type=int, default=100, help="minimiser steps of the stability runs")
+ap.add_argument("--trace-seed", type=int, default=-1, help="protein_like_trace seed (default: the L = 300 fixture's target)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sd = synth.synth_weights(0, coord_scale=5.0)
@@ -41,8 +44,11 @@ st = Stages(sd, a.L, a.N)
 eng = st.eng
 L = a.L
 alnmat = encode_aln(synth.synth_msa(a.L, a.N, a.seed))
-gpath = os.path.join(ROOT, "tests", "golden", "fitns_L300_N2000_n10_m100.npz")
-T = torch.from_numpy(np.load(gpath)["target_ca"]).double().to(dev)
+if a.trace_seed >= 0:
+    T = torch.from_numpy(synth.protein_like_trace(a.L, a.trace_seed)).double().to(dev)
+else:
+    gpath = os.path.join(ROOT, "tests", "golden", "fitns_L300_N2000_n10_m100.npz")
+    T = torch.from_numpy(np.load(gpath)["target_ca"]).double().to(dev)
 T = T - T.mean(0, keepdim=True)
 
 
@@ -85,20 +91,21 @@ for eps in a.eps:
         sd2 = dict(sde)
         sd2["coord_fc.weight"] = Wf.cpu().numpy()
         eng.set_weights({k: torch.from_numpy(np.array(v)) for k, v in sd2.items()})
-        for (n, m) in ((10, 0), (10, 100)):
+        for (n, m) in ((a.n, 0), (a.n, a.m)):
             runs = {}
+            P = n + 1
             for mode in (0, 1, 2):
-                eng.set_option("conv_mode", mode)
+                eng.set_option("precision", mode)
                 coords, confs = eng.predict(alnmat, None, n, m)
                 eng.sync_check()
-                runs[mode] = (coords.cpu(), confs.cpu(), eng.fetch("ca_pass", 11 * L * 3).reshape(11, L, 3).cpu(),
-                              eng.fetch("conf_means", 11).cpu())
-            eng.set_option("conv_mode", 0)
+                runs[mode] = (coords.cpu(), confs.cpu(), eng.fetch("ca_pass", P * L * 3).reshape(P, L, 3).cpu(),
+                              eng.fetch("conf_means", P).cpu())
+            eng.set_option("precision", 0)
             for mo in (1, 2):
-                per = [rmsd(runs[0][2][p], runs[mo][2][p]) for p in range(11)]
+                per = [rmsd(runs[0][2][p], runs[mo][2][p]) for p in range(P)]
                 print(f"   n={n} m={m} mode 0 vs {mo}: final CA-RMSD {rmsd(runs[0][0][:, 1], runs[mo][0][:, 1]):.2e} max|dconf| "
                       f"{float((runs[0][1] - runs[mo][1]).abs().max()):.2e} per pass " + " ".join(f"{v:.1e}" for v in per), flush=True)
-            moved = [rmsd(runs[0][2][p], runs[0][2][0]) for p in range(11)]
+            moved = [rmsd(runs[0][2][p], runs[0][2][0]) for p in range(P)]
             print("   conf means", " ".join(f"{float(v):.4f}" for v in runs[0][3]),
                   " trace of pass p against pass 0:", " ".join(f"{v:.2g}" for v in moved),
                   " final:", stats(runs[0][0][:, 1].to(dev)), flush=True)

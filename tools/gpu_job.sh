@@ -1,7 +1,4 @@
 #!/bin/bash
-# scratch GPU job of a session: gpurun -- 'bash tools/gpu_job.sh'.  Every step under its own timeout (a step that
-# waited on an empty argument once cost a whole GPU call); outputs under gpurun_out/job/.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/job; mkdir -p $OUT
-timeout 2400 python -m pytest tests -q -m gpu > $OUT/all.log 2>&1; tail -25 $OUT/all.log
-timeout 1500 python bench.py --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json; tail -5 $OUT/bench.err
+for m in 0 2; do for L in 48 82 96 112 128 144 160 176 200 240; do for b in 1 2; do timeout 300 python tools/conv_only.py 40 $L $m $b 2>&1 | tail -1; done; done; done | tee $OUT/conv_bands.log
