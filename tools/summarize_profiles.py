@@ -28,7 +28,7 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
-for sub, leg in (("prof_bench", "f16x3"), ("prof_bench_f32", "f32")):
+for sub, leg in (("prof_bench_bf16x3", "bf16x3"), ("prof_bench_f32", "f32"), ("prof_bench_f16x2", "f16x2")):
     stats = os.path.join(G, sub, "bench_kernel_stats.csv")
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(P, f"{tag}_bench_kernel_stats_{leg}.csv"))
@@ -46,6 +46,15 @@ if os.path.exists(f32_stats):
     assert not bad, bad
 
 
+# the headline leg (precision 2): full-width operands - no split-f16 kernel (22-bit operands) may appear in its table
+hl_stats = os.path.join(P, f"{tag}_bench_kernel_stats_bf16x3.csv")
+if os.path.exists(hl_stats):
+    bad = [r["Name"] for r in csv.DictReader(open(hl_stats))
+           if any(k in r["Name"] for k in ("f16x3", "vgru_persist_kernel(", "vgru2_step_kernel", "act_split_kernel<0>"))]
+    print("headline leg (precision 2): split-f16 kernels in its kernel table:", bad or "none")
+    assert not bad, bad
+
+
 def counters(name):
     path = os.path.join(G, "pmc", name, f"{name}_counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -57,14 +66,17 @@ def counters(name):
 
 
 L = 300
-for sfx, kernel, src, out_txt, out_json, expect in (
-        ("", "conv5x5_f16x3_kernel", "dmpfold2_amd/csrc/conv_f16.h", f"{tag}_conv5x5_pmc.txt", "conv5x5_pmc.json",
-         1444 * 4 * 8 * 25 * 8 * 3),
-        ("_f32", "conv5x5_maxout_kernel", "dmpfold2_amd/csrc/trunk.hip", f"{tag}_conv5x5_f32_pmc.txt", "conv5x5_f32_pmc.json",
-         1444 * 4 * 64 * 25 * 8)):
+# PMC passes: tools/pmc_conv.sh <conv_mode> 300 m<conv_mode> writes gpurun_out/pmc/m<mode>_{sq1,sq2,fetch,write}
+for sfx, kernel, src, out_txt, out_json, expect, abytes in (
+        ("m2", "conv5x5_bf16x6_kernel", "dmpfold2_amd/csrc/conv_bf16.h", f"{tag}_conv5x5_bf16_pmc.txt", "conv5x5_bf16_pmc.json",
+         1444 * 4 * 8 * 25 * 8 * 6, 6.0),
+        ("m0", "conv5x5_f16x3_kernel", "dmpfold2_amd/csrc/conv_f16.h", f"{tag}_conv5x5_pmc.txt", "conv5x5_pmc.json",
+         1444 * 4 * 8 * 25 * 8 * 3, 4.0),
+        ("m1", "conv5x5_maxout_kernel", "dmpfold2_amd/csrc/trunk.hip", f"{tag}_conv5x5_f32_pmc.txt", "conv5x5_f32_pmc.json",
+         1444 * 4 * 64 * 25 * 8, 4.0)):
     lines, conv, calib = [], {}, {}
     for name in ("sq1", "sq2", "fetch", "write"):
-        for kern, cs in counters(name + sfx).items():
+        for kern, cs in counters(sfx + "_" + name).items():
             for c, vals in cs.items():
                 mean = sum(vals) / len(vals)
                 if kernel in kern:
@@ -80,10 +92,11 @@ for sfx, kernel, src, out_txt, out_json, expect in (
     gui = conv.get("GRBM_GUI_ACTIVE", 0.0)
     fetch_kib, write_kib = conv.get("FETCH_SIZE", 0.0), conv.get("WRITE_SIZE", 0.0)
     hbm = (2.0 * fetch_kib + write_kib) * 1024.0
-    # algorithmic bytes per launch: input activations (f16x3: two f16 pieces = 4 B per value; f32: 4 B) + weights + output
-    algo = 4.0 * (128 * L * L + 512 * 128 * 25 + 128 * L * L)
+    # algorithmic bytes per launch: input activations (bf16x6: three bf16 pieces = 6 B per value; f16x3: two f16 pieces = 4 B;
+    # f32: 4 B) + weights in the same form + the float32 output
+    algo = abytes * (128 * L * L + 512 * 128 * 25) + 4.0 * 128 * L * L
     with open(os.path.join(P, out_txt), "w") as fh:
-        fh.write(f"# {kernel}, L=300, 16 launches of one trunk pass; rocprofv3 --pmc passes (tools/profile_r05.sh)\n")
+        fh.write(f"# {kernel}, L=300, 16 launches of one trunk pass; rocprofv3 --pmc passes (tools/pmc_conv.sh)\n")
         fh.write("\n".join(lines) + "\n")
         if gui and busy:
             # GRBM_GUI_ACTIVE sums the 8 XCDs; MFMA busy cycles sum over the 1024 SIMDs
