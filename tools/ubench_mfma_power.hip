@@ -21,6 +21,24 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ ab, i
     a[i] = __builtin_bit_cast(f16x8, ab[(i * 64 + lane)]);
     b[i] = __builtin_bit_cast(f16x8, ab[((4 + i) * 64 + lane)]);
   }
+#ifdef USE_16X16
+  // -DUSE_16X16: v_mfma_f32_16x16x32_bf16 (half the MACs per instruction, a quarter of the accumulator registers): does the
+  // shape change what the power cap allows?  Two instructions per slot keep the FLOP count of a loop iteration equal.
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc4[16];
+  for (int q = 0; q < 16; ++q)
+    for (int r = 0; r < 4; ++r) acc4[q][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      acc4[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[q & 3]), __builtin_bit_cast(bf16x8, b[(q >> 1) & 3]), acc4[q], 0, 0, 0);
+  }
+  float s4 = 0.f;
+  for (int q = 0; q < 16; ++q)
+    for (int r = 0; r < 4; ++r) s4 += acc4[q][r];
+  if (s4 == 12345.678f) out[0] = s4;
+  return;
+#endif
   f32x16 acc[8];
   for (int q = 0; q < 8; ++q)
     for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
@@ -28,7 +46,12 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ ab, i
 #pragma unroll
     for (int q = 0; q < 8; ++q)
 #ifdef USE_BF16
+#ifdef SAME_B
+      // -DSAME_B: eight consecutive MFMAs share their B operand (the convolution's row reuse: one pixel fragment, several taps)
+      acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q & 3]), __builtin_bit_cast(bf16x8, b[0]), acc[q], 0, 0, 0);
+#else
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q & 3]), __builtin_bit_cast(bf16x8, b[(q >> 1) & 3]), acc[q], 0, 0, 0);
+#endif
 #else
       acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q & 3], b[(q >> 1) & 3], acc[q], 0, 0, 0);
 #endif
