@@ -135,6 +135,9 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * second stream beside this step's trailing update - where one prediction has the device to itself (dmp_predict,
  * dmp_spd_inverse, dmp_dca_features): 0 never, 1 (default) from 64 tile rows on (D > 8064: 23.5 against 25.4 ms at
  * D = 10500; at D = 6300 it loses, 8.7 against 7.7 ms), 2 at every size.  Same bits in every mode.
+ * "conv_tile_bands" = 0 / 1 / 2 (round 6): pixel tile of the split-product convolutions - 1 = 16 x 16, 2 = 8 rows x 16
+ * columns (twice the workgroups), 0 (default) = 8 x 16 where the 16 x 16 shape would leave half the CUs without a workgroup
+ * (L <= 80), 16 x 16 above.  The same bits in every setting.
  * "act_scaling" (default 1): conv_mode 0 takes the f16 pieces of 2^e x activation, with e chosen per residual block
  * at dmp_weights_finalize from the InstanceNorm weights of the blocks before it (a bound of the residual stream), so the
  * low pieces of the bulk of the activations are normal f16 numbers whether the trunk sits at 1e-3 or at 1e4, and a trunk
