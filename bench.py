@@ -391,8 +391,6 @@ def main(argv=None):
 
     from dmpfold2_amd import synth, _lib, shard
     from dmpfold2_amd.predict import Pipeline, Engine, encode_aln
-    if os.environ.get("DMP_PY_SCHED") == "1":            # A/B (developer): the round-5 Python scheduler, if the untracked copy is there
-        from dmpfold2_amd._py_sched import Pipeline
     lib = _lib.load()
     if world > 1 and not share_gpu:
         shard.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))

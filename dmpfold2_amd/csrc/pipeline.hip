@@ -455,8 +455,7 @@ void scheduler_main(dmp_pipeline* p) {
         only_completions = p->pending.empty() && p->running == 0;
       }
       p->stat_idle_rounds++;
-      static const int idle_us = env_int("DMP_SCHED_SLEEP_US", 20);
-      std::this_thread::sleep_for(std::chrono::microseconds(only_completions ? 200 : idle_us));
+      std::this_thread::sleep_for(std::chrono::microseconds(only_completions ? 200 : 20));
     }
   }
 }

@@ -396,14 +396,16 @@ class Pipeline:
     of rounds 1-5 had - submit / pump / drain / result, step / poll / peek for the streaming batch front end, collect for
     the repeat of faulted targets."""
 
-    def __init__(self, device, max_L, max_N, state_dict, streams=2, precision=None):
+    def __init__(self, device, max_L, max_N, state_dict, streams=2, precision=None, torch_streams=False):
+        """`torch_streams`: the engines run on PyTorch pool streams handed to the library (dmp_pipeline_create_on) instead of
+        the library's own - for a host that wants every stream to be one its allocator knows."""
         self.lib = _lib.load()
         self.device = _resolve_device(device)
         S = max(1, int(streams))
         self._p = C.c_void_p()
         max_N = int(min(max_N, MAX_SEQS))
         with torch.cuda.device(self.device):
-            if os.environ.get("DMP_PIPE_TORCH_STREAMS") == "1":          # the engines on PyTorch pool streams (dmp_pipeline_create_on)
+            if torch_streams:
                 self._torch_streams = [torch.cuda.Stream(device=self.device) for _ in range(S)]
                 arr = (C.c_void_p * S)(*[st.cuda_stream for st in self._torch_streams])
                 _lib.check(self.lib.dmp_pipeline_create_on(self.device.index, int(max_L), max_N, S, arr, C.byref(self._p)))

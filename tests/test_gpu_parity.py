@@ -1121,6 +1121,18 @@ def test_c_abi_pipeline_submit_poll_status_release(synth_sd):
         assert stats[0] >= 1 and 2 <= stats[1] <= 4 and stats[4] == 0
     finally:
         lib.dmp_pipeline_destroy(p)
+    # the same on the CALLER'S streams (dmp_pipeline_create_on, here through the Python wrapper on PyTorch pool streams):
+    # the same bits
+    from dmpfold2_amd.predict import Pipeline
+    pipe = Pipeline(dev, 128, 512, synth_sd, streams=2, precision=2, torch_streams=True)
+    try:
+        assert [e._stream.cuda_stream for e in pipe.engines] == [st.cuda_stream for st in pipe._torch_streams]
+        res = pipe.run(msas[:3], 2, 5)
+        torch.cuda.synchronize()
+        for (c, f), (c0, f0) in zip(res, outs[:3]):
+            assert torch.equal(c, c0) and torch.equal(f, f0)
+    finally:
+        pipe.close()
 
 
 @pytest.mark.parametrize("L", [17, 40, 82, 200])
