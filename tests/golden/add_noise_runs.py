@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""More samples of the reference's own spread for a `fit*` fixture of make_goldens.py (build container only).
+"""More samples of the reference's own spread for a synthetic-alignment fixture of make_goldens.py (build container only).
 
     python tests/golden/add_noise_runs.py fit_L1000_N2000_n3_m1000 5 6
 
@@ -34,10 +34,17 @@ def main():
     g = dict(np.load(path))
     L = g["coords"].shape[0]
     n, m = int(g["iterations"]), int(g["minsteps"])
-    sd = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]), seed=int(g["weights_seed"]))
+    if "coord_gru_mds_scale" in g:
+        sd = synth.headline_fixture_weights(g["coord_fc"], float(g["coord_gru_mds_scale"]),
+                                            seed=int(g["weights_seed"]) if "weights_seed" in g else 0)
+    else:
+        sd = synth.synth_weights(int(g["weights_seed"]) if "weights_seed" in g else 0, coord_scale=5.0)
     assert synth.weights_checksum(sd) == bytes(g["weights_sha256"]).decode()
     W = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
-    alnmat = O.encode_aln(synth.synth_msa(L, int(g["msa_rows"]), int(g["msa_seed"])))
+    rows = int(g["msa_rows"]) if "msa_rows" in g else int(name.split("_N")[1].split("_")[0])       # (older fixtures: from the name)
+    alnmat = O.encode_aln(synth.synth_msa(L, rows, int(g["msa_seed"])))
+    import hashlib
+    assert hashlib.sha256(np.ascontiguousarray(alnmat).tobytes()).hexdigest() == bytes(g["alnmat_sha256"]).decode()
     ref_ca = torch.from_numpy(g["coords"][:, 1])
     ref_conf = torch.from_numpy(g["confs"])
     ref_pass = torch.from_numpy(g["ca_pass"])
