@@ -158,8 +158,9 @@ struct dmp_ctx {
   bool vgru_persist_ok = false;            // the device has the 256 CUs the persistent form is laid out for
   int vgru_debug_drop_wg = 0;              // TEST option "vgru_debug_drop_wg": launch the persistent chain one workgroup short (its row
                                            // barrier must time out ONCE, raise DMP_FAULT_VGRU_HANDOFF and leave the row loop)
-  int vgru_f32 = -1;                       // option "vgru_f32": 1 = float32 MFMAs + library gates (vgru_f32.hip), 0 = split-f16
-                                           // products, -1 (default) = follow the convolution: float32 with conv_mode 1
+  int vgru_f32 = 1;                        // option "vgru_f32": 1 = float32 MFMAs + library gates (vgru_f32.hip), 0 = split-f16
+                                           // products, -1 = follow the convolution: float32 with conv_mode 1.  A context
+                                           // starts in option "precision" 2: conv_mode 2 + vgru_f32 1 (round 6)
   int vg_ntiles = 0, vg_maxN = 0;          // group this context leads (vgru.hip): column tiles, deepest member alignment
   int vg_tile0[8] = {0};                   // ... first column tile of every member
   int vg_cap_cols = 0;                     // columns the state buffers hold (a group's members side by side)
@@ -203,7 +204,7 @@ struct dmp_ctx {
   float* xb = nullptr;
   float* xdense = nullptr;  // [128][L][L] scratch for the stage-level API
   uint16_t* xsplit = nullptr;  // [3][16][P][P][8] bf16 pieces of the current activations
-  int conv_mode = 0;           // 0: f16x3 split products (default), 1: exact f32 MFMA, 2: bf16x6 split
+  int conv_mode = 2;           // 2: exact 3 x bf16 pieces, 6 products (default: full-width operands), 1: f32 MFMA, 0: f16x3 split products (fast mode)
   int act_scaling = 1;         // conv_mode 0: f16 pieces of x_scale * activation per block (0 = unscaled pieces)
   bool xsplit_current = false; // the producer of the activations already wrote their bf16 pieces
   bool ab_current = false;     // the statistics reduction already wrote this block's InstanceNorm coefficients

@@ -176,11 +176,10 @@ def _env_precision():
     return int(v)
 
 
-# What the reference's own entry points compute in is float32 (predict.py:136 `.float()`, network.py:25-31), so the DROP-IN
-# entry points of this package - aln_to_coords, the CLI, the batch front end - default to the setting whose operands carry
-# float32's 24 significand bits at the 16-bit matrix cores' rate (option "precision" = 2); DMPFOLD_PRECISION=0 selects the
-# fast 22-23-bit mode (about 1.8 x the speed), 1 the f32 matrix-core instructions.  A context made through the C ABI or
-# an `Engine` made directly starts in the library's setting (precision 0) unless DMPFOLD_PRECISION says otherwise.
+# What the reference's own entry points compute in is float32 (predict.py:136 `.float()`, network.py:25-31), so a context
+# - through the C ABI, an `Engine`, a `Pipeline`, aln_to_coords, the CLI, the batch front end - starts in the setting whose
+# operands carry float32's 24 significand bits at the 16-bit matrix cores' rate (option "precision" = 2).
+# DMPFOLD_PRECISION=0 selects the fast 22-23-bit mode (about 1.8 x the speed), 1 the f32 matrix-core instructions.
 DROP_IN_PRECISION = 2
 
 

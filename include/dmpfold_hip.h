@@ -84,23 +84,24 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
 /* (device memory held by the context: option "device_mib" of dmp_ctx_get_option, read only) */
 
 /* Options (additive).  "conv_mode" selects how the 5x5 convolutions form their float32 products:
- *   0 (default)  each float32 operand split into two f16 pieces, 3 f16 MFMA products, float32
+ *   0            each float32 operand split into two f16 pieces, 3 f16 MFMA products, float32
  *                accumulation - same error against float64 as a float32 convolution, 5.3x the
  *                f32 matrix-core rate; activations must stay inside the f16 range (|x| < 6e4,
  *                checked on the device, reported by dmp_sync_faults);
  *   1            the f32 matrix-core instruction (bitwise an fmaf chain);
- *   2            exact 3-way bf16 split, 6 bf16 MFMA products (no range limit, 2.7x the f32 rate).
+ *   2 (default)  exact 3-way bf16 split, 6 bf16 MFMA products (no range limit, 2.7x the f32 rate).
  * "conv_f32_exact" = 1 is shorthand for conv_mode 1 (0 restores the default).
- * "precision" = 0 / 1 / 2 is the end-to-end switch: 0 = a context's initial setting, the FAST mode (split-f16 products
- * of 22-23-bit operands in the convolutions AND in the vertical GRU, whose gates use the hardware v_exp_f32 / v_rcp_f32);
+ * "precision" = 0 / 1 / 2 is the end-to-end switch: 0 = the FAST mode (split-f16 products of 22-23-bit operands in the
+ * convolutions AND in the vertical GRU, whose gates use the hardware v_exp_f32 / v_rcp_f32; 1.8 x the speed of 2);
  * 1 = the reference's arithmetic instruction for instruction - conv_mode 1 and the float32 vertical GRU
  * (v_mfma_f32_16x16x4_f32 products, the device library's expf / tanhf in the gates: nn.GRU in float32, network.py:189,
  * 223-224); with it no f16 / bf16 matrix-core kernel runs; 2 (round 6) = FULL-WIDTH operands at the 16-bit matrix cores'
  * rate - conv_mode 2 (every float32 operand as three exact bf16 pieces = 24 significand bits, the six piece products
- * above 2^-24 accumulated in float32) and the float32 vertical GRU of setting 1: the setting the drop-in entry points
- * (aln_to_coords, the CLI, the batch front end) default to, 1.7 x the speed of setting 1.
+ * above 2^-24 accumulated in float32) and the float32 vertical GRU of setting 1: A CONTEXT'S INITIAL SETTING (the
+ * reference computes in float32: predict.py:136, network.py:25-31) and what the drop-in entry points run; 1.7 x the
+ * speed of setting 1.
  * Reads back 0 / 1 / 2, or -1 for a mixed setting.
- * "vgru_f32" = -1 / 0 / 1: the vertical GRU alone; -1 (default) follows the convolution (float32 exactly when
+ * "vgru_f32" = -1 / 0 / 1: the vertical GRU alone (initially 1, with "precision" 2); -1 follows the convolution (float32 exactly when
  * conv_mode is 1, so "conv_mode" 1 and "precision" 1 select the same thing), 0 / 1 force the split-f16 / the float32
  * form whatever the convolution does.  Reads back what the next prediction will run (0 / 1).  The float32 form costs
  * 5.3 x the matrix-core time of the split form (41 against 15 ms for one alignment of 2000 x 300, 196 against 72 ms

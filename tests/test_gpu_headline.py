@@ -9,6 +9,7 @@ Tolerances: CA-RMSD <= 1e-3 A and |dconf| < 1e-4 at minsteps=0 (BASELINE.json no
 minimiser max(1e-3, 3 x the reference's own 8-vs-1-thread deviation stored in the fixture).
 """
 import contextlib
+import ctypes as C
 import hashlib
 import io
 import os
@@ -643,9 +644,10 @@ def test_two_part_default_weights_route(synth_sd, tmp_path, monkeypatch, weights
 
 
 def test_drop_in_default_is_full_width_and_the_environment_selects_the_arithmetic(monkeypatch, weights_file, synth_sd):
-    """aln_to_coords / the CLI have no argument for the arithmetic.  Their default is option "precision" = 2 - the
-    reference computes in float32 (predict.py:136, network.py:25-31), so the drop-in carries float32's 24-bit operands
-    (three exact bf16 pieces, float32 vertical GRU) - and DMPFOLD_PRECISION selects the others: 1 = the f32 matrix-core
+    """aln_to_coords / the CLI have no argument for the arithmetic.  Their default - and that of a context made through
+    the C ABI or of an Engine - is option "precision" = 2: the reference computes in float32 (predict.py:136,
+    network.py:25-31), so float32's 24-bit operands (three exact bf16 pieces, float32 vertical GRU); DMPFOLD_PRECISION
+    selects the others (this suite's conftest sets it to 0 for every other test): 1 = the f32 matrix-core
     instructions, 0 = the fast 22-bit mode.  Each gives the bits of an engine set to that precision by hand; the three
     differ from each other by rounding only."""
     from dmpfold2_amd import predict as P
@@ -671,7 +673,14 @@ def test_drop_in_default_is_full_width_and_the_environment_selects_the_arithmeti
     e = P.Engine("cuda:0", alnmat.shape[1], alnmat.shape[0])
     try:
         e.set_weights({k: torch.from_numpy(np.array(v)) for k, v in synth_sd.items()})
-        assert e.get_option("precision") == 0              # an engine made directly starts in the library's setting
+        assert e.get_option("precision") == 2              # an engine made directly starts in the library's setting ...
+        raw = C.c_void_p()                                 # ... which is a context's own: full-width operands
+        lib = P._lib.load()
+        P._lib.check(lib.dmp_ctx_create(0, 64, 8, C.byref(raw)))
+        v = C.c_int(-5)
+        P._lib.check(lib.dmp_ctx_get_option(raw, b"precision", C.byref(v)))
+        lib.dmp_ctx_destroy(raw)
+        assert v.value == 2
         for prec in (0, 1, 2):
             e.set_option("precision", prec)
             c2, f2 = e.predict_checked(alnmat, None, 1, 0)
