@@ -427,7 +427,7 @@ def main(argv=None):
         prec = LEGS[name]["precision"]
         pipe.set_option("precision", prec)
         for e in pipe.engines:
-            assert e.get_option("precision") == prec and e.get_option("vgru_f32") == (1 if prec else 0)
+            assert e.get_option("precision") == prec and e.get_option("vgru_f32") == prec
         warm = pipe.run(targets[:warmup * B], ITERS, MINSTEPS)
         sync_all()
         cap = 16 * (ITERS + 1) * (steps * B // S + 2)

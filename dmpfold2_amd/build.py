@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libdmpfold_hip.so")
-SOURCES = ["api.hip", "pipeline.hip", "gemm.hip", "msa.hip", "dca.hip", "gru.hip", "vgru.hip", "vgru_f32.hip", "trunk.hip", "train.hip", "mds.hip",
+SOURCES = ["api.hip", "pipeline.hip", "gemm.hip", "msa.hip", "dca.hip", "gru.hip", "vgru.hip", "vgru_f32.hip", "vgru_x3.hip", "trunk.hip", "train.hip", "mds.hip",
            "coords.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # coords.hip: no SLP vectoriser = no packed-f32 instructions.  The vectoriser turns the cross products of the

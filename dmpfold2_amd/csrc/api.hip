@@ -473,6 +473,7 @@ int dmp_ctx_create(int device, int max_L, int max_N, dmp_ctx** out) {
     }
   A_(vgru_run, 256);                 // VRun (legacy) / VGroupRec (vgru.hip)
   A_(vgru_sync, 2048);               // VPSync (vgru.hip)
+  A_(vgru_wq, (int64_t)vgru_x3_stream_bytes());
   A_(vout, L * WIDTH);
   A_(seq_g, L * 1536);
   A_(seq_a, L * WIDTH);
@@ -550,16 +551,16 @@ int dmp_ctx_set_option(dmp_ctx* ctx, const char* name, int value) {
   if (k == "conv_tile_bands") { DMP_ARG(value >= 0 && value <= 2, "conv_tile_bands must be 0 (by length), 1 (16 x 16) or 2 (8 x 16)"); ctx->conv_tile_bands = value; return DMP_OK; }
   if (k == "vgru_persistent") { ctx->vgru_persist = value ? 1 : 0; return DMP_OK; }
   if (k == "vgru_debug_drop_wg") { ctx->vgru_debug_drop_wg = value ? 1 : 0; return DMP_OK; }     // tests only
-  if (k == "vgru_f32") { DMP_ARG(value >= -1 && value <= 1, "vgru_f32 must be -1 (follow conv_mode), 0 or 1"); ctx->vgru_f32 = value; return DMP_OK; }
+  if (k == "vgru_f32") { DMP_ARG(value >= -1 && value <= 2, "vgru_f32 must be -1 (follow conv_mode), 0, 1 or 2"); ctx->vgru_f32 = value; return DMP_OK; }
   if (k == "precision") {
     // 0: float32-grade split-f16 products in the convolutions and the vertical GRU (22-bit operands; the fast mode);
     // 1: the reference's arithmetic instruction for instruction - float32 MFMAs in both, library gate functions;
     // 2: full-width operands at the 16-bit matrix cores' rate - every float32 operand of the convolutions split EXACTLY
     //    into three bf16 pieces (3 x 8 = 24 significand bits), the six piece products above 2^-24 accumulated in float32
-    //    (conv_bf16.h), and the float32 vertical GRU of setting 1
-    DMP_ARG(value >= 0 && value <= 2, "precision must be 0 (split f16), 1 (float32 MFMA) or 2 (exact bf16 x 3 split + float32 GRU)");
+    //    (conv_bf16.h), and the vertical GRU the same way (vgru_x3.hip) with the library gate functions of setting 1
+    DMP_ARG(value >= 0 && value <= 2, "precision must be 0 (split f16), 1 (float32 MFMA) or 2 (exact bf16 x 3 split)");
     ctx->conv_mode = value;
-    ctx->vgru_f32 = value == 2 ? 1 : -1;
+    ctx->vgru_f32 = value == 2 ? 2 : -1;
     return DMP_OK;
   }
   if (k == "conv_mode") {
@@ -584,7 +585,7 @@ int dmp_ctx_get_option(const dmp_ctx* ctx, const char* name, int* h_value) {
   if (k == "vgru_f32") { *h_value = vgru_runs_f32(ctx); return DMP_OK; }          // what the next prediction will run
   if (k == "precision") {                                                          // 0 / 1 / 2, or -1 for a mixed setting
     const int v = vgru_runs_f32(ctx);
-    *h_value = (ctx->conv_mode == 1 && v) ? 1 : ((ctx->conv_mode == 2 && v) ? 2 : ((ctx->conv_mode == 0 && !v) ? 0 : -1));
+    *h_value = ctx->conv_mode == v ? v : -1;
     return DMP_OK;
   }
   // read-only: 1 once every launch of the group chain this context leads has been issued (the scheduler hands the

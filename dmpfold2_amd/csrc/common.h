@@ -154,13 +154,15 @@ struct dmp_ctx {
   uint16_t* hH[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // same state as f16 pieces [2][64][Lb][8]
   uint8_t* vgru_run = nullptr;             // device VRun / VRun2 record read by the graph's step kernels
   uint8_t* vgru_sync = nullptr;            // VPSync of the persistent chain (vgru.hip): XCD arrival counters, row flags
+  uint8_t* vgru_wq = nullptr;              // vgru_x3.hip: the weight pieces its waves stream (written at every launch), 24 MiB
   int vgru_persist = 1;                    // option "vgru_persistent": the chain as ONE weight-stationary launch (0: one launch per row)
   bool vgru_persist_ok = false;            // the device has the 256 CUs the persistent form is laid out for
   int vgru_debug_drop_wg = 0;              // TEST option "vgru_debug_drop_wg": launch the persistent chain one workgroup short (its row
                                            // barrier must time out ONCE, raise DMP_FAULT_VGRU_HANDOFF and leave the row loop)
-  int vgru_f32 = 1;                        // option "vgru_f32": 1 = float32 MFMAs + library gates (vgru_f32.hip), 0 = split-f16
-                                           // products, -1 = follow the convolution: float32 with conv_mode 1.  A context
-                                           // starts in option "precision" 2: conv_mode 2 + vgru_f32 1 (round 6)
+  int vgru_f32 = 2;                        // option "vgru_f32": 2 = full-width operands as three bf16 pieces + library gates
+                                           // (vgru_x3.hip), 1 = float32 MFMAs + library gates (vgru_f32.hip), 0 = split-f16
+                                           // products, -1 = follow the convolution: float32 with conv_mode 1, else split-f16.
+                                           // A context starts in option "precision" 2: conv_mode 2 + vgru_f32 2 (round 6)
   int vg_ntiles = 0, vg_maxN = 0;          // group this context leads (vgru.hip): column tiles, deepest member alignment
   int vg_tile0[8] = {0};                   // ... first column tile of every member
   int vg_cap_cols = 0;                     // columns the state buffers hold (a group's members side by side)
@@ -293,8 +295,10 @@ int gru_vertical_steps(dmp_ctx* c, const uint8_t* d_msa, int N, int L, int t_lo,
 // records of all members into the leader's buffer and clears their states, steps runs rows [t_lo, t_hi), output
 // hands a member its L x 512 result.
 int vgru_kernel_attrs(dmp_ctx* c);
-// the vertical GRU of this context's next prediction runs in float32 (vgru_f32.hip) - option "vgru_f32", or following
-// the convolution's mode when that option is -1
+size_t vgru_x3_stream_bytes();            // size of dmp_ctx::vgru_wq (vgru_x3.hip)
+// the arithmetic of the vertical GRU of this context's next prediction: 0 split-f16 (vgru.hip), 1 float32 MFMAs
+// (vgru_f32.hip), 2 three exact bf16 pieces per operand (vgru_x3.hip) - option "vgru_f32", or following the convolution's
+// mode when that option is -1
 inline int vgru_runs_f32(const dmp_ctx* c) { return c->vgru_f32 >= 0 ? c->vgru_f32 : (c->conv_mode == 1 ? 1 : 0); }
 // Kernels whose workgroups wait for EACH OTHER inside the launch - the cluster kernels (sequence GRU, minimiser,
 // cluster tridiagonalisation: 32 workgroups that hand values over) and the persistent vertical GRU (256 workgroups

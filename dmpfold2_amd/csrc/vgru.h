@@ -1,5 +1,5 @@
-// Declarations shared by the two translation units of the vertical GRU (vgru.hip: split-f16 products, the default;
-// vgru_f32.hip: the reference's float32 arithmetic).
+// Declarations shared by the three translation units of the vertical GRU (vgru.hip: split-f16 products, the fast mode;
+// vgru_f32.hip: the reference's float32 instructions; vgru_x3.hip: full-width operands as three bf16 pieces, the default).
 #pragma once
 #include "common.h"
 
@@ -56,5 +56,8 @@ constexpr unsigned VP_BARRIER_SPINS_FIRST = 8u * VP_BARRIER_SPINS;
 // vgru_f32.hip: rows [t_lo, t_hi) of the group set up on `lead` in float32 (option "vgru_f32")
 int vgru_f32_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s);
 int vgru_f32_kernel_attrs(dmp_ctx* c);
+// vgru_x3.hip: the same rows with every float32 operand as three exact bf16 pieces (option "vgru_f32" = 2)
+int vgru_x3_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s);
+int vgru_x3_kernel_attrs(dmp_ctx* c);
 
 }  // namespace dmp

@@ -794,7 +794,8 @@ int vgru_kernel_attrs(dmp_ctx* c) {
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
   DMP_HIP(hipFuncSetAttribute((const void*)vgru2_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, VG2_LDS_BYTES));
-  return vgru_f32_kernel_attrs(c);
+  if (int rc = vgru_f32_kernel_attrs(c)) return rc;
+  return vgru_x3_kernel_attrs(c);
 }
 
 // Group record of n member alignments (their column tiles one after the other in the LEADER's state buffers)
@@ -843,6 +844,7 @@ int vgru_group_steps(dmp_ctx* lead, int t_lo, int t_hi, hipStream_t s) {
   if (t_hi > lead->vg_maxN + 1) t_hi = lead->vg_maxN + 1;
   if (t_lo < 0) t_lo = 0;
   if (t_lo & 1) { set_error("vertical-GRU chunks start at even rows (got %d)", t_lo); return DMP_ERR_ARG; }
+  if (vgru_runs_f32(lead) == 2) return vgru_x3_group_steps(lead, t_lo, t_hi, s);
   if (vgru_runs_f32(lead)) return vgru_f32_group_steps(lead, t_lo, t_hi, s);
   VGroupRec* rec = reinterpret_cast<VGroupRec*>(lead->vgru_run);
   if (lead->vgru_persist && lead->vgru_persist_ok) {

@@ -97,13 +97,14 @@ void dmp_ctx_destroy(dmp_ctx* ctx);
  * (v_mfma_f32_16x16x4_f32 products, the device library's expf / tanhf in the gates: nn.GRU in float32, network.py:189,
  * 223-224); with it no f16 / bf16 matrix-core kernel runs; 2 (round 6) = FULL-WIDTH operands at the 16-bit matrix cores'
  * rate - conv_mode 2 (every float32 operand as three exact bf16 pieces = 24 significand bits, the six piece products
- * above 2^-24 accumulated in float32) and the float32 vertical GRU of setting 1: A CONTEXT'S INITIAL SETTING (the
+ * above 2^-24 accumulated in float32) and the vertical GRU the same way ("vgru_f32" 2: three bf16 pieces per operand
+ * of its three products, float32 accumulation, the library gate functions of setting 1): A CONTEXT'S INITIAL SETTING (the
  * reference computes in float32: predict.py:136, network.py:25-31) and what the drop-in entry points run; 1.7 x the
  * speed of setting 1.
  * Reads back 0 / 1 / 2, or -1 for a mixed setting.
- * "vgru_f32" = -1 / 0 / 1: the vertical GRU alone (initially 1, with "precision" 2); -1 follows the convolution (float32 exactly when
- * conv_mode is 1, so "conv_mode" 1 and "precision" 1 select the same thing), 0 / 1 force the split-f16 / the float32
- * form whatever the convolution does.  Reads back what the next prediction will run (0 / 1).  The float32 form costs
+ * "vgru_f32" = -1 / 0 / 1 / 2: the vertical GRU alone (initially 2, with "precision" 2); -1 follows the convolution (float32 exactly when
+ * conv_mode is 1, so "conv_mode" 1 and "precision" 1 select the same thing), 0 / 1 / 2 force the split-f16 / the float32
+ * / the three-piece bf16 form whatever the convolution does.  Reads back what the next prediction will run (0 / 1 / 2).  The float32 form costs
  * 5.3 x the matrix-core time of the split form (41 against 15 ms for one alignment of 2000 x 300, 196 against 72 ms
  * for a chain of eight); its fallback without the persistent launch ("vgru_persistent" = 0) is the same kernel, one
  * launch per row, the same bits.

@@ -477,10 +477,11 @@ def test_largest_length_end_to_end(synth_sd, oracle_weights):
         idxm = torch.from_numpy(msa.astype(np.int64))
         vr = O._gru(oracle_weights, "vgru", oracle_weights["embed.weight"][idxm], 22, 512, 2, False, False)[-1].numpy()
         assert np.abs(v - vr).max() < 1e-5
-        st.eng.set_option("vgru_f32", 1)                   # the float32 form at the largest length (64 tiles, 8 per XCD)
-        v32 = st.gru_vertical(msa).cpu().numpy()
-        st.eng.set_option("vgru_f32", -1)
-        assert np.abs(v32 - vr).max() < 3e-6
+        for form in (1, 2):                                # the float32 / three-piece bf16 forms at the largest length (64 tiles, 8 per XCD)
+            st.eng.set_option("vgru_f32", form)
+            v32 = st.gru_vertical(msa).cpu().numpy()
+            st.eng.set_option("vgru_f32", -1)
+            assert np.abs(v32 - vr).max() < 3e-6, form
         coords, confs = st.eng.predict(msa, None, 1, 10)
         st.eng.sync_check()
         c, f = coords.cpu().numpy(), confs.cpu().numpy()

@@ -663,7 +663,7 @@ def test_drop_in_default_is_full_width_and_the_environment_selects_the_arithmeti
             monkeypatch.setenv("DMPFOLD_PRECISION", env)
         c, f = P.aln_to_coords(aln, device="cuda:0", iterations=1, minsteps=0, weights_file=weights_file)
         eng = P._ENGINES[0]
-        assert eng.get_option("precision") == want and eng.get_option("vgru_f32") == (1 if want else 0)
+        assert eng.get_option("precision") == want and eng.get_option("vgru_f32") == want
         assert eng.get_option("conv_mode") == want
         if want in got:
             assert torch.equal(got[want][0], c) and torch.equal(got[want][1], f)       # unset == "2"

@@ -589,7 +589,7 @@ def test_throughput_pipeline_matches_single_engine(st_engine, synth_sd):
 
 @pytest.mark.parametrize("persistent", [1, 0])
 @pytest.mark.parametrize("group,riders,precision", [(1, 4, 0), (2, 4, 0), (4, 4, 0), (4, 0, 0), (2, 6, 0), (3, 2, 0), (4, 7, 0),
-                                                    (4, 4, 1), (2, 6, 1)])
+                                                    (4, 4, 1), (2, 6, 1), (4, 4, 2), (2, 6, 2)])
 def test_grouped_vertical_gru_is_bitwise_the_ungrouped_one(synth_sd, monkeypatch, group, riders, persistent, precision):
     """dmp_predict_group_vgru: predictions that start together run their vertical GRUs as ONE chain (the group
     leader's units) - ragged in L and N, a one-row alignment among them, more targets than engines, so groups of every
@@ -687,7 +687,7 @@ def test_persistent_vertical_gru_vs_oracle_and_launch_chain(st_engine, synth_sd,
 def test_float32_vertical_gru_is_the_references_arithmetic(st_engine, synth_sd, oracle_weights):
     """Round 5: option "precision" = 1 runs the vertical GRU on float32 MFMAs with library gate
     functions (vgru_persist_f32_kernel) - nn.GRU's arithmetic (network.py:189, 223-224) - together with the exact-f32
-    convolution.  Against the oracle's nn.GRU on a ragged group at a TIGHTER bound than the split-f16 form's 1e-5; the
+    convolution; round 6: "precision" = 2 runs it with full-width operands on the bf16 matrix cores (vgru_persist_x3_kernel).  Against the oracle's nn.GRU on a ragged group at a TIGHTER bound than the split-f16 form's 1e-5; the
     launch-per-row fallback is the same kernel without the barrier: the same bits; a member's bits do not depend on its
     group; the option reads back; "vgru_f32" overrides it per context."""
     import ctypes as C
@@ -716,43 +716,54 @@ def test_float32_vertical_gru_is_the_references_arithmetic(st_engine, synth_sd, 
     try:
         assert eng.get_option("precision") == 0 and eng.get_option("vgru_f32") == 0
         split = chain(msas, 1)
-        eng.set_option("precision", 1)
-        assert eng.get_option("precision") == 1 and eng.get_option("vgru_f32") == 1 and eng.get_option("conv_mode") == 1
-        grouped = chain(msas, 1)
-        assert eng.sync_faults() == 0
-        rows = chain(msas, 0)
-        worst = 0.0
-        for m, a, b, h in zip(msas, grouped, rows, split):
-            x = oracle_weights["embed.weight"][torch.from_numpy(m.astype(np.int64))]
-            ref = O._gru(oracle_weights, "vgru", x, 22, 512, 2, False, False)[-1]
-            with torch.no_grad():
-                ref64 = g64(x.double())[0][-1]
-            worst = max(worst, float((a.cpu() - ref).abs().max()))
-            assert float((a.cpu() - ref).abs().max()) < 3e-6, m.shape          # float32 against float32
-            # ... and as close to the float64 recurrence as the reference's own float32 run is (x 2)
-            assert float((a.cpu().double() - ref64).abs().max()) <= 2.0 * float((ref.double() - ref64).abs().max()) + 1e-7
-            assert torch.equal(a, b), m.shape                                  # per-row launches: the same kernel
-            assert float((a - h).abs().max()) < 1e-5 and not torch.equal(a, h)  # the split-f16 form is another arithmetic
-        print("float32 vertical GRU: max |dev| from the oracle's nn.GRU", worst)
-        for i, m in enumerate(msas):
-            alone = chain([m], 1)[0]
-            assert torch.equal(alone, grouped[i]), i
-            pair = chain([msas[(i + 1) % len(msas)], m], 1)[1]
-            assert torch.equal(pair, grouped[i]), i
-        assert eng.sync_faults() == 0
-        # "vgru_f32" overrides: float32 convolutions with the split-f16 GRU (the round-4 meaning of conv_mode 1) ...
+        results = {}
+        # precision 1: float32 MFMAs (vgru_f32.hip); precision 2 (round 6): every operand as three exact bf16 pieces, six
+        # piece products (vgru_x3.hip) - both with the library gate functions, both held to the same bounds
+        for precision in (1, 2):
+            eng.set_option("precision", precision)
+            assert eng.get_option("precision") == precision and eng.get_option("vgru_f32") == precision
+            assert eng.get_option("conv_mode") == precision
+            grouped = chain(msas, 1)
+            assert eng.sync_faults() == 0
+            rows = chain(msas, 0)
+            worst = 0.0
+            for m, a, b, h in zip(msas, grouped, rows, split):
+                x = oracle_weights["embed.weight"][torch.from_numpy(m.astype(np.int64))]
+                ref = O._gru(oracle_weights, "vgru", x, 22, 512, 2, False, False)[-1]
+                with torch.no_grad():
+                    ref64 = g64(x.double())[0][-1]
+                worst = max(worst, float((a.cpu() - ref).abs().max()))
+                assert float((a.cpu() - ref).abs().max()) < 3e-6, m.shape          # float32 against float32
+                # ... and as close to the float64 recurrence as the reference's own float32 run is (x 2)
+                assert float((a.cpu().double() - ref64).abs().max()) <= 2.0 * float((ref.double() - ref64).abs().max()) + 1e-7
+                assert torch.equal(a, b), m.shape                                  # per-row launches: the same kernel
+                assert float((a - h).abs().max()) < 1e-5 and not torch.equal(a, h)  # the split-f16 form is another arithmetic
+            print("vertical GRU, precision", precision, ": max |dev| from the oracle's nn.GRU", worst)
+            for i, m in enumerate(msas):
+                alone = chain([m], 1)[0]
+                assert torch.equal(alone, grouped[i]), i
+                pair = chain([msas[(i + 1) % len(msas)], m], 1)[1]
+                assert torch.equal(pair, grouped[i]), i
+            assert eng.sync_faults() == 0
+            results[precision] = grouped
+        assert not torch.equal(results[1][0], results[2][0])                       # two arithmetics ...
+        assert float((results[1][0] - results[2][0]).abs().max()) < 2e-6           # ... of the same width
+        # "vgru_f32" overrides: the exact convolutions with the split-f16 GRU ...
         eng.set_option("vgru_f32", 0)
         assert eng.get_option("precision") == -1
         assert torch.equal(chain(msas[:2], 1)[0], split[0])
+        # ... or with the float32-MFMA GRU (the round-6 headline before vgru_x3.hip)
+        eng.set_option("vgru_f32", 1)
+        assert eng.get_option("precision") == -1 and eng.get_option("conv_mode") == 2
+        assert torch.equal(chain(msas[:2], 1)[0], results[1][0])
         # ... and back to following the convolution's mode
         eng.set_option("precision", 0)
         assert eng.get_option("precision") == 0 and eng.get_option("conv_mode") == 0
         assert torch.equal(chain(msas[:2], 1)[0], split[0])
-        # precision 2 (round 6): the exact three-piece bf16 convolution WITH the float32 vertical GRU; conv_mode 2 alone (the
-        # range fallback of the fast mode) keeps the split-f16 GRU and reads back as a mixed setting
         eng.set_option("precision", 2)
-        assert eng.get_option("precision") == 2 and eng.get_option("conv_mode") == 2 and eng.get_option("vgru_f32") == 1
-        assert torch.equal(chain(msas[:2], 1)[0], grouped[0])
+        assert eng.get_option("precision") == 2 and eng.get_option("conv_mode") == 2 and eng.get_option("vgru_f32") == 2
+        assert torch.equal(chain(msas[:2], 1)[0], results[2][0])
+        # conv_mode 2 alone (the range fallback of the fast mode) keeps the split-f16 GRU and reads back as a mixed setting
         eng.set_option("precision", 0)
         eng.set_option("conv_mode", 2)
         assert eng.get_option("precision") == -1 and eng.get_option("vgru_f32") == 0

@@ -24,5 +24,6 @@ cd $R
 DMPFOLD_PRECISION=2 timeout 600 python tools/lane_trace.py > $O/lane_trace_p2.txt 2>&1
 timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 timeout 1500 python tools/bench_configs.py --skip-c5-f32 > $O/configs.jsonl 2> $O/configs.err
-DMPFOLD_PRECISION=2 VGRU_F32=1 timeout 600 python tools/time_vgru_persist.py 8 300 2000 > $O/vgru_f32.txt 2>&1
+VGRU_F32=1 timeout 600 python tools/time_vgru_persist.py 8 300 2000 > $O/vgru_f32.txt 2>&1
+VGRU_F32=2 timeout 600 python tools/time_vgru_persist.py 8 300 2000 > $O/vgru_x3.txt 2>&1
 tail -c 600 $O/bench.json; tail -4 $O/single_run_noprof_p2.txt; head -30 $O/single_timeline_p2.txt

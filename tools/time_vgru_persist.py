@@ -3,7 +3,7 @@
 launch chain of rounds 2-3 (= 0): results (max |difference|, grouping bit-identity, a small case against the oracle's
 nn.GRU) and the time of one chain serving k = 1 .. K targets.
 
-    [VGRU_F32=1] python tools/time_vgru_persist.py [K=8] [L=300] [N=2000]
+    [VGRU_F32=0|1|2] python tools/time_vgru_persist.py [K=8] [L=300] [N=2000]
 """
 import ctypes as C
 import os
@@ -27,8 +27,8 @@ sd = {k: torch.from_numpy(np.array(v)) for k, v in synth.synth_weights(0, coord_
 lead = Engine(dev, L, N, stream=torch.cuda.Stream(dev))
 lead.set_weights(sd)
 lib = lead.lib
-if os.environ.get("VGRU_F32") == "1":                    # the float32 form (vgru_f32.hip) instead of the split-f16 one
-    lead.set_option("vgru_f32", 1)
+# VGRU_F32: 0 the split-f16 form, 1 float32 MFMAs (vgru_f32.hip), 2 three bf16 pieces per operand (vgru_x3.hip)
+lead.set_option("vgru_f32", int(os.environ.get("VGRU_F32", "0")))
 print("persistent form available:", lead.get_option("vgru_persistent"), " float32:", lead.get_option("vgru_f32"), flush=True)
 
 
