@@ -18,10 +18,11 @@ HIP-event intervals around every convolution launch (recorded on the launching s
   * `value` / `roofline` / `dtype` - THE HEADLINE: option "precision" 2, full-width operands at the 16-bit matrix cores'
     rate.  Every float32 operand of the convolutions is split EXACTLY into three bf16 pieces (3 x 8 = the 24 significand
     bits of a float32), the six piece products above 2^-24 are accumulated in float32 (conv5x5_bf16x6_kernel), and the
-    vertical GRU runs on the f32 matrix cores with library gate functions.  Priced against the dense bf16 peak / 6.
+    vertical GRU's three products are computed the same way (vgru_persist_x3_kernel) with library gate functions.
+    Priced against the dense bf16 peak / 6.
     The full --steps / --warmup;
   * `value_f32` / `roofline_f32`: option "precision" 1 - the reference's instruction for instruction: the f32 MFMA
-    convolution (bitwise an fmaf chain) and the same float32 vertical GRU; no 16-bit matrix-core kernel runs in this leg;
+    convolution (bitwise an fmaf chain) and the float32-MFMA vertical GRU; no 16-bit matrix-core kernel runs in this leg;
     priced against the 157.3 TFLOP/s f32 matrix-core peak (SURVEY 8d);
   * `value_split_f16` / `roofline_split_f16`: option "precision" 0, the FAST mode - two f16 pieces per operand (22-23
     significand bits: narrower than float32's 24, so this number is never the metric), 3 f16 MFMA products.
@@ -59,7 +60,8 @@ LEGS = {
                          "bf16 pieces = 24 significand bits, six bf16 MFMA products per float32 product, float32 accumulate)",
                "dtype": "f32 with full-width operands on the bf16 matrix cores (option precision = 2): convolution operands "
                         "split exactly into 3 bf16 pieces (24 significand bits), the 6 piece products above 2^-24 accumulated "
-                        "in f32 by v_mfma_f32_32x32x16_bf16; vertical GRU on v_mfma_f32_16x16x4_f32 with library expf / tanhf; "
+                        "in f32 by v_mfma_f32_32x32x16_bf16; vertical GRU the same way (3 bf16 pieces per operand, 6 products on "
+                        "v_mfma_f32_16x16x32_bf16) with library expf / tanhf; "
                         "everything else f32 (f64 statistics and eigensolver)",
                "pmc": "conv5x5_bf16_pmc.json", "src": "dmpfold2_amd/csrc/conv_bf16.h"},
     "f32": {"precision": 1, "sfx": "_f32", "peak": PEAK_F32_MFMA_TFLOPS, "products": 1,

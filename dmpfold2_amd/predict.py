@@ -163,8 +163,8 @@ def raise_for_faults(bits):
 def _env_precision():
     """DMPFOLD_PRECISION selects the arithmetic (option "precision" of include/dmpfold_hip.h) for the drop-in entry points -
     aln_to_coords, the CLI, the batch front end - which have no argument for it:
-      2  full-width operands on the 16-bit matrix cores: the convolutions' float32 operands as three exact bf16 pieces (24
-         significand bits, six products), float32 vertical GRU;
+      2  full-width operands on the 16-bit matrix cores: the float32 operands of the convolutions and of the vertical GRU
+         as three exact bf16 pieces (24 significand bits, six products);
       1  the reference's instructions: float32 matrix-core convolutions and vertical GRU (about half the speed of 2);
       0  the fast mode: two f16 pieces per operand (22-23 significand bits), about 1.8 x the speed of 2.
     Unset = the library's default."""

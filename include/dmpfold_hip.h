@@ -28,8 +28,8 @@ extern "C" {
 #endif
 
 /* 5 (round 6): 65 functions.  New: the dmp_pipeline_* family (16 functions) - the throughput scheduler behind the C ABI;
- *    option "precision" accepts 2 (exact three-piece bf16 convolution + float32 vertical GRU: full-width operands at the
- *    16-bit matrix cores' rate).
+ *    option "precision" accepts 2 (exact three-piece bf16 convolution and vertical GRU: full-width operands at the
+ *    16-bit matrix cores' rate; "vgru_f32" accepts 2 for the latter alone).
  * 4 (round 5): 49 functions.  New: dmp_block_conv5x5_maxout_winners (the training slice's forward: maxout output + the
  *    winners autograd saves), dmp_head_conv_bwd, dmp_stem_maxout_winners and dmp_stem_bwd; dmp_block_conv5x5_maxout_bwd takes the saved winners (d_idx, NULL = run
  *    the forward again: the ABI-3 behaviour).  New options: precision (0 split-f16 / 1 the reference's float32 end to end),

@@ -735,13 +735,13 @@ def test_aln_to_coords_is_reentrant_two_threads_two_weight_files(tmp_path, synth
     P._ENGINES.clear()
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 def test_missing_workgroup_of_the_persistent_chain_times_out_once_and_falls_back(synth_sd, capsys, precision):
     """a workgroup of the persistent vertical GRU that is missing for good - another process holds CUs -
     used to make EVERY row wait the full spin bound again (hours at N = 3000).  With the test option the chain is launched
     one workgroup short: the row barrier of one XCD times out once, DMP_FAULT_VGRU_HANDOFF is raised, the kernel leaves
-    its row loop, and predict_checked repeats with one launch per row - within seconds, with the right answer, in both
-    arithmetic settings."""
+    its row loop, and predict_checked repeats with one launch per row - within seconds, with the right answer, in all
+    three arithmetic settings."""
     import time
     from dmpfold2_amd import synth
     from dmpfold2_amd.predict import Engine, encode_aln, FAULT_VGRU_HANDOFF
