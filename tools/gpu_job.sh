@@ -1,4 +1,6 @@
 #!/bin/bash
+# scratch GPU job of a session: gpurun -- 'bash tools/gpu_job.sh'.  Every step under its own timeout; outputs under gpurun_out/job/.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/job; mkdir -p $OUT
-VGRU_F32=2 timeout 600 python tools/time_vgru_persist.py 8 300 2000 > $OUT/vgru_x3.txt 2>&1; grep -E "oracle|=1: one chain|faults|bits" $OUT/vgru_x3.txt | cut -c1-600
+timeout 2700 python -m pytest tests -x -q -m gpu > $OUT/all.log 2>&1; tail -5 $OUT/all.log | cut -c1-300
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
